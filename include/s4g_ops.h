@@ -1,0 +1,132 @@
+/*
+ * s4g_ops.h -- C ABI of libs4g_hip.so, the MI355X (gfx950) replacement for the
+ * reference's pybind11 extension `pn2_ext`.
+ *
+ * Reference interface replaced (paths relative to
+ * /root/reference/inference/grasp_proposal/network_models/models/pointnet2_utils/):
+ *   csrc/main.cpp:6-14 registers seven at::Tensor functions; each entry point
+ *   below cites the prototype it replaces.  The reference's Python wrappers
+ *   (functions.py:42,72,99,105,127,163,170) are the only callers.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain device pointers and int64 sizes, no torch types.
+ *   - return 0 on success, <0 = S4G_E* argument error (nothing launched),
+ *     >0 = hipError_t from the launch.  No exceptions, no allocation, no
+ *     host synchronisation, no global state; re-entrant.
+ *   - the caller owns every buffer (outputs and workspace) and passes the HIP
+ *     stream to launch on (hipStream_t as void*; NULL = default stream) --
+ *     the reference launches on the legacy default stream with no guard.
+ *   - clouds are channel-first fp32 exactly as the Python API hands them over,
+ *     (B,3,N) contiguous; the reference's internal (B,N,3) transposed copies
+ *     (sampling_kernel.cu:141, ball_query_kernel.cu:105-106,
+ *     interpolate_kernel.cu:111-112) are not made.
+ *   - indices are int64 as in the reference (AT kLong outputs).
+ *   - `flags`: bit 0 (S4G_FLAG_FMAD) selects the distance arithmetic.
+ *       0: every fp32 op rounded separately, d = ((dx*dx)+(dy*dy))+(dz*dz)
+ *          (canonical; what the oracle and all parity tests use)
+ *       1: emulate nvcc's default -fmad contraction,
+ *          d = fma(dz,dz, fma(dy,dy, dx*dx)).
+ */
+#ifndef S4G_OPS_H_
+#define S4G_OPS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S4G_ABI_VERSION 1
+
+#define S4G_OK 0
+#define S4G_EINVAL (-1)     /* bad size / null pointer */
+#define S4G_EWORKSPACE (-2) /* workspace too small */
+#define S4G_EUNSUPPORTED (-3)
+
+#define S4G_FLAG_FMAD 1
+
+typedef void *s4g_stream_t; /* hipStream_t */
+
+/* operator ids for s4g_workspace_bytes */
+#define S4G_OP_FPS 1
+#define S4G_OP_BALL_QUERY 2
+#define S4G_OP_THREE_NN 3
+
+int s4g_abi_version(void);
+const char *s4g_error_string(int code);
+
+/* Bytes of device scratch an operator needs for the given problem
+ * (0 if none).  dims: FPS (B,N,M,0); BALL_QUERY (B,N,M,K); THREE_NN (B,N1,N2,0). */
+size_t s4g_workspace_bytes(int op, int64_t B, int64_t d0, int64_t d1, int64_t d2);
+
+/* FarthestPointSample(points (B,3,N), num_centroids) -> index (B,M) int64
+ * replaces csrc/sampling.h:7-9, csrc/sampling_kernel.cu:128-172.
+ * Requires M > 0, N >= M (sampling_kernel.cu:137-139).  idx[b,0] = 0. */
+int s4g_fps_f32(const float *xyz_b3n, int64_t B, int64_t N, int64_t M,
+                int64_t *idx_bm, void *ws, size_t ws_bytes, int flags,
+                s4g_stream_t stream);
+
+/* BallQuery(points (B,3,N), centroids (B,3,M), radius, K)
+ *   -> index (B,M,K) int64, count (B,M) int64
+ * replaces csrc/ball_query.h:7-11, csrc/ball_query_kernel.cu:89-133.
+ * Outputs are fully written (rows without any hit are zero, as the
+ * reference's at::zeros leaves them). */
+int s4g_ball_query_f32(const float *xyz_b3n, const float *ctr_b3m, int64_t B,
+                       int64_t N, int64_t M, float radius, int64_t K,
+                       int64_t *idx_bmk, int64_t *cnt_bm, void *ws,
+                       size_t ws_bytes, int flags, s4g_stream_t stream);
+
+/* GroupPointsForward(input (B,C,N), index (B,M,K)) -> (B,C,M,K)
+ * replaces csrc/grouping.h:7-9, csrc/grouping_kernel.cu:32-54. */
+int s4g_group_points_f32(const float *in_bcn, const int64_t *idx_bmk, int64_t B,
+                         int64_t C, int64_t N, int64_t M, int64_t K,
+                         float *out_bcmk, s4g_stream_t stream);
+
+/* GroupPointsBackward(grad_output (B,C,M,K), index, N) -> grad_input (B,C,N)
+ * replaces csrc/grouping.h:11-14, csrc/grouping_kernel.cu:106-152.
+ * grad_in is zeroed by the call, then scatter-added (fp32 atomics). */
+int s4g_group_points_backward_f32(const float *gout_bcmk,
+                                  const int64_t *idx_bmk, int64_t B, int64_t C,
+                                  int64_t N, int64_t M, int64_t K,
+                                  float *gin_bcn, s4g_stream_t stream);
+
+/* gather_points(points (B,C,N), index (B,M)) -> (B,C,M)
+ * replaces the torch.gather in functions.py:10-25. */
+int s4g_gather_points_f32(const float *in_bcn, const int64_t *idx_bm, int64_t B,
+                          int64_t C, int64_t N, int64_t M, float *out_bcm,
+                          s4g_stream_t stream);
+
+/* PointSearch(query (B,3,N1), key (B,3,N2), 3)
+ *   -> index (B,N1,3) int64, SQUARED distance (B,N1,3) fp32
+ * replaces csrc/interpolate.h:8-11, csrc/interpolate_kernel.cu:92-132.
+ * Requires N2 >= 3 (interpolate_kernel.cu:106). */
+int s4g_three_nn_f32(const float *q_b3n1, const float *k_b3n2, int64_t B,
+                     int64_t N1, int64_t N2, int64_t *idx_bn3, float *d2_bn3,
+                     void *ws, size_t ws_bytes, int flags, s4g_stream_t stream);
+
+/* InterpolateForward(input (B,C,N2), index (B,N1,3), weight (B,N1,3))
+ *   -> (B,C,N1)
+ * replaces csrc/interpolate.h:13-16, csrc/interpolate_kernel.cu:191-236. */
+int s4g_three_interpolate_f32(const float *feat_bcn2, const int64_t *idx_bn3,
+                              const float *w_bn3, int64_t B, int64_t C,
+                              int64_t N2, int64_t N1, float *out_bcn1,
+                              int flags, s4g_stream_t stream);
+
+/* InterpolateBackward(grad_output (B,C,N1), index, weight, N2) -> (B,C,N2)
+ * replaces csrc/interpolate.h:18-22, csrc/interpolate_kernel.cu:296-341. */
+int s4g_three_interpolate_backward_f32(const float *gout_bcn1,
+                                       const int64_t *idx_bn3,
+                                       const float *w_bn3, int64_t B, int64_t C,
+                                       int64_t N2, int64_t N1, float *gin_bcn2,
+                                       s4g_stream_t stream);
+
+/* Inverse-distance weights of FeatureInterpolator.forward
+ * (modules.py:118-120): w = (1/max(d2,eps)) / sum_k (1/max(d2,eps)). */
+int s4g_interp_weights_f32(const float *d2_bn3, int64_t B, int64_t N1,
+                           float eps, float *w_bn3, s4g_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S4G_OPS_H_ */

@@ -1,0 +1,184 @@
+"""ctypes/numpy front-end of the CPU oracle (``oracle/s4g_oracle.c``).
+
+TEST INFRASTRUCTURE ONLY -- see the header of ``s4g_oracle.c``.  Only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import this module, and only as the checker / reported CPU baseline.  The
+product package (``s4g_release_amd``) never imports it.
+
+Every function takes and returns numpy arrays in the reference's Python-level
+layouts (``(B,3,N)`` fp32 clouds, int64 indices) and mirrors one reference
+operator (PN2U = inference/grasp_proposal/network_models/models/pointnet2_utils):
+
+  fps / fps_literal     PN2U/csrc/sampling_kernel.cu:49-172
+  ball_query            PN2U/csrc/ball_query_kernel.cu:33-133
+  group_points(+bwd)    PN2U/csrc/grouping_kernel.cu:32-152
+  gather_points         PN2U/functions.py:10-25
+  three_nn              PN2U/csrc/interpolate_kernel.cu:32-132
+  three_interpolate(+bwd) PN2U/csrc/interpolate_kernel.cu:138-341
+  interp_weights        PN2U/modules.py:118-120
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libs4g_oracle.so")
+_lib = None
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_i64 = ctypes.c_int64
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (no GPU needed)."""
+    src = os.path.join(_HERE, "s4g_oracle.c")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libs4g_oracle.so"],
+                          stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        L = _lib
+        for name in ("s4g_oracle_fps", "s4g_oracle_fps_literal"):
+            getattr(L, name).argtypes = [_f32p, _i64, _i64, _i64, _i64p, ctypes.c_int]
+        L.s4g_oracle_ball_query.argtypes = [_f32p, _f32p, _i64, _i64, _i64, ctypes.c_float,
+                                            _i64, _i64p, _i64p, ctypes.c_int]
+        L.s4g_oracle_group_points.argtypes = [_f32p, _i64p, _i64, _i64, _i64, _i64, _i64, _f32p]
+        L.s4g_oracle_group_points_backward.argtypes = [_f32p, _i64p, _i64, _i64, _i64, _i64, _i64, _f32p]
+        L.s4g_oracle_gather_points.argtypes = [_f32p, _i64p, _i64, _i64, _i64, _i64, _f32p]
+        L.s4g_oracle_three_nn.argtypes = [_f32p, _f32p, _i64, _i64, _i64, _i64p, _f32p, ctypes.c_int]
+        L.s4g_oracle_three_interpolate.argtypes = [_f32p, _i64p, _f32p, _i64, _i64, _i64, _i64,
+                                                   _f32p, ctypes.c_int]
+        L.s4g_oracle_three_interpolate_backward.argtypes = [_f32p, _i64p, _f32p, _i64, _i64, _i64,
+                                                            _i64, _f32p]
+        L.s4g_oracle_interp_weights.argtypes = [_f32p, _i64, _i64, ctypes.c_float, _f32p]
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i64a(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f32p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_i64p)
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("oracle %s failed with code %d" % (what, rc))
+
+
+def fps(points, num_centroids, fmad=0, literal=False):
+    points = _f32(points)
+    B, C, N = points.shape
+    if C != 3:
+        raise RuntimeError("points.size(1) must be 3")
+    idx = np.zeros((B, num_centroids), dtype=np.int64)
+    fn = lib().s4g_oracle_fps_literal if literal else lib().s4g_oracle_fps
+    _check(fn(_fp(points), B, N, num_centroids, _ip(idx), fmad), "fps")
+    return idx
+
+
+def fps_literal(points, num_centroids, fmad=0):
+    return fps(points, num_centroids, fmad, literal=True)
+
+
+def ball_query(points, centroids, radius, num_neighbours, fmad=0):
+    points, centroids = _f32(points), _f32(centroids)
+    B, _, N = points.shape
+    M = centroids.shape[2]
+    K = int(num_neighbours)
+    idx = np.zeros((B, M, K), dtype=np.int64)
+    cnt = np.zeros((B, M), dtype=np.int64)
+    _check(lib().s4g_oracle_ball_query(_fp(points), _fp(centroids), B, N, M,
+                                       ctypes.c_float(radius), K, _ip(idx), _ip(cnt), fmad),
+           "ball_query")
+    return idx, cnt
+
+
+def group_points(points, index):
+    points, index = _f32(points), _i64a(index)
+    B, C, N = points.shape
+    _, M, K = index.shape
+    out = np.empty((B, C, M, K), dtype=np.float32)
+    _check(lib().s4g_oracle_group_points(_fp(points), _ip(index), B, C, N, M, K, _fp(out)),
+           "group_points")
+    return out
+
+
+def group_points_backward(grad_out, index, num_points):
+    grad_out, index = _f32(grad_out), _i64a(index)
+    B, C, M, K = grad_out.shape
+    gin = np.empty((B, C, num_points), dtype=np.float32)
+    _check(lib().s4g_oracle_group_points_backward(_fp(grad_out), _ip(index), B, C, num_points,
+                                                  M, K, _fp(gin)), "group_points_backward")
+    return gin
+
+
+def gather_points(points, index):
+    points, index = _f32(points), _i64a(index)
+    B, C, N = points.shape
+    M = index.shape[1]
+    out = np.empty((B, C, M), dtype=np.float32)
+    _check(lib().s4g_oracle_gather_points(_fp(points), _ip(index), B, C, N, M, _fp(out)),
+           "gather_points")
+    return out
+
+
+def three_nn(query_xyz, key_xyz, fmad=0):
+    """Returns (index (B,N1,3) int64, SQUARED distance (B,N1,3) fp32)."""
+    q, k = _f32(query_xyz), _f32(key_xyz)
+    B, _, N1 = q.shape
+    N2 = k.shape[2]
+    idx = np.empty((B, N1, 3), dtype=np.int64)
+    d2 = np.empty((B, N1, 3), dtype=np.float32)
+    _check(lib().s4g_oracle_three_nn(_fp(q), _fp(k), B, N1, N2, _ip(idx), _fp(d2), fmad),
+           "three_nn")
+    return idx, d2
+
+
+def interp_weights(d2, eps=1e-10):
+    d2 = _f32(d2)
+    B, N1, _ = d2.shape
+    w = np.empty_like(d2)
+    _check(lib().s4g_oracle_interp_weights(_fp(d2), B, N1, ctypes.c_float(eps), _fp(w)),
+           "interp_weights")
+    return w
+
+
+def three_interpolate(feature, index, weight, fmad=0):
+    feature, index, weight = _f32(feature), _i64a(index), _f32(weight)
+    B, C, N2 = feature.shape
+    N1 = index.shape[1]
+    out = np.empty((B, C, N1), dtype=np.float32)
+    _check(lib().s4g_oracle_three_interpolate(_fp(feature), _ip(index), _fp(weight), B, C, N2,
+                                              N1, _fp(out), fmad), "three_interpolate")
+    return out
+
+
+def three_interpolate_backward(grad_out, index, weight, num_inst):
+    grad_out, index, weight = _f32(grad_out), _i64a(index), _f32(weight)
+    B, C, N1 = grad_out.shape
+    gin = np.empty((B, C, num_inst), dtype=np.float32)
+    _check(lib().s4g_oracle_three_interpolate_backward(_fp(grad_out), _ip(index), _fp(weight),
+                                                       B, C, num_inst, N1, _fp(gin)),
+           "three_interpolate_backward")
+    return gin

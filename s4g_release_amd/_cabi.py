@@ -1,0 +1,72 @@
+"""ctypes binding of ``libs4g_hip.so`` (the C ABI declared in ``include/s4g_ops.h``).
+
+There is deliberately NO fallback: if the HIP library is missing or does not
+export a declared symbol, importing the operators fails loudly.  The oracle
+under ``oracle/`` is test infrastructure and is never imported from here.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libs4g_hip.so")
+
+S4G_ABI_VERSION = 1
+S4G_FLAG_FMAD = 1
+S4G_OP_FPS, S4G_OP_BALL_QUERY, S4G_OP_THREE_NN = 1, 2, 3
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_sz = ctypes.c_size_t
+_int = ctypes.c_int
+_f32 = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/s4g_ops.h one to one.
+SIGNATURES = {
+    "s4g_abi_version": (_int, []),
+    "s4g_error_string": (ctypes.c_char_p, [_int]),
+    "s4g_workspace_bytes": (_sz, [_int, _i64, _i64, _i64, _i64]),
+    "s4g_fps_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _sz, _int, _vp]),
+    "s4g_ball_query_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _sz,
+                                  _int, _vp]),
+    "s4g_group_points_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "s4g_group_points_backward_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "s4g_gather_points_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "s4g_three_nn_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _int, _vp]),
+    "s4g_three_interpolate_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp]),
+    "s4g_three_interpolate_backward_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp,
+                                                  _vp]),
+    "s4g_interp_weights_f32": (_int, [_vp, _i64, _i64, _f32, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library once; raise if it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libs4g_hip.so not found at %s -- build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C s4g_release_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            raise RuntimeError("libs4g_hip.so does not export %s" % name)
+        fn.restype = res
+        fn.argtypes = args
+    ver = L.s4g_abi_version()
+    if ver != S4G_ABI_VERSION:
+        raise RuntimeError("libs4g_hip.so ABI version %d != expected %d" % (ver, S4G_ABI_VERSION))
+    _lib = L
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().s4g_error_string(code)
+        raise RuntimeError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", code))

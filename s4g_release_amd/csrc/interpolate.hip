@@ -1,0 +1,126 @@
+// three_interpolate forward / backward for gfx950.
+//
+// Replaces InterpolateForwardKernel / InterpolateBackwardKernel (reference
+// pointnet2_utils/csrc/interpolate_kernel.cu:138-181, :243-286; hosts
+// :191-236, :296-341).  Forward semantics:
+//   acc = 0; for k in 0,1,2: acc += feat[b,c,idx[b,n,k]] * w[b,n,k]
+// in fp32, each product and each sum rounded (canonical mode) or as an fma
+// chain (S4G_FLAG_FMAD, what nvcc's -fmad would emit for `acc += a*b`).
+//
+// Lanes are consecutive dense points n (coalesced 4-byte stores per channel
+// row); a lane reads its 3 indices + 3 weights ONCE (the reference re-derives
+// generic-stride offsets and re-reads them for every channel) and walks a
+// group of channels, gathering from one L2/L1-resident (N2 x 4 B) row at a
+// time.
+#include "s4g_common.h"
+
+namespace s4g {
+
+constexpr int IP_THREADS = 256;
+constexpr int IP_CG = 16;  // channels per block row
+
+template <bool FMAD>
+__global__ __launch_bounds__(IP_THREADS) void three_interpolate_kernel(
+    const float* __restrict__ feat, const int64_t* __restrict__ idx,
+    const float* __restrict__ w, int C, int N2, int N1,
+    float* __restrict__ out) {
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * IP_CG;
+  const int n = blockIdx.x * IP_THREADS + threadIdx.x;
+  if (n >= N1) return;
+  const size_t o = ((size_t)b * N1 + n) * 3;
+  const int j0 = (int)idx[o], j1 = (int)idx[o + 1], j2 = (int)idx[o + 2];
+  const float w0 = w[o], w1 = w[o + 1], w2 = w[o + 2];
+  const int cend = min(c0 + IP_CG, C);
+  for (int ch = c0; ch < cend; ++ch) {
+    const float* __restrict__ src = feat + ((size_t)b * C + ch) * N2;
+    float acc = 0.0f;
+    if constexpr (FMAD) {
+      acc = __fmaf_rn(src[j0], w0, acc);
+      acc = __fmaf_rn(src[j1], w1, acc);
+      acc = __fmaf_rn(src[j2], w2, acc);
+    } else {
+      acc = __fadd_rn(acc, __fmul_rn(src[j0], w0));
+      acc = __fadd_rn(acc, __fmul_rn(src[j1], w1));
+      acc = __fadd_rn(acc, __fmul_rn(src[j2], w2));
+    }
+    out[((size_t)b * C + ch) * N1 + n] = acc;
+  }
+}
+
+__global__ __launch_bounds__(IP_THREADS) void three_interpolate_backward_kernel(
+    const float* __restrict__ gout, const int64_t* __restrict__ idx,
+    const float* __restrict__ w, int C, int N2, int N1,
+    float* __restrict__ gin) {
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * IP_CG;
+  const int n = blockIdx.x * IP_THREADS + threadIdx.x;
+  if (n >= N1) return;
+  const size_t o = ((size_t)b * N1 + n) * 3;
+  const int j0 = (int)idx[o], j1 = (int)idx[o + 1], j2 = (int)idx[o + 2];
+  const float w0 = w[o], w1 = w[o + 1], w2 = w[o + 2];
+  const int cend = min(c0 + IP_CG, C);
+  for (int ch = c0; ch < cend; ++ch) {
+    float* __restrict__ dst = gin + ((size_t)b * C + ch) * N2;
+    const float g = gout[((size_t)b * C + ch) * N1 + n];
+    atomicAdd(dst + j0, __fmul_rn(g, w0));  // interpolate_kernel.cu:283
+    atomicAdd(dst + j1, __fmul_rn(g, w1));
+    atomicAdd(dst + j2, __fmul_rn(g, w2));
+  }
+}
+
+}  // namespace s4g
+
+extern "C" int s4g_three_interpolate_f32(const float* feat_bcn2,
+                                         const int64_t* idx_bn3,
+                                         const float* w_bn3, int64_t B,
+                                         int64_t C, int64_t N2, int64_t N1,
+                                         float* out_bcn1, int flags,
+                                         s4g_stream_t stream) {
+  if (B < 0 || C < 0 || N2 <= 0 || N1 < 0 || B > 65535 || N2 >= (1ll << 31) ||
+      N1 >= (1ll << 31))
+    return S4G_EINVAL;
+  if (B == 0 || C == 0 || N1 == 0) return S4G_OK;
+  if (!feat_bcn2 || !idx_bn3 || !w_bn3 || !out_bcn1) return S4G_EINVAL;
+  const unsigned gy = (unsigned)((C + s4g::IP_CG - 1) / s4g::IP_CG);
+  if (gy > 65535) return S4G_EINVAL;
+  const dim3 grid((unsigned)((N1 + s4g::IP_THREADS - 1) / s4g::IP_THREADS), gy,
+                  (unsigned)B);
+  hipStream_t st = (hipStream_t)stream;
+  if (flags & S4G_FLAG_FMAD)
+    hipLaunchKernelGGL((s4g::three_interpolate_kernel<true>), grid,
+                       dim3(s4g::IP_THREADS), 0, st, feat_bcn2, idx_bn3, w_bn3,
+                       (int)C, (int)N2, (int)N1, out_bcn1);
+  else
+    hipLaunchKernelGGL((s4g::three_interpolate_kernel<false>), grid,
+                       dim3(s4g::IP_THREADS), 0, st, feat_bcn2, idx_bn3, w_bn3,
+                       (int)C, (int)N2, (int)N1, out_bcn1);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
+
+extern "C" int s4g_three_interpolate_backward_f32(
+    const float* gout_bcn1, const int64_t* idx_bn3, const float* w_bn3,
+    int64_t B, int64_t C, int64_t N2, int64_t N1, float* gin_bcn2,
+    s4g_stream_t stream) {
+  if (B < 0 || C < 0 || N2 <= 0 || N1 < 0 || B > 65535 || N2 >= (1ll << 31) ||
+      N1 >= (1ll << 31))
+    return S4G_EINVAL;
+  if (B == 0 || C == 0) return S4G_OK;
+  if (!gin_bcn2) return S4G_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e =
+      hipMemsetAsync(gin_bcn2, 0, sizeof(float) * (size_t)(B * C * N2), st);
+  if (e != hipSuccess) return (int)e;
+  if (N1 == 0) return S4G_OK;
+  if (!gout_bcn1 || !idx_bn3 || !w_bn3) return S4G_EINVAL;
+  const unsigned gy = (unsigned)((C + s4g::IP_CG - 1) / s4g::IP_CG);
+  if (gy > 65535) return S4G_EINVAL;
+  const dim3 grid((unsigned)((N1 + s4g::IP_THREADS - 1) / s4g::IP_THREADS), gy,
+                  (unsigned)B);
+  hipLaunchKernelGGL(s4g::three_interpolate_backward_kernel, grid,
+                     dim3(s4g::IP_THREADS), 0, st, gout_bcn1, idx_bn3, w_bn3,
+                     (int)C, (int)N2, (int)N1, gin_bcn2);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}

@@ -1,0 +1,92 @@
+// Device-side helpers shared by the gfx950 kernels of libs4g_hip.so.
+// Wave = 64 lanes everywhere; this code targets CDNA4 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/s4g_ops.h"
+
+#define S4G_WAVE 64
+
+#define S4G_LAUNCH_CHECK()                        \
+  do {                                            \
+    hipError_t e_ = hipGetLastError();            \
+    if (e_ != hipSuccess) return (int)e_;         \
+  } while (0)
+
+namespace s4g {
+
+// Squared distance with the arithmetic contract of include/s4g_ops.h.
+// The translation units are compiled with -ffp-contract=off, and the
+// __f*_rn intrinsics additionally pin each rounding.
+template <bool FMAD>
+__device__ __forceinline__ float dist2(float x1, float y1, float z1, float x2,
+                                       float y2, float z2) {
+  const float dx = __fsub_rn(x2, x1);
+  const float dy = __fsub_rn(y2, y1);
+  const float dz = __fsub_rn(z2, z1);
+  if constexpr (FMAD) {
+    float t = __fmul_rn(dx, dx);
+    t = __fmaf_rn(dy, dy, t);
+    t = __fmaf_rn(dz, dz, t);
+    return t;
+  } else {
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)),
+                     __fmul_rn(dz, dz));
+  }
+}
+
+// ---- DPP helpers (gfx9 encodings) ------------------------------------------
+// quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E,
+// row_half_mirror = 0x141, row_mirror = 0x140.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF,
+                                               false);
+}
+
+// After these four steps every lane holds the max of its row of 16 lanes.
+__device__ __forceinline__ uint32_t row16_max_u32(uint32_t v) {
+  v = max(v, dpp_u32<0xB1>(v));
+  v = max(v, dpp_u32<0x4E>(v));
+  v = max(v, dpp_u32<0x141>(v));
+  v = max(v, dpp_u32<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ uint32_t row16_min_u32(uint32_t v) {
+  v = min(v, dpp_u32<0xB1>(v));
+  v = min(v, dpp_u32<0x4E>(v));
+  v = min(v, dpp_u32<0x141>(v));
+  v = min(v, dpp_u32<0x140>(v));
+  return v;
+}
+
+// Wave-wide (64 lanes) reductions; the result is wave-uniform (SGPR).
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  v = row16_max_u32(v);
+  const uint32_t a = __builtin_amdgcn_readlane(v, 0);
+  const uint32_t b = __builtin_amdgcn_readlane(v, 16);
+  const uint32_t c = __builtin_amdgcn_readlane(v, 32);
+  const uint32_t d = __builtin_amdgcn_readlane(v, 48);
+  return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  v = row16_min_u32(v);
+  const uint32_t a = __builtin_amdgcn_readlane(v, 0);
+  const uint32_t b = __builtin_amdgcn_readlane(v, 16);
+  const uint32_t c = __builtin_amdgcn_readlane(v, 32);
+  const uint32_t d = __builtin_amdgcn_readlane(v, 48);
+  return min(min(a, b), min(c, d));
+}
+
+__device__ __forceinline__ int lane_id() {
+  return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
+}
+
+// Number of set bits of `mask` strictly below this lane.
+__device__ __forceinline__ int mask_rank(uint64_t mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi(
+      (uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+
+}  // namespace s4g

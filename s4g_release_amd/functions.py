@@ -1,0 +1,348 @@
+"""Operator API of the PointNet++ hot path on MI355X.
+
+Mirror of the reference's
+``inference/grasp_proposal/network_models/models/pointnet2_utils/functions.py``
+(same callables, positional signatures, return order and autograd behaviour:
+``gather_points`` :10-25, ``farthest_point_sample`` :28-50, ``ball_query``
+:53-80, ``group_points`` :83-109, ``search_nn_distance`` :112-135,
+``feature_interpolate`` :145-174) over ``libs4g_hip.so`` instead of ``pn2_ext``.
+North-star spellings (``furthest_point_sample``, ``three_nn``,
+``three_interpolate``) are aliases.
+
+Like the reference, there is no CPU path: tensors must live on a HIP device
+(the reference's CHECK_CUDA), and a missing HIP library is an error.
+Differences, all deliberate:
+  * fp32 only (the reference also dispatches double; S4G never uses it);
+  * kernels run on torch's CURRENT stream and on the tensor's device (the
+    reference launches on the legacy default stream without a device guard);
+  * inputs are consumed channel-first as they come -- no transposed copies.
+"""
+import os
+
+import torch
+
+from . import _cabi
+
+# 0 = canonical arithmetic (every fp32 op rounded), 1 = nvcc -fmad emulation.
+_DIST_FLAGS = _cabi.S4G_FLAG_FMAD if os.environ.get("S4G_DIST_MODE", "strict") == "fmad" else 0
+
+
+def set_distance_mode(mode):
+    """'strict' (default; what the oracle pins) or 'fmad' (nvcc contraction)."""
+    global _DIST_FLAGS
+    if mode not in ("strict", "fmad"):
+        raise ValueError("mode must be 'strict' or 'fmad'")
+    _DIST_FLAGS = _cabi.S4G_FLAG_FMAD if mode == "fmad" else 0
+
+
+def _check_dev(t, name):
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA tensor" % name)  # CHECK_CUDA of the reference
+
+
+def _f32c(t, name):
+    _check_dev(t, name)
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s must be float32 (got %s)" % (name, t.dtype))
+    return t.contiguous()
+
+
+def _i64c(t, name):
+    _check_dev(t, name)
+    if t.dtype != torch.int64:
+        raise RuntimeError("%s must be int64 (got %s)" % (name, t.dtype))
+    return t.contiguous()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None and t.numel() > 0 else None
+
+
+def _workspace(op, dev, B, d0, d1, d2):
+    nbytes = _cabi.lib().s4g_workspace_bytes(op, B, d0, d1, d2)
+    if nbytes == 0:
+        return None, 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return ws, nbytes
+
+
+# ----------------------------------------------------------------------------
+# raw (non-autograd) entry points: the seven pn2_ext functions
+# (reference csrc/main.cpp:7-13)
+# ----------------------------------------------------------------------------
+def _farthest_point_sample(points, num_centroids):
+    points = _f32c(points, "points")
+    if points.dim() != 3 or points.size(1) != 3:
+        raise RuntimeError("points.size(1) does not equal to 3")  # sampling_kernel.cu:137
+    B, _, N = points.shape
+    M = int(num_centroids)
+    if not M > 0:
+        raise RuntimeError("num_centroids is not greater than 0")  # :138
+    if not N >= M:
+        raise RuntimeError("num_points is not greater than or equal to num_centroids")  # :139
+    index = torch.empty((B, M), dtype=torch.int64, device=points.device)
+    with torch.cuda.device(points.device):
+        ws, nbytes = _workspace(_cabi.S4G_OP_FPS, points.device, B, N, M, 0)
+        rc = _cabi.lib().s4g_fps_f32(_ptr(points), B, N, M, _ptr(index), _ptr(ws), nbytes,
+                                     _DIST_FLAGS, _stream())
+    _cabi.check(rc, "farthest_point_sample")
+    return index
+
+
+def _ball_query(points, centroids, radius, num_neighbours):
+    points = _f32c(points, "points")
+    centroids = _f32c(centroids, "centroids")
+    if points.dim() != 3 or points.size(1) != 3:
+        raise RuntimeError("points.size(1) does not equal to 3")  # ball_query_kernel.cu:102
+    if centroids.dim() != 3 or centroids.size(1) != 3:
+        raise RuntimeError("centroids.size(1) does not equal to 3")  # :103
+    if centroids.size(0) != points.size(0):
+        raise RuntimeError("points and centroids must share the batch size")
+    B, _, N = points.shape
+    M = centroids.size(2)
+    K = int(num_neighbours)
+    if K <= 0:
+        raise RuntimeError("num_neighbours must be positive")
+    index = torch.empty((B, M, K), dtype=torch.int64, device=points.device)
+    count = torch.empty((B, M), dtype=torch.int64, device=points.device)
+    with torch.cuda.device(points.device):
+        ws, nbytes = _workspace(_cabi.S4G_OP_BALL_QUERY, points.device, B, N, M, K)
+        rc = _cabi.lib().s4g_ball_query_f32(_ptr(points), _ptr(centroids), B, N, M, float(radius),
+                                            K, _ptr(index), _ptr(count), _ptr(ws), nbytes,
+                                            _DIST_FLAGS, _stream())
+    _cabi.check(rc, "ball_query")
+    return index, count
+
+
+def _group_points_forward(points, index):
+    points = _f32c(points, "input")
+    index = _i64c(index, "index")
+    if points.dim() != 3:
+        raise RuntimeError("input.dim() does not equal to 3")  # grouping_kernel.cu:44
+    if index.dim() != 3:
+        raise RuntimeError("index.dim() does not equal to 3")  # :45
+    if index.size(0) != points.size(0):
+        raise RuntimeError("index.size(0) does not equal to batch_size")  # :46
+    B, C, N = points.shape
+    _, M, K = index.shape
+    out = torch.empty((B, C, M, K), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        rc = _cabi.lib().s4g_group_points_f32(_ptr(points), _ptr(index), B, C, N, M, K, _ptr(out),
+                                              _stream())
+    _cabi.check(rc, "group_points_forward")
+    return out
+
+
+def _group_points_backward(grad_output, index, num_points):
+    grad_output = _f32c(grad_output, "grad_output")
+    index = _i64c(index, "index")
+    if grad_output.dim() != 4 or index.dim() != 3:
+        raise RuntimeError("grad_output must be 4-d and index 3-d")  # grouping_kernel.cu:118-119
+    B, C, M, K = grad_output.shape
+    if tuple(index.shape) != (B, M, K):
+        raise RuntimeError("index shape does not match grad_output")  # :120-122
+    gin = torch.empty((B, C, int(num_points)), dtype=torch.float32, device=grad_output.device)
+    with torch.cuda.device(grad_output.device):
+        rc = _cabi.lib().s4g_group_points_backward_f32(_ptr(grad_output), _ptr(index), B, C,
+                                                       int(num_points), M, K, _ptr(gin), _stream())
+    _cabi.check(rc, "group_points_backward")
+    return gin
+
+
+def _point_search(query_xyz, key_xyz, num_neighbours):
+    query_xyz = _f32c(query_xyz, "query_xyz")
+    key_xyz = _f32c(key_xyz, "key_xyz")
+    B = query_xyz.size(0)
+    if key_xyz.size(0) != B:
+        raise RuntimeError("key_xyz.size(0) does not equal to batch_size")  # interpolate_kernel.cu:101
+    if query_xyz.size(1) != 3 or key_xyz.size(1) != 3:
+        raise RuntimeError("xyz.size(1) does not equal to 3")  # :102-103
+    if int(num_neighbours) != 3:
+        raise RuntimeError("num_neighbours does not equal to K (3)")  # :105
+    N1, N2 = query_xyz.size(2), key_xyz.size(2)
+    if not N2 >= 3:
+        raise RuntimeError("num_key is not greater than or equal to num_neighbours")  # :106
+    index = torch.empty((B, N1, 3), dtype=torch.int64, device=query_xyz.device)
+    dist = torch.empty((B, N1, 3), dtype=torch.float32, device=query_xyz.device)
+    with torch.cuda.device(query_xyz.device):
+        rc = _cabi.lib().s4g_three_nn_f32(_ptr(query_xyz), _ptr(key_xyz), B, N1, N2, _ptr(index),
+                                          _ptr(dist), None, 0, _DIST_FLAGS, _stream())
+    _cabi.check(rc, "point_search")
+    return index, dist
+
+
+def _interpolate_forward(feature, index, weight):
+    feature = _f32c(feature, "input")
+    index = _i64c(index, "index")
+    weight = _f32c(weight, "weight")
+    B, C, N2 = feature.shape
+    if index.size(0) != B or index.size(2) != 3:
+        raise RuntimeError("index must be (batch_size, N, 3)")  # interpolate_kernel.cu:202-203
+    N1 = index.size(1)
+    if tuple(weight.shape) != (B, N1, 3):
+        raise RuntimeError("weight must be (batch_size, N, 3)")  # :204-206
+    out = torch.empty((B, C, N1), dtype=torch.float32, device=feature.device)
+    with torch.cuda.device(feature.device):
+        rc = _cabi.lib().s4g_three_interpolate_f32(_ptr(feature), _ptr(index), _ptr(weight), B, C,
+                                                   N2, N1, _ptr(out), _DIST_FLAGS, _stream())
+    _cabi.check(rc, "interpolate_forward")
+    return out
+
+
+def _interpolate_backward(grad_output, index, weight, num_inst):
+    grad_output = _f32c(grad_output, "grad_output")
+    index = _i64c(index, "index")
+    weight = _f32c(weight, "weight")
+    B, C, N1 = grad_output.shape
+    if tuple(index.shape) != (B, N1, 3) or tuple(weight.shape) != (B, N1, 3):
+        raise RuntimeError("index / weight must be (batch_size, N, 3)")  # :307-311
+    gin = torch.empty((B, C, int(num_inst)), dtype=torch.float32, device=grad_output.device)
+    with torch.cuda.device(grad_output.device):
+        rc = _cabi.lib().s4g_three_interpolate_backward_f32(_ptr(grad_output), _ptr(index),
+                                                            _ptr(weight), B, C, int(num_inst), N1,
+                                                            _ptr(gin), _stream())
+    _cabi.check(rc, "interpolate_backward")
+    return gin
+
+
+def interp_weights(distance, eps=1e-10):
+    """Inverse-distance weights of FeatureInterpolator.forward (modules.py:118-120)
+    in one launch instead of three elementwise ones."""
+    distance = _f32c(distance, "distance")
+    B, N1, _ = distance.shape
+    w = torch.empty_like(distance)
+    with torch.cuda.device(distance.device):
+        rc = _cabi.lib().s4g_interp_weights_f32(_ptr(distance), B, N1, float(eps), _ptr(w),
+                                                _stream())
+    _cabi.check(rc, "interp_weights")
+    return w
+
+
+# ----------------------------------------------------------------------------
+# public operator API (reference functions.py)
+# ----------------------------------------------------------------------------
+def gather_points(points, index):
+    """Gather xyz of centroids according to indices (functions.py:10-25).
+
+    points (B, C, N), index (B, M) -> (B, C, M).  Differentiable like the
+    reference's torch.gather.
+    """
+    if points.requires_grad:
+        index_expand = index.unsqueeze(1).expand(points.size(0), points.size(1), index.size(1))
+        return points.gather(2, index_expand)
+    points = _f32c(points, "points")
+    index = _i64c(index, "index")
+    B, C, N = points.shape
+    M = index.size(1)
+    out = torch.empty((B, C, M), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        rc = _cabi.lib().s4g_gather_points_f32(_ptr(points), _ptr(index), B, C, N, M, _ptr(out),
+                                               _stream())
+    _cabi.check(rc, "gather_points")
+    return out
+
+
+class FarthestPointSample(torch.autograd.Function):
+    """functions.py:28-47"""
+
+    @staticmethod
+    def forward(ctx, points, num_centroids):
+        index = _farthest_point_sample(points, num_centroids)
+        ctx.mark_non_differentiable(index)
+        return index
+
+    @staticmethod
+    def backward(ctx, *grad_outputs):
+        return None, None
+
+
+farthest_point_sample = FarthestPointSample.apply
+
+
+class BallQuery(torch.autograd.Function):
+    """functions.py:53-77"""
+
+    @staticmethod
+    def forward(ctx, points, centroids, radius, num_neighbours):
+        index, count = _ball_query(points, centroids, radius, num_neighbours)
+        ctx.mark_non_differentiable(index, count)
+        return index, count
+
+    @staticmethod
+    def backward(ctx, *grad_outputs):
+        return None, None, None, None
+
+
+ball_query = BallQuery.apply
+
+
+class GroupPoints(torch.autograd.Function):
+    """functions.py:83-106"""
+
+    @staticmethod
+    def forward(ctx, points, index):
+        ctx.save_for_backward(index)
+        ctx.num_points = points.size(2)
+        return _group_points_forward(points, index)
+
+    @staticmethod
+    def backward(ctx, *grad_output):
+        index = ctx.saved_tensors[0]
+        grad_input = _group_points_backward(grad_output[0], index, ctx.num_points)
+        return grad_input, None
+
+
+group_points = GroupPoints.apply
+
+
+class SearchNNDistance(torch.autograd.Function):
+    """functions.py:112-132.  Returns (index, SQUARED distance), in that order."""
+
+    @staticmethod
+    def forward(ctx, query_xyz, key_xyz, num_neighbors):
+        index, distance = _point_search(query_xyz, key_xyz, num_neighbors)
+        ctx.mark_non_differentiable(index, distance)
+        return index, distance
+
+    @staticmethod
+    def backward(ctx, *grad_outputs):
+        return None, None, None
+
+
+search_nn_distance = SearchNNDistance.apply
+
+
+class FeatureInterpolate(torch.autograd.Function):
+    """functions.py:145-171"""
+
+    @staticmethod
+    def forward(ctx, feature, index, weight):
+        _, _, num_inst = feature.size()
+        ctx.save_for_backward(index, weight)
+        ctx.num_inst = num_inst
+        return _interpolate_forward(feature, index, weight)
+
+    @staticmethod
+    def backward(ctx, *grad_out):
+        index, weight = ctx.saved_tensors
+        grad_input = _interpolate_backward(grad_out[0], index, weight, ctx.num_inst)
+        return grad_input, None, None
+
+
+feature_interpolate = FeatureInterpolate.apply
+
+# north-star spellings (erikwijmans lineage); same objects.
+furthest_point_sample = farthest_point_sample
+
+
+def three_nn(query_xyz, key_xyz):
+    """Alias of search_nn_distance(q, k, 3); returns (index, squared distance)
+    in the REFERENCE's order (functions.py:127-128), not (dist, idx)."""
+    return search_nn_distance(query_xyz, key_xyz, 3)
+
+
+three_interpolate = feature_interpolate

@@ -1,0 +1,194 @@
+"""GPU parity tests: every operator of libs4g_hip.so, called through the
+Python operator API (ctypes -> C ABI -> HIP kernels), against the CPU oracle on
+the same seeded inputs.  Integer results must be bit-exact; fp32 results of the
+canonical-arithmetic ops (squared distances, weights, interpolation) too."""
+import numpy as np
+import pytest
+import torch
+
+from s4g_release_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _quantized(rng, B, N, levels=4, scale=0.25):
+    return rng.integers(0, levels, size=(B, 3, N)).astype(np.float32) * np.float32(scale)
+
+
+@pytest.fixture(scope="module")
+def F():
+    from s4g_release_amd import functions
+    functions.set_distance_mode("strict")
+    return functions
+
+
+# ------------------------------------------------------------------ FPS
+@pytest.mark.parametrize("N,M", [(3, 3), (15, 7), (16, 16), (64, 64), (100, 37), (513, 64),
+                                 (1024, 256), (1500, 41), (5120, 1024), (6000, 100),
+                                 (12000, 64), (20000, 50)])
+def test_fps_small_and_ties(F, oracle, dev, N, M):
+    rng = np.random.default_rng(N + M)
+    for pts in (_quantized(rng, 2, N), rng.random((2, 3, N), dtype=np.float32)):
+        got = F.farthest_point_sample(_t(pts, dev), M).cpu().numpy()
+        assert got.dtype == np.int64
+        assert np.array_equal(got, oracle.fps(pts, M))
+
+
+@pytest.mark.parametrize("variant", ["tabletop-v1", "dup-heavy", "uniform-box"])
+def test_fps_full_size_sa1(F, oracle, dev, variant):
+    pts = synth.make_batch([0, 1], 25600, variant=variant)
+    got = F.farthest_point_sample(_t(pts, dev), 5120).cpu().numpy()
+    assert np.array_equal(got, oracle.fps(pts, 5120))
+
+
+def test_fps_streaming_fallback_large_cloud(F, oracle, dev):
+    pts = synth.make_batch([2], 51200)
+    got = F.farthest_point_sample(_t(pts, dev), 300).cpu().numpy()
+    assert np.array_equal(got, oracle.fps(pts, 300))
+
+
+def test_fps_fmad_mode(F, oracle, dev):
+    pts = synth.make_batch([4], 4096)
+    try:
+        F.set_distance_mode("fmad")
+        got = F.farthest_point_sample(_t(pts, dev), 512).cpu().numpy()
+    finally:
+        F.set_distance_mode("strict")
+    assert np.array_equal(got, oracle.fps(pts, 512, fmad=1))
+
+
+def test_fps_argument_errors(F, dev):
+    pts = torch.zeros(1, 3, 4, device=dev)
+    with pytest.raises(RuntimeError):
+        F.farthest_point_sample(pts, 5)
+    with pytest.raises(RuntimeError):
+        F.farthest_point_sample(pts, 0)
+    with pytest.raises(RuntimeError):
+        F.farthest_point_sample(torch.zeros(1, 4, 4, device=dev), 2)
+
+
+# ------------------------------------------------------------------ ball query
+@pytest.mark.parametrize("variant", ["tabletop-v1", "dup-heavy", "uniform-box"])
+@pytest.mark.parametrize("N,M,r,K", [(25600, 5120, 0.02, 64), (5120, 1024, 0.08, 64),
+                                     (1024, 256, 0.32, 64), (777, 33, 0.05, 7)])
+def test_ball_query_matches_oracle(F, oracle, dev, variant, N, M, r, K):
+    pts = synth.make_batch([0, 5], N, variant=variant)
+    ctr = oracle.gather_points(pts, oracle.fps(pts, M))
+    idx, cnt = F.ball_query(_t(pts, dev), _t(ctr, dev), r, K)
+    ridx, rcnt = oracle.ball_query(pts, ctr, r, K)
+    assert idx.dtype == torch.int64 and cnt.dtype == torch.int64
+    assert np.array_equal(cnt.cpu().numpy(), rcnt)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+
+
+def test_ball_query_empty_balls_and_padding(F, oracle, dev):
+    pts = np.zeros((1, 3, 10), dtype=np.float32)
+    pts[0, 0, :] = np.arange(10)
+    ctr = np.array([[[4.0, 100.0], [0.0, 0.0], [0.0, 0.0]]], dtype=np.float32)
+    idx, cnt = F.ball_query(_t(pts, dev), _t(ctr, dev), 1.5, 6)
+    assert cnt.cpu().tolist() == [[3, 0]]
+    assert idx.cpu()[0, 0].tolist() == [3, 4, 5, 3, 3, 3]
+    assert idx.cpu()[0, 1].tolist() == [0] * 6
+
+
+# ------------------------------------------------------------------ group / gather
+@pytest.mark.parametrize("C,N,M,K", [(3, 25600, 5120, 64), (256, 5120, 1024, 64), (5, 100, 7, 3)])
+def test_group_points_matches_oracle(F, oracle, dev, C, N, M, K):
+    rng = np.random.default_rng(C)
+    feat = rng.standard_normal((2, C, N)).astype(np.float32)
+    index = rng.integers(0, N, size=(2, M, K))
+    out = F.group_points(_t(feat, dev), _t(index, dev))
+    assert out.is_contiguous() and tuple(out.shape) == (2, C, M, K)
+    assert np.array_equal(out.cpu().numpy(), oracle.group_points(feat, index))
+    # the caller mutates the result in place (modules.py:44): must be a fresh tensor
+    out -= 1.0
+
+
+def test_gather_points_matches_oracle(F, oracle, dev):
+    rng = np.random.default_rng(1)
+    pts = rng.standard_normal((3, 3, 999)).astype(np.float32)
+    index = rng.integers(0, 999, size=(3, 77))
+    out = F.gather_points(_t(pts, dev), _t(index, dev))
+    assert np.array_equal(out.cpu().numpy(), oracle.gather_points(pts, index))
+
+
+def test_group_points_backward(F, oracle, dev):
+    rng = np.random.default_rng(2)
+    feat = torch.from_numpy(rng.standard_normal((2, 6, 50)).astype(np.float32)).to(dev)
+    feat.requires_grad_(True)
+    index = rng.integers(0, 50, size=(2, 9, 4))
+    g = rng.standard_normal((2, 6, 9, 4)).astype(np.float32)
+    out = F.group_points(feat, _t(index, dev))
+    out.backward(_t(g, dev))
+    ref = oracle.group_points_backward(g, index, 50)
+    assert np.allclose(feat.grad.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------ 3-NN + interpolate
+@pytest.mark.parametrize("N1,N2", [(1024, 256), (5120, 1024), (25600, 5120), (70, 3)])
+def test_three_nn_matches_oracle(F, oracle, dev, N1, N2):
+    pts = synth.make_batch([0, 7], max(N1, 64))[:, :, :N1]
+    keys = oracle.gather_points(pts, oracle.fps(pts, N2))
+    idx, d2 = F.search_nn_distance(_t(pts, dev), _t(keys, dev), 3)
+    ridx, rd2 = oracle.three_nn(pts, keys)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(d2.cpu().numpy(), rd2)       # squared, bit-exact
+    i2, dd = F.three_nn(_t(pts, dev), _t(keys, dev))
+    assert torch.equal(i2, idx) and torch.equal(dd, d2)
+
+
+def test_three_nn_ties_and_errors(F, oracle, dev):
+    rng = np.random.default_rng(3)
+    q, k = _quantized(rng, 2, 300), _quantized(rng, 2, 40)
+    idx, d2 = F.search_nn_distance(_t(q, dev), _t(k, dev), 3)
+    ridx, rd2 = oracle.three_nn(q, k)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d2.cpu().numpy(), rd2)
+    with pytest.raises(RuntimeError):
+        F.search_nn_distance(_t(q, dev), _t(k, dev), 2)          # only k == 3
+    with pytest.raises(RuntimeError):
+        F.search_nn_distance(_t(q, dev), _t(k[:, :, :2], dev), 3)  # N2 >= 3
+
+
+@pytest.mark.parametrize("C,N2,N1", [(1024, 256, 1024), (512, 5120, 25600), (5, 9, 100)])
+def test_three_interpolate_matches_oracle(F, oracle, dev, C, N2, N1):
+    rng = np.random.default_rng(C)
+    feat = rng.standard_normal((2, C, N2)).astype(np.float32)
+    idx = rng.integers(0, N2, size=(2, N1, 3))
+    d2 = rng.random((2, N1, 3), dtype=np.float32) * np.float32(1e-3)
+    d2[0, 0] = 0
+    w = F.interp_weights(_t(d2, dev))
+    rw = oracle.interp_weights(d2)
+    assert np.array_equal(w.cpu().numpy(), rw)
+    # torch's three elementwise ops (modules.py:118-120) give the same bits
+    inv = 1.0 / torch.clamp(_t(d2, dev), min=1e-10)
+    assert torch.equal(inv / torch.sum(inv, dim=2, keepdim=True), w)
+    out = F.feature_interpolate(_t(feat, dev), _t(idx, dev), w)
+    assert np.array_equal(out.cpu().numpy(), oracle.three_interpolate(feat, idx, rw))
+
+
+def test_three_interpolate_backward(F, oracle, dev):
+    rng = np.random.default_rng(4)
+    feat = torch.from_numpy(rng.standard_normal((2, 6, 20)).astype(np.float32)).to(dev)
+    feat.requires_grad_(True)
+    idx = rng.integers(0, 20, size=(2, 31, 3))
+    w = rng.random((2, 31, 3), dtype=np.float32)
+    g = rng.standard_normal((2, 6, 31)).astype(np.float32)
+    out = F.feature_interpolate(feat, _t(idx, dev), _t(w, dev))
+    out.backward(_t(g, dev))
+    ref = oracle.three_interpolate_backward(g, idx, w, 20)
+    assert np.allclose(feat.grad.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_runs_on_current_stream(F, oracle, dev):
+    pts = synth.make_batch([1], 2048)
+    s = torch.cuda.Stream(device=dev)
+    x = _t(pts, dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        idx = F.farthest_point_sample(x, 128)
+    s.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), oracle.fps(pts, 128))

@@ -1,0 +1,125 @@
+"""CPU tests: the C oracle against an independent numpy restatement
+(tests/naive.py), FPS closed-form tie rule against the literal block emulation,
+and the edge cases the reference's sanity checks imply."""
+import numpy as np
+import pytest
+
+from tests import naive
+from s4g_release_amd import synth
+
+
+def _quantized(rng, B, N, levels=4, scale=0.25):
+    return (rng.integers(0, levels, size=(B, 3, N)).astype(np.float32) * np.float32(scale))
+
+
+@pytest.mark.parametrize("N,M", [(3, 3), (15, 7), (16, 16), (17, 5), (100, 100), (513, 64),
+                                 (700, 300), (1500, 41)])
+def test_fps_closed_form_equals_literal_on_ties(oracle, N, M):
+    rng = np.random.default_rng(N * 1000 + M)
+    pts = _quantized(rng, 2, N)
+    a = oracle.fps(pts, M)
+    b = oracle.fps_literal(pts, M)
+    assert np.array_equal(a, b)
+    assert np.array_equal(oracle.fps(pts, M, fmad=1), oracle.fps_literal(pts, M, fmad=1))
+    assert (a[:, 0] == 0).all()
+
+
+@pytest.mark.parametrize("N,M", [(5, 5), (40, 9), (600, 17)])
+def test_fps_literal_matches_numpy_thread_emulation(oracle, N, M):
+    rng = np.random.default_rng(7 + N)
+    for pts in (_quantized(rng, 1, N), rng.random((1, 3, N), dtype=np.float32)):
+        assert np.array_equal(oracle.fps_literal(pts, M), naive.fps_literal(pts, M))
+
+
+def test_fps_all_identical_points_repeats_index(oracle):
+    pts = np.ones((1, 3, 50), dtype=np.float32)
+    assert (oracle.fps(pts, 10) == 0).all()
+    assert (oracle.fps_literal(pts, 10) == 0).all()
+
+
+def test_fps_rejects_bad_sizes(oracle):
+    pts = np.zeros((1, 3, 4), dtype=np.float32)
+    with pytest.raises(RuntimeError):
+        oracle.fps(pts, 5)   # N < M  (sampling_kernel.cu:139)
+    with pytest.raises(RuntimeError):
+        oracle.fps(pts, 0)   # M <= 0 (sampling_kernel.cu:138)
+
+
+@pytest.mark.parametrize("variant", ["tabletop-v1", "dup-heavy", "uniform-box"])
+def test_ball_query_matches_numpy(oracle, variant):
+    pts = synth.make_batch([3], 2048, variant=variant)
+    ctr = oracle.gather_points(pts, oracle.fps(pts, 128))
+    for r, K in ((0.02, 64), (0.08, 16), (0.5, 8), (1e-4, 4)):
+        i1, c1 = oracle.ball_query(pts, ctr, r, K)
+        i2, c2 = naive.ball_query(pts, ctr, r, K)
+        assert np.array_equal(i1, i2) and np.array_equal(c1, c2)
+
+
+def test_ball_query_empty_ball_row_is_zero(oracle):
+    pts = np.zeros((1, 3, 8), dtype=np.float32)
+    ctr = np.full((1, 3, 2), 5.0, dtype=np.float32)
+    idx, cnt = oracle.ball_query(pts, ctr, 0.1, 4)
+    assert (idx == 0).all() and (cnt == 0).all()
+
+
+def test_ball_query_padding_is_first_hit(oracle):
+    pts = np.zeros((1, 3, 10), dtype=np.float32)
+    pts[0, 0, :] = np.arange(10)
+    ctr = pts[:, :, 4:5].copy()
+    idx, cnt = oracle.ball_query(pts, ctr, 1.5, 6)   # hits 3,4,5
+    assert cnt[0, 0] == 3
+    assert idx[0, 0].tolist() == [3, 4, 5, 3, 3, 3]
+
+
+def test_three_nn_matches_numpy_with_ties(oracle):
+    rng = np.random.default_rng(11)
+    for q, k in ((_quantized(rng, 2, 200), _quantized(rng, 2, 50)),
+                 (rng.random((1, 3, 300), dtype=np.float32), rng.random((1, 3, 3), dtype=np.float32))):
+        i1, d1 = oracle.three_nn(q, k)
+        i2, d2 = naive.three_nn(q, k)
+        assert np.array_equal(i1, i2)
+        assert np.array_equal(d1, d2)
+    with pytest.raises(RuntimeError):
+        oracle.three_nn(q, k[:, :, :2])   # N2 >= 3 (interpolate_kernel.cu:106)
+
+
+def test_group_gather_interpolate_match_numpy(oracle):
+    rng = np.random.default_rng(5)
+    feat = rng.standard_normal((2, 7, 90)).astype(np.float32)
+    index = rng.integers(0, 90, size=(2, 13, 5))
+    assert np.array_equal(oracle.group_points(feat, index), naive.group_points(feat, index))
+    assert np.array_equal(oracle.gather_points(feat, index[:, :, 0]),
+                          naive.gather_points(feat, index[:, :, 0]))
+    d2 = rng.random((2, 33, 3), dtype=np.float32)
+    d2[0, 0] = 0.0   # clamps at eps
+    w = oracle.interp_weights(d2)
+    assert np.array_equal(w, naive.interp_weights(d2))
+    i3 = rng.integers(0, 90, size=(2, 33, 3))
+    assert np.array_equal(oracle.three_interpolate(feat, i3, w), naive.three_interpolate(feat, i3, w))
+    with pytest.raises(RuntimeError):
+        oracle.group_points(feat, index + 90)   # out-of-range index
+
+
+def test_backward_ops_are_adjoint(oracle):
+    rng = np.random.default_rng(9)
+    feat = rng.standard_normal((1, 4, 30)).astype(np.float32)
+    index = rng.integers(0, 30, size=(1, 6, 5))
+    g = rng.standard_normal((1, 4, 6, 5)).astype(np.float32)
+    lhs = float((oracle.group_points(feat, index).astype(np.float64) * g).sum())
+    rhs = float((oracle.group_points_backward(g, index, 30).astype(np.float64) * feat).sum())
+    assert abs(lhs - rhs) < 1e-4
+    i3 = rng.integers(0, 30, size=(1, 11, 3))
+    w = rng.random((1, 11, 3), dtype=np.float32)
+    g2 = rng.standard_normal((1, 4, 11)).astype(np.float32)
+    lhs = float((oracle.three_interpolate(feat, i3, w).astype(np.float64) * g2).sum())
+    rhs = float((oracle.three_interpolate_backward(g2, i3, w, 30).astype(np.float64) * feat).sum())
+    assert abs(lhs - rhs) < 1e-4
+
+
+def test_synth_is_deterministic_and_permuted():
+    a = synth.make_scene(5, 4096)
+    b = synth.make_scene(5, 4096)
+    assert a.dtype == np.float32 and a.shape == (3, 4096) and np.array_equal(a, b)
+    assert not np.array_equal(a, synth.make_scene(6, 4096))
+    d = synth.make_scene(0, 4096, variant="dup-heavy")
+    assert len(np.unique(d.T, axis=0)) < 4096
