@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: scenes/sec of the S4G forward pass on 25 600-point clouds.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* is one forward pass over one batch of `--batch` (default 16) synthetic
+`tabletop-v1` scenes per GPU, clouds already resident in HBM, four head outputs
+left in HBM; with N > 1 every rank runs its own scenes (weak scaling, no
+data-path collective) and the per-point outputs are all-gathered over RCCL.
+The timed region is bracketed by barrier + synchronize on both sides and the
+slowest rank's time is used.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      the kernel(s) the north star names: ball_query + group_points at
+                SA1 size (HBM-bound), live HIP-event durations from the timed region
+  kernels       every native launch: mean ms, algorithmic bytes, GB/s
+  cpu_baseline  the CPU oracle forward (oracle/pn2_forward.py) on ONE scene,
+                rank 0 at N == 1 only -- a reported baseline, not the target
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3      # fp32-in MFMA = fp32 vector peak
+GFLOP_PER_SCENE = 203.48       # SURVEY.md Appendix B (BN folded, 2*MAC)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="scenes per GPU per step")
+    ap.add_argument("--points", type=int, default=25600)
+    ap.add_argument("--impl", default="auto", choices=["auto", "fused", "modules"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", default="tabletop-v1")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from s4g_release_amd import _cabi, functions as F, synth
+    from s4g_release_amd.model import S4GConfig, build_pointnet2_cls, randomize_bn_
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run"
+                  % (world, args.gpus), file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    _cabi.lib()   # no HIP library -> fail loudly, never a fallback
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    cfg = S4GConfig()
+    torch.manual_seed(20260101)
+    net = build_pointnet2_cls(cfg)
+    randomize_bn_(net, 20260102)
+    net = net.to(dev).eval()
+
+    impl = args.impl
+    fused_cls = None
+    if impl in ("auto", "fused"):
+        try:
+            from s4g_release_amd.fused import FusedPointNet2 as fused_cls
+        except ImportError:
+            if impl == "fused":
+                raise
+    if fused_cls is not None:
+        runner = fused_cls(net)
+        impl = "fused"
+    else:
+        runner = net
+        impl = "modules"
+
+    B = args.batch
+    scene_ids = [rank * B + i for i in range(B)]
+    pts = torch.from_numpy(synth.make_batch(scene_ids, args.points, variant=args.variant)).to(dev)
+    batch = {"scene_points": pts}
+    heads = ("score", "frame_R", "frame_t", "movable_logits")
+
+    def step():
+        with torch.no_grad():
+            pred = runner(batch)
+            if world > 1:
+                local = torch.cat([pred[k] for k in heads], dim=1).contiguous()   # (B,21,N)
+                gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=dev)
+                dist.all_gather_into_tensor(gathered, local)
+                return gathered
+            return pred
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    F.OpTimer.reset(enabled=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    F.OpTimer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    scenes = world * B * args.steps
+    value = scenes / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    kernels = {}
+    for name, (n, ms, nbytes) in sorted(F.OpTimer.summary().items()):
+        kernels[name] = {"launches": n, "ms": round(ms, 5), "bytes": int(nbytes),
+                         "GBps": round(nbytes / ms / 1e6, 2) if ms > 0 else None}
+
+    # north-star roofline: ball_query + group_points(xyz) at SA1 size
+    N, M, K = args.points, cfg.num_centroids[0], cfg.num_neighbours[0]
+    bq = kernels.get("ball_query[N=%d,M=%d,K=%d]" % (N, M, K))
+    gp = kernels.get("group_points[C=3,N=%d,M=%d,K=%d]" % (N, M, K))
+    fq = kernels.get("query_group[N=%d,M=%d,K=%d]" % (N, M, K))
+    roofline = None
+    if bq and gp:
+        nbytes = bq["bytes"] + gp["bytes"]
+        ms = bq["ms"] + gp["ms"]
+        roofline = {"kernel": "ball_query + group_points(xyz), SA1", "bound": "hbm",
+                    "achieved": round(nbytes / ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_launch": nbytes, "ms_per_launch": round(ms, 5),
+                    "scenes_per_launch": B}
+    elif fq:
+        roofline = {"kernel": "fused ball_query+group_points(xyz), SA1", "bound": "hbm",
+                    "achieved": fq["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(fq["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_launch": fq["bytes"], "ms_per_launch": fq["ms"],
+                    "scenes_per_launch": B}
+    dense_tf = GFLOP_PER_SCENE * value / world / 1e3
+    roofline_dense = {"kernel": "whole forward, dense contraction flops only", "bound": "mfma",
+                      "achieved": round(dense_tf, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                      "frac": round(dense_tf / FP32_MFMA_PEAK_TF, 4)}
+
+    cpu_baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import pn2_forward
+        torch.set_num_threads(os.cpu_count() or 1)
+        sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        one = pts[:1].cpu().numpy()
+        t1 = time.perf_counter()
+        ref = pn2_forward.forward(sd, one, cfg.num_centroids, cfg.radius, cfg.num_neighbours)
+        cpu_s = time.perf_counter() - t1
+        with torch.no_grad():
+            got = runner({"scene_points": pts[:1]})
+        err = max(float(np.max(np.abs(got[k].cpu().numpy() - ref[k]))) for k in heads)
+        cpu_baseline = {"value": round(1.0 / cpu_s, 4), "unit": "scenes/sec",
+                        "cores": torch.get_num_threads(), "kind": "port",
+                        "sample": "1 scene (scene %d) of the same workload, oracle C ops "
+                                  "(1 thread) + torch CPU conv/BN (%d threads)"
+                                  % (scene_ids[0], torch.get_num_threads()),
+                        "max_abs_err_gpu_vs_cpu": err}
+
+    line = {
+        "metric": "scenes/sec (25.6k-pt clouds) end-to-end grasp inference",
+        "value": round(value, 3), "unit": "scenes/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "S4G PN2_CLS forward (3 SA + 3 FP + 4 heads), %d scenes/GPU/step, "
+                               "%d-pt %s clouds, fp32, impl=%s" % (B, args.points, args.variant, impl),
+                   "scenes_per_gpu": B, "num_points": args.points, "global_batch": world * B,
+                   "parallelism": "scenes sharded over %d GPU(s), all-gather of 21 ch/point" % world},
+        "roofline": roofline, "roofline_dense": roofline_dense, "kernels": kernels,
+        "cpu_baseline": cpu_baseline,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

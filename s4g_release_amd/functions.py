@@ -58,6 +58,47 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class OpTimer:
+    """Optional HIP-event timing of every native launch (used by bench.py).
+
+    Events are recorded on the stream the kernel is launched on (torch's
+    current stream), immediately before and after the launch."""
+    enabled = False
+    records = []   # (op name, start event, end event, algorithmic bytes)
+
+    @classmethod
+    def reset(cls, enabled):
+        cls.enabled = enabled
+        cls.records = []
+
+    @classmethod
+    def summary(cls):
+        """{op: (launches, mean ms, algorithmic bytes per launch)}; call after a sync."""
+        acc = {}
+        for name, e0, e1, nbytes in cls.records:
+            n, t, b = acc.get(name, (0, 0.0, 0))
+            acc[name] = (n + 1, t + e0.elapsed_time(e1), b + nbytes)
+        return {k: (n, t / n, b / n) for k, (n, t, b) in acc.items()}
+
+
+class _timed:
+    def __init__(self, name, nbytes):
+        self.name, self.nbytes = name, nbytes
+
+    def __enter__(self):
+        if OpTimer.enabled:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if OpTimer.enabled:
+            self.e1.record()
+            OpTimer.records.append((self.name, self.e0, self.e1, self.nbytes))
+        return False
+
+
 def _ptr(t):
     return t.data_ptr() if t is not None and t.numel() > 0 else None
 
@@ -87,8 +128,9 @@ def _farthest_point_sample(points, num_centroids):
     index = torch.empty((B, M), dtype=torch.int64, device=points.device)
     with torch.cuda.device(points.device):
         ws, nbytes = _workspace(_cabi.S4G_OP_FPS, points.device, B, N, M, 0)
-        rc = _cabi.lib().s4g_fps_f32(_ptr(points), B, N, M, _ptr(index), _ptr(ws), nbytes,
-                                     _DIST_FLAGS, _stream())
+        with _timed("fps[N=%d,M=%d]" % (N, M), B * (12 * N + 8 * M)):
+            rc = _cabi.lib().s4g_fps_f32(_ptr(points), B, N, M, _ptr(index), _ptr(ws), nbytes,
+                                         _DIST_FLAGS, _stream())
     _cabi.check(rc, "farthest_point_sample")
     return index
 
@@ -111,9 +153,11 @@ def _ball_query(points, centroids, radius, num_neighbours):
     count = torch.empty((B, M), dtype=torch.int64, device=points.device)
     with torch.cuda.device(points.device):
         ws, nbytes = _workspace(_cabi.S4G_OP_BALL_QUERY, points.device, B, N, M, K)
-        rc = _cabi.lib().s4g_ball_query_f32(_ptr(points), _ptr(centroids), B, N, M, float(radius),
-                                            K, _ptr(index), _ptr(count), _ptr(ws), nbytes,
-                                            _DIST_FLAGS, _stream())
+        with _timed("ball_query[N=%d,M=%d,K=%d]" % (N, M, K),
+                    B * (12 * N + 12 * M + 8 * M * K + 8 * M)):
+            rc = _cabi.lib().s4g_ball_query_f32(_ptr(points), _ptr(centroids), B, N, M,
+                                                float(radius), K, _ptr(index), _ptr(count),
+                                                _ptr(ws), nbytes, _DIST_FLAGS, _stream())
     _cabi.check(rc, "ball_query")
     return index, count
 
@@ -131,8 +175,10 @@ def _group_points_forward(points, index):
     _, M, K = index.shape
     out = torch.empty((B, C, M, K), dtype=torch.float32, device=points.device)
     with torch.cuda.device(points.device):
-        rc = _cabi.lib().s4g_group_points_f32(_ptr(points), _ptr(index), B, C, N, M, K, _ptr(out),
-                                              _stream())
+        with _timed("group_points[C=%d,N=%d,M=%d,K=%d]" % (C, N, M, K),
+                    B * (4 * C * N + 8 * M * K + 4 * C * M * K)):
+            rc = _cabi.lib().s4g_group_points_f32(_ptr(points), _ptr(index), B, C, N, M, K,
+                                                  _ptr(out), _stream())
     _cabi.check(rc, "group_points_forward")
     return out
 
@@ -169,8 +215,10 @@ def _point_search(query_xyz, key_xyz, num_neighbours):
     index = torch.empty((B, N1, 3), dtype=torch.int64, device=query_xyz.device)
     dist = torch.empty((B, N1, 3), dtype=torch.float32, device=query_xyz.device)
     with torch.cuda.device(query_xyz.device):
-        rc = _cabi.lib().s4g_three_nn_f32(_ptr(query_xyz), _ptr(key_xyz), B, N1, N2, _ptr(index),
-                                          _ptr(dist), None, 0, _DIST_FLAGS, _stream())
+        with _timed("three_nn[N1=%d,N2=%d]" % (N1, N2), B * (12 * N2 + 12 * N1 + 24 * N1 + 12 * N1)):
+            rc = _cabi.lib().s4g_three_nn_f32(_ptr(query_xyz), _ptr(key_xyz), B, N1, N2,
+                                              _ptr(index), _ptr(dist), None, 0, _DIST_FLAGS,
+                                              _stream())
     _cabi.check(rc, "point_search")
     return index, dist
 
@@ -187,8 +235,11 @@ def _interpolate_forward(feature, index, weight):
         raise RuntimeError("weight must be (batch_size, N, 3)")  # :204-206
     out = torch.empty((B, C, N1), dtype=torch.float32, device=feature.device)
     with torch.cuda.device(feature.device):
-        rc = _cabi.lib().s4g_three_interpolate_f32(_ptr(feature), _ptr(index), _ptr(weight), B, C,
-                                                   N2, N1, _ptr(out), _DIST_FLAGS, _stream())
+        with _timed("three_interpolate[C=%d,N2=%d,N1=%d]" % (C, N2, N1),
+                    B * (4 * C * N2 + 24 * N1 + 12 * N1 + 4 * C * N1)):
+            rc = _cabi.lib().s4g_three_interpolate_f32(_ptr(feature), _ptr(index), _ptr(weight), B,
+                                                       C, N2, N1, _ptr(out), _DIST_FLAGS,
+                                                       _stream())
     _cabi.check(rc, "interpolate_forward")
     return out
 
