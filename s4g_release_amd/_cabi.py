@@ -51,6 +51,11 @@ def lib():
             "libs4g_hip.so not found at %s -- build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C s4g_release_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    # torch bundles its own libamdhip64.so.7 and the system ROCm has one with the
+    # same SONAME: whichever is loaded first serves the whole process.  Import
+    # torch first so the kernels and torch's allocator/streams share ONE runtime
+    # (loading ours first gives "no ROCm-capable device" on the first launch).
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:
