@@ -126,6 +126,90 @@ int s4g_three_interpolate_backward_f32(const float *gout_bcn1,
 int s4g_interp_weights_f32(const float *d2_bn3, int64_t B, int64_t N1,
                            float eps, float *w_bn3, s4g_stream_t stream);
 
+
+/* ---------------------------------------------------------------------------
+ * Inference fast path: the shared-MLP contraction on the fp32 matrix cores.
+ *
+ * One launch computes, for `groups` independent problems (blockIdx.y),
+ *     Y[p][n] = act( sum_k A[p][k] * W[n][k] + bias[n] ),  p < P, n < Cout
+ * with BatchNorm already folded into W / bias by the caller and every
+ * activation stored channels-last ([position][channel], fp32).  It replaces
+ * the per-layer Conv{1,2}d(k=1) -> BatchNorm -> ReLU of
+ * network_models/nn_utils/conv.py:28-34,68-74 together with the tensor
+ * plumbing around it in pointnet2_utils/modules.py (group + concat :42-50,
+ * max over neighbours :242-243, interpolate + concat :118-127).
+ *
+ * loader  S4G_GEMM_LOAD_PLAIN   A row p = A + p*lda + a_coff + g*a_gcol
+ *         S4G_GEMM_LOAD_GATHER  A row p = [ feat[b*N + gidx[p]][0..Cf) |
+ *                                xyz[b,:,gidx[p]] - ctr[b,:,m] | 0.. ]
+ *                                (K order [feat, xyz]; W permuted to match)
+ *         S4G_GEMM_LOAD_INTERP  A row p = [ sum_k nw[p,k]*sparse[b*N2+nidx[p,k]] |
+ *                                dense[p][0..C1) ]
+ * epilogue S4G_GEMM_EPI_STORE   out[p*ldc + c_coff + g*c_gcol + n]
+ *          S4G_GEMM_EPI_MAX     out[(p/K)*ldc + c_coff + n] = max over the K
+ *                               consecutive rows of a group (K in 16,32,64)
+ *          S4G_GEMM_EPI_CHANNEL_FIRST  (B,C,N) tensors cf_ptr[h], channel
+ *                               ranges cf_start[h]..cf_start[h+1], sigmoid on
+ *                               channels >= cf_sigmoid_from
+ * W is [groups][Cout][Kpad] with Kpad % 8 == 0 (zero padded), bias
+ * [groups][Cout].  Cf, C2 must be multiples of 32; lda, a_coff, C1 of 4.
+ * ------------------------------------------------------------------------- */
+#define S4G_GEMM_LOAD_PLAIN 0
+#define S4G_GEMM_LOAD_GATHER 1
+#define S4G_GEMM_LOAD_INTERP 2
+#define S4G_GEMM_EPI_STORE 0
+#define S4G_GEMM_EPI_MAX 1
+#define S4G_GEMM_EPI_CHANNEL_FIRST 2
+
+typedef struct s4g_gemm_desc {
+  int32_t loader, epilogue, groups, relu;
+  int32_t P, Cin, Kpad, Cout;
+  const float *W;
+  const float *bias;
+  int32_t w_gstride, b_gstride; /* elements between groups */
+  /* PLAIN */
+  const float *A;
+  int32_t lda, a_coff, a_gcol;
+  /* GATHER */
+  const int32_t *gidx; /* (B*M*K) neighbour index inside its scene */
+  const float *feat;   /* (B*N, Cf) channels-last or NULL when Cf == 0 */
+  const float *xyz;    /* (B,3,N) */
+  const float *ctr;    /* (B,3,M) */
+  int32_t Cf, N, M, K;
+  /* INTERP */
+  const int32_t *nidx; /* (B*N1, 3) */
+  const float *nw;     /* (B*N1, 3) */
+  const float *sparse; /* (B*N2, C2) */
+  const float *dense;  /* (B*N1, C1) or NULL when C1 == 0 */
+  int32_t C2, C1, N2, N1;
+  /* output */
+  float *out;
+  int32_t ldc, c_coff, c_gcol;
+  float *cf_ptr[4];
+  int32_t cf_start[5];
+  int32_t cf_sigmoid_from, cf_N;
+} s4g_gemm_desc_t;
+
+int s4g_mlp_gemm_f32(const s4g_gemm_desc_t *desc, s4g_stream_t stream);
+
+/* int32-index variants used by the fast path (same kernels and semantics as
+ * s4g_ball_query_f32 / s4g_three_nn_f32; the int64 API tensors are an
+ * interface requirement of the reference, not of the hardware).
+ * s4g_three_nn_weights_i32 also applies the inverse-distance weights of
+ * modules.py:118-120 and does not write the distances. */
+int s4g_ball_query_i32(const float *xyz_b3n, const float *ctr_b3m, int64_t B,
+                       int64_t N, int64_t M, float radius, int64_t K,
+                       int32_t *idx_bmk, int32_t *cnt_bm, void *ws,
+                       size_t ws_bytes, int flags, s4g_stream_t stream);
+int s4g_three_nn_weights_i32(const float *q_b3n1, const float *k_b3n2, int64_t B,
+                             int64_t N1, int64_t N2, float eps, int32_t *idx_bn3,
+                             float *w_bn3, void *ws, size_t ws_bytes, int flags,
+                             s4g_stream_t stream);
+/* FPS + centroid gather in one call: idx (B,M) int32 and ctr (B,3,M) planar. */
+int s4g_fps_gather_i32(const float *xyz_b3n, int64_t B, int64_t N, int64_t M,
+                       int32_t *idx_bm, float *ctr_b3m, void *ws, size_t ws_bytes,
+                       int flags, s4g_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,8 +20,33 @@ _sz = ctypes.c_size_t
 _int = ctypes.c_int
 _f32 = ctypes.c_float
 
+_i32 = ctypes.c_int32
+
+
+class GemmDesc(ctypes.Structure):
+    """ctypes mirror of `s4g_gemm_desc_t` (include/s4g_ops.h)."""
+    _fields_ = [
+        ("loader", _i32), ("epilogue", _i32), ("groups", _i32), ("relu", _i32),
+        ("P", _i32), ("Cin", _i32), ("Kpad", _i32), ("Cout", _i32),
+        ("W", _vp), ("bias", _vp), ("w_gstride", _i32), ("b_gstride", _i32),
+        ("A", _vp), ("lda", _i32), ("a_coff", _i32), ("a_gcol", _i32),
+        ("gidx", _vp), ("feat", _vp), ("xyz", _vp), ("ctr", _vp),
+        ("Cf", _i32), ("N", _i32), ("M", _i32), ("K", _i32),
+        ("nidx", _vp), ("nw", _vp), ("sparse", _vp), ("dense", _vp),
+        ("C2", _i32), ("C1", _i32), ("N2", _i32), ("N1", _i32),
+        ("out", _vp), ("ldc", _i32), ("c_coff", _i32), ("c_gcol", _i32),
+        ("cf_ptr", _vp * 4), ("cf_start", _i32 * 5), ("cf_sigmoid_from", _i32), ("cf_N", _i32),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/s4g_ops.h one to one.
 SIGNATURES = {
+    "s4g_mlp_gemm_f32": (_int, [ctypes.POINTER(GemmDesc), _vp]),
+    "s4g_ball_query_i32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _sz,
+                                  _int, _vp]),
+    "s4g_three_nn_weights_i32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _sz,
+                                        _int, _vp]),
+    "s4g_fps_gather_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _int, _vp]),
     "s4g_abi_version": (_int, []),
     "s4g_error_string": (ctypes.c_char_p, [_int]),
     "s4g_workspace_bytes": (_sz, [_int, _i64, _i64, _i64, _i64]),

@@ -20,10 +20,10 @@ namespace s4g {
 constexpr int BQ_WAVES_PER_BLOCK = 4;
 constexpr int BQ_UNROLL = 4;
 
-template <bool FMAD>
+template <bool FMAD, typename IdxT>
 __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void ball_query_scan_kernel(
     const float* __restrict__ xyz, const float* __restrict__ ctr, int N, int M,
-    float r2, int K, int64_t* __restrict__ idx, int64_t* __restrict__ cnt_out) {
+    float r2, int K, IdxT* __restrict__ idx, IdxT* __restrict__ cnt_out) {
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * BQ_WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void ball_query_scan_kerne
   const float* __restrict__ pz = py + N;
   const float* __restrict__ c = ctr + (size_t)b * 3 * M;
   const float cx = c[m], cy = c[M + m], cz = c[2 * M + m];
-  int64_t* __restrict__ row = idx + ((size_t)b * M + m) * K;
+  IdxT* __restrict__ row = idx + ((size_t)b * M + m) * K;
 
   int cnt = 0;    // wave-uniform
   int first = 0;  // index of the first hit
@@ -55,18 +55,44 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void ball_query_scan_kerne
       const uint64_t mask = __ballot(hit);
       if (mask != 0) {
         const int pos = cnt + mask_rank(mask);
-        if (hit && pos < K) row[pos] = (int64_t)j;
+        if (hit && pos < K) row[pos] = (IdxT)j;
         if (cnt == 0) first = j0 + u * 64 + (__ffsll((unsigned long long)mask) - 1);
         cnt += __popcll(mask);
       }
     }
   }
   if (cnt > K) cnt = K;
-  const int64_t fill = (int64_t)first;  // 0 when there was no hit
+  const IdxT fill = (IdxT)first;  // 0 when there was no hit
   for (int k = cnt + lane; k < K; k += 64) row[k] = fill;
-  if (lane == 0) cnt_out[(size_t)b * M + m] = (int64_t)cnt;
+  if (lane == 0) cnt_out[(size_t)b * M + m] = (IdxT)cnt;
 }
 
+}  // namespace s4g
+
+namespace s4g {
+template <typename IdxT>
+static int ball_query_dispatch(const float* xyz, const float* ctr, int64_t B,
+                               int64_t N, int64_t M, float radius, int64_t K,
+                               IdxT* idx, IdxT* cnt, int flags,
+                               hipStream_t st) {
+  if (B < 0 || N <= 0 || M < 0 || K <= 0 || N >= (1ll << 31) || B > 65535)
+    return S4G_EINVAL;
+  if (B == 0 || M == 0) return S4G_OK;
+  if (!xyz || !ctr || !idx || !cnt) return S4G_EINVAL;
+  // r2 exactly as ball_query_kernel.cu:49 computes it: fp32 product.
+  const float r2 = radius * radius;
+  const dim3 block(64 * BQ_WAVES_PER_BLOCK);
+  const dim3 grid((unsigned)((M + BQ_WAVES_PER_BLOCK - 1) / BQ_WAVES_PER_BLOCK),
+                  (unsigned)B);
+  if (flags & S4G_FLAG_FMAD)
+    hipLaunchKernelGGL((ball_query_scan_kernel<true, IdxT>), grid, block, 0, st,
+                       xyz, ctr, (int)N, (int)M, r2, (int)K, idx, cnt);
+  else
+    hipLaunchKernelGGL((ball_query_scan_kernel<false, IdxT>), grid, block, 0, st,
+                       xyz, ctr, (int)N, (int)M, r2, (int)K, idx, cnt);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
 }  // namespace s4g
 
 extern "C" int s4g_ball_query_f32(const float* xyz_b3n, const float* ctr_b3m,
@@ -76,27 +102,21 @@ extern "C" int s4g_ball_query_f32(const float* xyz_b3n, const float* ctr_b3m,
                                   s4g_stream_t stream) {
   (void)ws;
   (void)ws_bytes;
-  if (B < 0 || N <= 0 || M < 0 || K <= 0 || N >= (1ll << 31) || B > 65535)
-    return S4G_EINVAL;
-  if (B == 0 || M == 0) return S4G_OK;
-  if (!xyz_b3n || !ctr_b3m || !idx_bmk || !cnt_bm) return S4G_EINVAL;
-  // r2 exactly as ball_query_kernel.cu:49 computes it: fp32 product.
-  const float r2 = radius * radius;
-  const dim3 block(64 * s4g::BQ_WAVES_PER_BLOCK);
-  const dim3 grid((unsigned)((M + s4g::BQ_WAVES_PER_BLOCK - 1) /
-                             s4g::BQ_WAVES_PER_BLOCK),
-                  (unsigned)B);
-  hipStream_t st = (hipStream_t)stream;
-  if (flags & S4G_FLAG_FMAD)
-    hipLaunchKernelGGL((s4g::ball_query_scan_kernel<true>), grid, block, 0, st,
-                       xyz_b3n, ctr_b3m, (int)N, (int)M, r2, (int)K, idx_bmk,
-                       cnt_bm);
-  else
-    hipLaunchKernelGGL((s4g::ball_query_scan_kernel<false>), grid, block, 0, st,
-                       xyz_b3n, ctr_b3m, (int)N, (int)M, r2, (int)K, idx_bmk,
-                       cnt_bm);
-  S4G_LAUNCH_CHECK();
-  return S4G_OK;
+  return s4g::ball_query_dispatch<int64_t>(xyz_b3n, ctr_b3m, B, N, M, radius, K,
+                                           idx_bmk, cnt_bm, flags,
+                                           (hipStream_t)stream);
+}
+
+extern "C" int s4g_ball_query_i32(const float* xyz_b3n, const float* ctr_b3m,
+                                  int64_t B, int64_t N, int64_t M, float radius,
+                                  int64_t K, int32_t* idx_bmk, int32_t* cnt_bm,
+                                  void* ws, size_t ws_bytes, int flags,
+                                  s4g_stream_t stream) {
+  (void)ws;
+  (void)ws_bytes;
+  return s4g::ball_query_dispatch<int32_t>(xyz_b3n, ctr_b3m, B, N, M, radius, K,
+                                           idx_bmk, cnt_bm, flags,
+                                           (hipStream_t)stream);
 }
 
 namespace s4g {

@@ -86,10 +86,10 @@ __device__ __forceinline__ void fps_pick(const float (&x)[PPT],
   }
 }
 
-template <int PPT, bool FMAD>
+template <int PPT, bool FMAD, typename IdxT>
 __global__ __launch_bounds__(FPS_THREADS) void fps_reg_kernel(
-    const float* __restrict__ xyz, int N, int M, int64_t* __restrict__ idx,
-    int lg_bs) {
+    const float* __restrict__ xyz, int N, int M, IdxT* __restrict__ idx,
+    float* __restrict__ ctr, int lg_bs) {
   __shared__ FpsSlot slots[2][FPS_WAVES];
   const int b = blockIdx.x;
   const int t = threadIdx.x;
@@ -98,7 +98,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_reg_kernel(
   const float* __restrict__ px = xyz + (size_t)b * 3 * N;
   const float* __restrict__ py = px + N;
   const float* __restrict__ pz = py + N;
-  int64_t* __restrict__ out = idx + (size_t)b * M;
+  IdxT* __restrict__ out = idx + (size_t)b * M;
+  float* __restrict__ cout = ctr ? ctr + (size_t)b * 3 * M : nullptr;
 
   float x[PPT], y[PPT], z[PPT], md[PPT];
 #pragma unroll
@@ -117,7 +118,14 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_reg_kernel(
 
   int cur = 0;
   float cx = px[0], cy = py[0], cz = pz[0];
-  if (t == 0) out[0] = 0;
+  if (t == 0) {
+    out[0] = 0;
+    if (cout) {
+      cout[0] = cx;
+      cout[M] = cy;
+      cout[2 * M] = cz;
+    }
+  }
 
   for (int i = 1; i < M; ++i) {
     float best = 0.0f;
@@ -146,15 +154,22 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_reg_kernel(
     if (pw >= 0) fps_pick<PPT, 0, PPT>(x, y, z, pw, wl, sx, sy, sz);
     fps_block_exchange(slots[i & 1], wave, lane, wmax, wtie, sx, sy, sz, cur,
                        cx, cy, cz);
-    if (t == 0) out[i] = (int64_t)cur;
+    if (t == 0) {
+      out[i] = (IdxT)cur;
+      if (cout) {  // centroid gather fused in: the winner's xyz is already here
+        cout[i] = cx;
+        cout[M + i] = cy;
+        cout[2 * M + i] = cz;
+      }
+    }
   }
 }
 
 // Streaming fallback: any N < 2^23.  min-distance in `temp` (B,N) fp32.
-template <bool FMAD>
+template <bool FMAD, typename IdxT>
 __global__ __launch_bounds__(FPS_THREADS) void fps_stream_kernel(
-    const float* __restrict__ xyz, int N, int M, int64_t* __restrict__ idx,
-    float* __restrict__ temp, int lg_bs) {
+    const float* __restrict__ xyz, int N, int M, IdxT* __restrict__ idx,
+    float* __restrict__ ctr, float* __restrict__ temp, int lg_bs) {
   __shared__ FpsSlot slots[2][FPS_WAVES];
   const int b = blockIdx.x;
   const int t = threadIdx.x;
@@ -164,7 +179,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_stream_kernel(
   const float* __restrict__ py = px + N;
   const float* __restrict__ pz = py + N;
   float* __restrict__ md = temp + (size_t)b * N;
-  int64_t* __restrict__ out = idx + (size_t)b * M;
+  IdxT* __restrict__ out = idx + (size_t)b * M;
+  float* __restrict__ cout = ctr ? ctr + (size_t)b * 3 * M : nullptr;
 
   for (int j = t; j < N; j += FPS_THREADS) md[j] = __builtin_inff();
   const uint32_t bs_mask = (1u << lg_bs) - 1u;
@@ -172,7 +188,14 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_stream_kernel(
 
   int cur = 0;
   float cx = px[0], cy = py[0], cz = pz[0];
-  if (t == 0) out[0] = 0;
+  if (t == 0) {
+    out[0] = 0;
+    if (cout) {
+      cout[0] = cx;
+      cout[M] = cy;
+      cout[2 * M] = cz;
+    }
+  }
 
   for (int i = 1; i < M; ++i) {
     float best = 0.0f;
@@ -196,7 +219,14 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_stream_kernel(
     const float sx = px[jw], sy = py[jw], sz = pz[jw];
     fps_block_exchange(slots[i & 1], wave, lane, wmax, wtie, sx, sy, sz, cur,
                        cx, cy, cz);
-    if (t == 0) out[i] = (int64_t)cur;
+    if (t == 0) {
+      out[i] = (IdxT)cur;
+      if (cout) {  // centroid gather fused in: the winner's xyz is already here
+        cout[i] = cx;
+        cout[M + i] = cy;
+        cout[2 * M + i] = cz;
+      }
+    }
   }
 }
 
@@ -213,16 +243,16 @@ static int ref_block_lg(int64_t n) {
   return cnt;
 }
 
-template <bool FMAD>
+template <bool FMAD, typename IdxT>
 static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
-                      int64_t* idx, void* ws, size_t ws_bytes,
+                      IdxT* idx, float* ctr, void* ws, size_t ws_bytes,
                       hipStream_t stream) {
   const int lg = ref_block_lg(N);
   const dim3 grid((unsigned)B), block(FPS_THREADS);
 #define S4G_FPS_CASE(P)                                                      \
   if (N <= (int64_t)FPS_THREADS * P) {                                       \
-    hipLaunchKernelGGL((fps_reg_kernel<P, FMAD>), grid, block, 0, stream,    \
-                       xyz, (int)N, (int)M, idx, lg);                        \
+    hipLaunchKernelGGL((fps_reg_kernel<P, FMAD, IdxT>), grid, block, 0,      \
+                       stream, xyz, (int)N, (int)M, idx, ctr, lg);           \
     S4G_LAUNCH_CHECK();                                                      \
     return S4G_OK;                                                           \
   }
@@ -235,8 +265,8 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
 #undef S4G_FPS_CASE
   if (ws_bytes < (size_t)B * (size_t)N * sizeof(float) || ws == nullptr)
     return S4G_EWORKSPACE;
-  hipLaunchKernelGGL((fps_stream_kernel<FMAD>), grid, block, 0, stream, xyz,
-                     (int)N, (int)M, idx, (float*)ws, lg);
+  hipLaunchKernelGGL((fps_stream_kernel<FMAD, IdxT>), grid, block, 0, stream,
+                     xyz, (int)N, (int)M, idx, ctr, (float*)ws, lg);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }
@@ -256,6 +286,19 @@ extern "C" int s4g_fps_f32(const float* xyz_b3n, int64_t B, int64_t N,
   if (!xyz_b3n || !idx_bm) return S4G_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (flags & S4G_FLAG_FMAD)
-    return s4g::launch_fps<true>(xyz_b3n, B, N, M, idx_bm, ws, ws_bytes, st);
-  return s4g::launch_fps<false>(xyz_b3n, B, N, M, idx_bm, ws, ws_bytes, st);
+    return s4g::launch_fps<true, int64_t>(xyz_b3n, B, N, M, idx_bm, nullptr, ws, ws_bytes, st);
+  return s4g::launch_fps<false, int64_t>(xyz_b3n, B, N, M, idx_bm, nullptr, ws, ws_bytes, st);
+}
+
+extern "C" int s4g_fps_gather_i32(const float* xyz_b3n, int64_t B, int64_t N,
+                                  int64_t M, int32_t* idx_bm, float* ctr_b3m,
+                                  void* ws, size_t ws_bytes, int flags,
+                                  s4g_stream_t stream) {
+  if (B < 0 || M <= 0 || N < M || N >= (1 << 23)) return S4G_EINVAL;
+  if (B == 0) return S4G_OK;
+  if (!xyz_b3n || !idx_bm || !ctr_b3m) return S4G_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (flags & S4G_FLAG_FMAD)
+    return s4g::launch_fps<true, int32_t>(xyz_b3n, B, N, M, idx_bm, ctr_b3m, ws, ws_bytes, st);
+  return s4g::launch_fps<false, int32_t>(xyz_b3n, B, N, M, idx_bm, ctr_b3m, ws, ws_bytes, st);
 }

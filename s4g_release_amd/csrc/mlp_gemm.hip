@@ -1,0 +1,448 @@
+// Shared-MLP contraction on the fp32 matrix cores of gfx950.
+//
+// Replaces, for inference, what the reference spreads over cuDNN/cuBLAS and
+// ATen kernels per layer (reference nn_utils/conv.py:28-34,68-74: 1x1 conv ->
+// BatchNorm -> ReLU; pointnet2_utils/modules.py:42-50 group + concat,
+// :242-243 max over neighbours, :118-127 interpolate + concat):
+//
+//   Y[p][n] = act( sum_k A[p][k] * W[n][k] + bias[n] )
+//
+// with BatchNorm folded into W/bias on the host, positions p as GEMM rows and
+// all activations stored CHANNELS-LAST ([position][channel]) so that
+//   * both MFMA operands are K-contiguous (16-byte LDS reads feed 4 MFMAs),
+//   * a grouped neighbour row is ONE contiguous C*4-byte gather,
+//   * the max over the K=64 neighbours of a centroid is an in-register max
+//     over the accumulator rows of one wave (the (B,C,M,K) pre-max tensor,
+//     335 MB/scene at SA1, is never written).
+// The A operand is produced by a fused loader:
+//   PLAIN   rows of a channels-last activation (optionally a column slice)
+//   GATHER  set-abstraction grouping: row = [feat[idx[p]] | xyz[idx[p]] - ctr]
+//           (modules.py:42-50; K order is [feat, xyz] -- W is permuted to match)
+//   INTERP  feature propagation: row = [sum_k w_k * sparse[idx_k] | dense[p]]
+//           (modules.py:118-127, interpolate_kernel.cu:160-174)
+// Arithmetic: v_mfma_f32_32x32x2_f32 -- exact fp32 products, fp32 accumulate
+// (bit-for-bit a k-ordered fmaf chain), so results stay within fp32 round-off
+// of the reference's fp32 convolution (tested to 1e-4 abs on the outputs).
+//
+// Tiling: 128 positions x 128 channels per 256-thread workgroup, 4 waves as
+// 2x2, each wave 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs).  K is walked
+// in 32-wide tiles staged global -> registers -> LDS (double buffered, one
+// barrier per tile; next tile's global loads are issued before the MFMAs of
+// the current one).  LDS rows are padded to 36 floats: conflict-free
+// ds_read_b128 for the 16-lane groups of gfx950.  Workgroup ids are remapped
+// so that the N-tiles sharing an A panel run back to back on one XCD (L2).
+#include "s4g_common.h"
+
+namespace s4g {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GM_BM = 128;
+constexpr int GM_BN = 128;
+constexpr int GM_BK = 32;
+constexpr int GM_LDS = 36;  // padded row stride (floats)
+constexpr int GM_THREADS = 256;
+
+enum { LOAD_PLAIN = 0, LOAD_GATHER = 1, LOAD_INTERP = 2 };
+enum { EPI_STORE = 0, EPI_MAX = 1, EPI_CHANNEL_FIRST = 2 };
+
+struct GemmParams {
+  // problem
+  int P, Cin, Kpad, Cout, relu;
+  const float* W;     // [groups][Cout][Kpad]
+  const float* bias;  // [groups][Cout]
+  // PLAIN: A + p*lda + a_coff + g*a_gcol
+  const float* A;
+  int lda, a_coff, a_gcol;
+  // GATHER: feat (B*N, Cf) channels-last, xyz (B,3,N), ctr (B,3,M), idx (B*M*K) int32
+  const int* gidx;
+  const float* feat;
+  const float* xyz;
+  const float* ctr;
+  int Cf, N, M, K;
+  // INTERP: sparse (B*N2, C2), dense (B*N1, C1), nidx/nw (B*N1, 3)
+  const int* nidx;
+  const float* nw;
+  const float* sparse;
+  const float* dense;
+  int C2, C1, N2, N1;
+  // output
+  float* out;  // STORE: out + p*ldc + c_coff + g*c_gcol ; MAX: row = p / K
+  int ldc, c_coff, c_gcol;
+  int w_gstride, b_gstride;
+  // CHANNEL_FIRST: out[b][c][n] split over up to 4 tensors
+  float* cf_ptr[4];
+  int cf_start[5];
+  int cf_sigmoid_from;  // channels >= this get a sigmoid
+  int cf_N;             // points per batch element
+  int mtiles, ntiles;
+};
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <int LOADER>
+struct ALoader {
+  // per-thread: 4 rows (t>>3)+32s, one 4-float chunk (t&7)
+  const float* src0[4];  // PLAIN: row base; GATHER: feat row base; INTERP: unused
+  bool ok[4];
+  // GATHER tail
+  float rel[4][3];
+  // INTERP
+  int i3[4][3];
+  float w3[4][3];
+  size_t drow[4];
+
+  __device__ __forceinline__ void init(const GemmParams& p, int p0, int g, int t) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int r = (t >> 3) + 32 * s;
+      const int pos = p0 + r;
+      ok[s] = pos < p.P;
+      const int pp = ok[s] ? pos : 0;
+      if constexpr (LOADER == LOAD_PLAIN) {
+        src0[s] = p.A + (size_t)pp * p.lda + p.a_coff + g * p.a_gcol;
+      } else if constexpr (LOADER == LOAD_GATHER) {
+        const int MK = p.M * p.K;
+        const int b = pp / MK;
+        const int m = (pp - b * MK) / p.K;
+        const int j = p.gidx[pp];
+        src0[s] = p.feat ? p.feat + ((size_t)b * p.N + j) * p.Cf : nullptr;
+        if ((t & 7) == 0) {
+          const float* x = p.xyz + (size_t)b * 3 * p.N;
+          const float* c = p.ctr + (size_t)b * 3 * p.M;
+          // group_xyz -= new_xyz (modules.py:44): one rounded subtraction
+          rel[s][0] = __fsub_rn(x[j], c[m]);
+          rel[s][1] = __fsub_rn(x[p.N + j], c[p.M + m]);
+          rel[s][2] = __fsub_rn(x[2 * p.N + j], c[2 * p.M + m]);
+        }
+      } else {
+        const int b = pp / p.N1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          i3[s][k] = b * p.N2 + p.nidx[(size_t)pp * 3 + k];
+          w3[s][k] = p.nw[(size_t)pp * 3 + k];
+        }
+        drow[s] = (size_t)pp;
+      }
+    }
+  }
+
+  // 4-float chunk of logical A row s at columns k0..k0+3
+  __device__ __forceinline__ float4 load(const GemmParams& p, int s, int k0, int t) const {
+    if (!ok[s]) return f4zero();
+    if constexpr (LOADER == LOAD_PLAIN) {
+      if (k0 >= p.Cin) return f4zero();
+      return *reinterpret_cast<const float4*>(src0[s] + k0);
+    } else if constexpr (LOADER == LOAD_GATHER) {
+      if (k0 < p.Cf) return *reinterpret_cast<const float4*>(src0[s] + k0);
+      if (k0 == p.Cf) return make_float4(rel[s][0], rel[s][1], rel[s][2], 0.f);
+      return f4zero();
+    } else {
+      if (k0 < p.C2) {
+        const float4 a = *reinterpret_cast<const float4*>(p.sparse + (size_t)i3[s][0] * p.C2 + k0);
+        const float4 b = *reinterpret_cast<const float4*>(p.sparse + (size_t)i3[s][1] * p.C2 + k0);
+        const float4 c = *reinterpret_cast<const float4*>(p.sparse + (size_t)i3[s][2] * p.C2 + k0);
+        float4 r;
+        // acc = 0; acc += f_k * w_k, k = 0,1,2 (interpolate_kernel.cu:160-174)
+        r.x = __fadd_rn(__fadd_rn(__fmul_rn(a.x, w3[s][0]), __fmul_rn(b.x, w3[s][1])), __fmul_rn(c.x, w3[s][2]));
+        r.y = __fadd_rn(__fadd_rn(__fmul_rn(a.y, w3[s][0]), __fmul_rn(b.y, w3[s][1])), __fmul_rn(c.y, w3[s][2]));
+        r.z = __fadd_rn(__fadd_rn(__fmul_rn(a.z, w3[s][0]), __fmul_rn(b.z, w3[s][1])), __fmul_rn(c.z, w3[s][2]));
+        r.w = __fadd_rn(__fadd_rn(__fmul_rn(a.w, w3[s][0]), __fmul_rn(b.w, w3[s][1])), __fmul_rn(c.w, w3[s][2]));
+        return r;
+      }
+      const int kd = k0 - p.C2;
+      if (kd < p.C1) return *reinterpret_cast<const float4*>(p.dense + drow[s] * p.C1 + kd);
+      return f4zero();
+    }
+  }
+};
+
+template <int LOADER, int EPI>
+__global__ __launch_bounds__(GM_THREADS, 2) void mlp_gemm_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                              // [2][BM][36]
+  float* Ws = smem + 2 * GM_BM * GM_LDS;         // [2][BN][36]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int g = blockIdx.y;
+
+  // XCD-aware bijective remap: consecutive ids on one XCD walk the N-tiles of
+  // one M-tile, so the shared A panel is an L2 hit.
+  const int nb = p.mtiles * p.ntiles;
+  int id = blockIdx.x;
+  {
+    const int q = nb >> 3, r = nb & 7, xcd = id & 7;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int mt = id / p.ntiles;
+  const int nt = id - mt * p.ntiles;
+  const int p0 = mt * GM_BM;
+  const int n0 = nt * GM_BN;
+
+  const float* __restrict__ Wg = p.W + (size_t)g * p.w_gstride;
+  const float* __restrict__ bg = p.bias + (size_t)g * p.b_gstride;
+
+  ALoader<LOADER> ld;
+  ld.init(p, p0, g, t);
+  const int chunk = t & 7;
+  const int srow = t >> 3;
+  const float* wrow[4];
+  bool wok[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int n = n0 + srow + 32 * s;
+    wok[s] = n < p.Cout;
+    wrow[s] = Wg + (size_t)(wok[s] ? n : 0) * p.Kpad;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int a_off = (wr * 64 + li) * GM_LDS + 4 * lh;
+  const int b_off = (wc * 64 + li) * GM_LDS + 4 * lh;
+  const int st_off = srow * GM_LDS + chunk * 4;
+
+  float4 ra[4], rw[4];
+  const int ntile_k = (p.Kpad + GM_BK - 1) / GM_BK;
+
+  auto gload = [&](int kt) {
+    const int k0 = kt * GM_BK + chunk * 4;
+    const bool live = k0 < p.Kpad;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      ra[s] = live ? ld.load(p, s, k0, t) : f4zero();
+      rw[s] = (live && wok[s]) ? *reinterpret_cast<const float4*>(wrow[s] + k0) : f4zero();
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* a = As + buf * GM_BM * GM_LDS + st_off;
+    float* w = Ws + buf * GM_BN * GM_LDS + st_off;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      *reinterpret_cast<float4*>(a + 32 * s * GM_LDS) = ra[s];
+      *reinterpret_cast<float4*>(w + 32 * s * GM_LDS) = rw[s];
+    }
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < ntile_k; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < ntile_k) gload(kt + 1);
+    const int krem = p.Kpad - kt * GM_BK;
+    const int nq = krem >= GM_BK ? 4 : (krem >> 3);
+    const float* a = As + buf * GM_BM * GM_LDS + a_off;
+    const float* w = Ws + buf * GM_BN * GM_LDS + b_off;
+    for (int q = 0; q < nq; ++q) {
+      const float4 a0 = *reinterpret_cast<const float4*>(a + 8 * q);
+      const float4 a1 = *reinterpret_cast<const float4*>(a + 32 * GM_LDS + 8 * q);
+      const float4 b0 = *reinterpret_cast<const float4*>(w + 8 * q);
+      const float4 b1 = *reinterpret_cast<const float4*>(w + 32 * GM_LDS + 8 * q);
+      const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+      const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][r], bv[0][r], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][r], bv[1][r], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][r], bv[0][r], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][r], bv[1][r], acc[1][1], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < ntile_k) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int n = n0 + wc * 64 + cb * 32 + li;
+    const bool nok = n < p.Cout;
+    const float bias = nok ? bg[n] : 0.f;
+    if constexpr (EPI == EPI_STORE) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = p0 + wr * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          float v = acc[rb][cb][r] + bias;
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (nok && row < p.P)
+            p.out[(size_t)row * p.ldc + p.c_coff + g * p.c_gcol + n] = v;
+        }
+    } else if constexpr (EPI == EPI_MAX) {
+      // max over groups of K consecutive rows, K in {16, 32, 64}; then
+      // bias + ReLU (monotone, so max-then-activate == activate-then-max).
+      if (p.K == 64) {
+        float m = acc[0][cb][0];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[rb][cb][r]);
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float v = m + bias;
+        if (p.relu) v = fmaxf(v, 0.f);
+        const int grp = (p0 + wr * 64) >> 6;
+        if (nok && lh == 0 && p0 + wr * 64 < p.P)
+          p.out[(size_t)grp * p.ldc + p.c_coff + n] = v;
+      } else if (p.K == 32) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          float m = acc[rb][cb][0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rb][cb][r]);
+          m = fmaxf(m, __shfl_xor(m, 32));
+          float v = m + bias;
+          if (p.relu) v = fmaxf(v, 0.f);
+          const int row0 = p0 + wr * 64 + rb * 32;
+          if (nok && lh == 0 && row0 < p.P)
+            p.out[(size_t)(row0 >> 5) * p.ldc + p.c_coff + n] = v;
+        }
+      } else {  // K == 16: rows 0-15 are regs with (r>>2) in {0,1}, rows 16-31 {2,3}
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            float m = acc[rb][cb][8 * hh];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) m = fmaxf(m, acc[rb][cb][8 * hh + r]);
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float v = m + bias;
+            if (p.relu) v = fmaxf(v, 0.f);
+            const int row0 = p0 + wr * 64 + rb * 32 + 16 * hh;
+            if (nok && lh == 0 && row0 < p.P)
+              p.out[(size_t)(row0 >> 4) * p.ldc + p.c_coff + n] = v;
+          }
+      }
+    } else {  // EPI_CHANNEL_FIRST: out[b][c][n_pt], 4 consecutive points per store
+      int head = 0;
+#pragma unroll
+      for (int h2 = 1; h2 < 4; ++h2)
+        if (n >= p.cf_start[h2]) head = h2;
+      const int cl = n - p.cf_start[head];
+      const int ch = p.cf_start[head + 1] - p.cf_start[head];
+      float* base = p.cf_ptr[head];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int row = p0 + wr * 64 + rb * 32 + 8 * r4 + 4 * lh;
+          if (nok && n < p.cf_start[4] && row < p.P) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x = acc[rb][cb][4 * r4 + e] + bias;
+              if (p.relu) x = fmaxf(x, 0.f);
+              if (n >= p.cf_sigmoid_from) x = 1.0f / (1.0f + expf(-x));
+              v[e] = x;
+            }
+            const int b = row / p.cf_N;
+            const int pt = row - b * p.cf_N;
+            float* dst = base + ((size_t)b * ch + cl) * p.cf_N + pt;
+            if (pt + 3 < p.cf_N && (p.cf_N & 3) == 0) {
+              *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int row_e = row + e;
+                if (row_e < p.P) {
+                  const int be = row_e / p.cf_N;
+                  const int pe = row_e - be * p.cf_N;
+                  base[((size_t)be * ch + cl) * p.cf_N + pe] = v[e];
+                }
+              }
+            }
+          }
+        }
+    }
+  }
+}
+
+template <int LOADER, int EPI>
+static int launch_gemm(const GemmParams& p, int groups, hipStream_t st) {
+  const size_t lds = sizeof(float) * 2 * (GM_BM + GM_BN) * GM_LDS;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&mlp_gemm_kernel<LOADER, EPI>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  const dim3 grid((unsigned)(p.mtiles * p.ntiles), (unsigned)groups);
+  hipLaunchKernelGGL((mlp_gemm_kernel<LOADER, EPI>), grid, dim3(GM_THREADS), lds, st, p);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
+
+}  // namespace s4g
+
+extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
+  using namespace s4g;
+  if (!d || d->P < 0 || d->Cout <= 0 || d->Kpad <= 0 || (d->Kpad & 7) || d->groups <= 0 ||
+      !d->W || !d->bias)
+    return S4G_EINVAL;
+  if (d->P == 0) return S4G_OK;
+  GemmParams p;
+  p.P = d->P; p.Cin = d->Cin; p.Kpad = d->Kpad; p.Cout = d->Cout; p.relu = d->relu;
+  p.W = d->W; p.bias = d->bias;
+  p.A = d->A; p.lda = d->lda; p.a_coff = d->a_coff; p.a_gcol = d->a_gcol;
+  p.gidx = d->gidx; p.feat = d->feat; p.xyz = d->xyz; p.ctr = d->ctr;
+  p.Cf = d->Cf; p.N = d->N; p.M = d->M; p.K = d->K;
+  p.nidx = d->nidx; p.nw = d->nw; p.sparse = d->sparse; p.dense = d->dense;
+  p.C2 = d->C2; p.C1 = d->C1; p.N2 = d->N2; p.N1 = d->N1;
+  p.out = d->out; p.ldc = d->ldc; p.c_coff = d->c_coff; p.c_gcol = d->c_gcol;
+  p.w_gstride = d->w_gstride; p.b_gstride = d->b_gstride;
+  for (int i = 0; i < 4; ++i) p.cf_ptr[i] = d->cf_ptr[i];
+  for (int i = 0; i < 5; ++i) p.cf_start[i] = d->cf_start[i];
+  p.cf_sigmoid_from = d->cf_sigmoid_from; p.cf_N = d->cf_N;
+  p.mtiles = (d->P + GM_BM - 1) / GM_BM;
+  p.ntiles = (d->Cout + GM_BN - 1) / GM_BN;
+  hipStream_t st = (hipStream_t)stream;
+
+  // loader-specific validation
+  if (d->loader == S4G_GEMM_LOAD_PLAIN) {
+    if (!d->A || (d->lda & 3) || (d->a_coff & 3) || (d->a_gcol & 3) || (d->Cin & 3)) return S4G_EINVAL;
+  } else if (d->loader == S4G_GEMM_LOAD_GATHER) {
+    if (!d->gidx || !d->xyz || !d->ctr || (d->Cf & 31) || (d->Cf > 0 && !d->feat) ||
+        d->K <= 0 || d->M <= 0 || d->N <= 0 || d->groups != 1)
+      return S4G_EINVAL;
+  } else if (d->loader == S4G_GEMM_LOAD_INTERP) {
+    if (!d->nidx || !d->nw || !d->sparse || (d->C2 & 31) || (d->C1 & 3) ||
+        (d->C1 > 0 && !d->dense) || d->N1 <= 0 || d->N2 <= 0 || d->groups != 1)
+      return S4G_EINVAL;
+  } else {
+    return S4G_EINVAL;
+  }
+  if (d->epilogue == S4G_GEMM_EPI_MAX) {
+    if (!(d->K == 16 || d->K == 32 || d->K == 64) || d->groups != 1 || !d->out) return S4G_EINVAL;
+  } else if (d->epilogue == S4G_GEMM_EPI_STORE) {
+    if (!d->out) return S4G_EINVAL;
+  } else if (d->epilogue == S4G_GEMM_EPI_CHANNEL_FIRST) {
+    if (d->cf_N <= 0 || d->groups != 1) return S4G_EINVAL;
+  } else {
+    return S4G_EINVAL;
+  }
+
+#define S4G_GEMM_CASE(L, E)                                            \
+  if (d->loader == L && d->epilogue == E)                              \
+    return launch_gemm<L, E>(p, d->groups, st);
+  S4G_GEMM_CASE(LOAD_PLAIN, EPI_STORE)
+  S4G_GEMM_CASE(LOAD_PLAIN, EPI_MAX)
+  S4G_GEMM_CASE(LOAD_PLAIN, EPI_CHANNEL_FIRST)
+  S4G_GEMM_CASE(LOAD_GATHER, EPI_STORE)
+  S4G_GEMM_CASE(LOAD_GATHER, EPI_MAX)
+  S4G_GEMM_CASE(LOAD_INTERP, EPI_STORE)
+#undef S4G_GEMM_CASE
+  return S4G_EUNSUPPORTED;
+}

@@ -18,10 +18,12 @@ namespace s4g {
 
 constexpr int NN_THREADS = 256;
 
-template <bool FMAD>
+// WEIGHTS: write the inverse-distance weights of modules.py:118-120 instead of
+// the squared distances (same arithmetic as interp_weights_kernel below).
+template <bool FMAD, bool WEIGHTS, typename IdxT>
 __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(
     const float* __restrict__ q, const float* __restrict__ key, int N1, int N2,
-    int64_t* __restrict__ idx, float* __restrict__ d2out) {
+    float eps, IdxT* __restrict__ idx, float* __restrict__ d2out) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * NN_THREADS + threadIdx.x;
   const float* __restrict__ qx = q + (size_t)b * 3 * N1;
@@ -50,12 +52,22 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(
   }
   if (i < N1) {
     const size_t o = ((size_t)b * N1 + i) * 3;
-    idx[o + 0] = (int64_t)i0;
-    idx[o + 1] = (int64_t)i1;
-    idx[o + 2] = (int64_t)i2;
-    d2out[o + 0] = b0;
-    d2out[o + 1] = b1;
-    d2out[o + 2] = b2;
+    idx[o + 0] = (IdxT)i0;
+    idx[o + 1] = (IdxT)i1;
+    idx[o + 2] = (IdxT)i2;
+    if constexpr (WEIGHTS) {
+      const float ia = __fdiv_rn(1.0f, b0 < eps ? eps : b0);
+      const float ib = __fdiv_rn(1.0f, b1 < eps ? eps : b1);
+      const float ic = __fdiv_rn(1.0f, b2 < eps ? eps : b2);
+      const float s = __fadd_rn(__fadd_rn(ia, ib), ic);
+      d2out[o + 0] = __fdiv_rn(ia, s);
+      d2out[o + 1] = __fdiv_rn(ib, s);
+      d2out[o + 2] = __fdiv_rn(ic, s);
+    } else {
+      d2out[o + 0] = b0;
+      d2out[o + 1] = b1;
+      d2out[o + 2] = b2;
+    }
   }
 }
 
@@ -93,13 +105,40 @@ extern "C" int s4g_three_nn_f32(const float* q_b3n1, const float* k_b3n2,
                   (unsigned)B);
   hipStream_t st = (hipStream_t)stream;
   if (flags & S4G_FLAG_FMAD)
-    hipLaunchKernelGGL((s4g::three_nn_kernel<true>), grid,
+    hipLaunchKernelGGL((s4g::three_nn_kernel<true, false, int64_t>), grid,
                        dim3(s4g::NN_THREADS), 0, st, q_b3n1, k_b3n2, (int)N1,
-                       (int)N2, idx_bn3, d2_bn3);
+                       (int)N2, 0.f, idx_bn3, d2_bn3);
   else
-    hipLaunchKernelGGL((s4g::three_nn_kernel<false>), grid,
+    hipLaunchKernelGGL((s4g::three_nn_kernel<false, false, int64_t>), grid,
                        dim3(s4g::NN_THREADS), 0, st, q_b3n1, k_b3n2, (int)N1,
-                       (int)N2, idx_bn3, d2_bn3);
+                       (int)N2, 0.f, idx_bn3, d2_bn3);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
+
+extern "C" int s4g_three_nn_weights_i32(const float* q_b3n1, const float* k_b3n2,
+                                        int64_t B, int64_t N1, int64_t N2,
+                                        float eps, int32_t* idx_bn3,
+                                        float* w_bn3, void* ws, size_t ws_bytes,
+                                        int flags, s4g_stream_t stream) {
+  (void)ws;
+  (void)ws_bytes;
+  if (B < 0 || N1 < 0 || N2 < 3 || B > 65535 || N2 >= (1ll << 31) ||
+      N1 >= (1ll << 31))
+    return S4G_EINVAL;
+  if (B == 0 || N1 == 0) return S4G_OK;
+  if (!q_b3n1 || !k_b3n2 || !idx_bn3 || !w_bn3) return S4G_EINVAL;
+  const dim3 grid((unsigned)((N1 + s4g::NN_THREADS - 1) / s4g::NN_THREADS),
+                  (unsigned)B);
+  hipStream_t st = (hipStream_t)stream;
+  if (flags & S4G_FLAG_FMAD)
+    hipLaunchKernelGGL((s4g::three_nn_kernel<true, true, int32_t>), grid,
+                       dim3(s4g::NN_THREADS), 0, st, q_b3n1, k_b3n2, (int)N1,
+                       (int)N2, eps, idx_bn3, w_bn3);
+  else
+    hipLaunchKernelGGL((s4g::three_nn_kernel<false, true, int32_t>), grid,
+                       dim3(s4g::NN_THREADS), 0, st, q_b3n1, k_b3n2, (int)N1,
+                       (int)N2, eps, idx_bn3, w_bn3);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }

@@ -64,7 +64,7 @@ class OpTimer:
     Events are recorded on the stream the kernel is launched on (torch's
     current stream), immediately before and after the launch."""
     enabled = False
-    records = []   # (op name, start event, end event, algorithmic bytes)
+    records = []   # (op name, start event, end event, algorithmic bytes, flops)
 
     @classmethod
     def reset(cls, enabled):
@@ -73,17 +73,17 @@ class OpTimer:
 
     @classmethod
     def summary(cls):
-        """{op: (launches, mean ms, algorithmic bytes per launch)}; call after a sync."""
+        """{op: (launches, mean ms, algorithmic bytes, flops per launch)}; call after a sync."""
         acc = {}
-        for name, e0, e1, nbytes in cls.records:
-            n, t, b = acc.get(name, (0, 0.0, 0))
-            acc[name] = (n + 1, t + e0.elapsed_time(e1), b + nbytes)
-        return {k: (n, t / n, b / n) for k, (n, t, b) in acc.items()}
+        for name, e0, e1, nbytes, flops in cls.records:
+            n, t, b, f = acc.get(name, (0, 0.0, 0, 0.0))
+            acc[name] = (n + 1, t + e0.elapsed_time(e1), b + nbytes, f + flops)
+        return {k: (n, t / n, b / n, f / n) for k, (n, t, b, f) in acc.items()}
 
 
 class _timed:
-    def __init__(self, name, nbytes):
-        self.name, self.nbytes = name, nbytes
+    def __init__(self, name, nbytes, flops=0.0):
+        self.name, self.nbytes, self.flops = name, nbytes, flops
 
     def __enter__(self):
         if OpTimer.enabled:
@@ -95,7 +95,7 @@ class _timed:
     def __exit__(self, *exc):
         if OpTimer.enabled:
             self.e1.record()
-            OpTimer.records.append((self.name, self.e0, self.e1, self.nbytes))
+            OpTimer.records.append((self.name, self.e0, self.e1, self.nbytes, self.flops))
         return False
 
 

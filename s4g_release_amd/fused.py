@@ -1,0 +1,290 @@
+"""Inference fast path of the S4G network on MI355X.
+
+Same function as `model.PointNet2.forward` in eval mode (reference
+`network_models/models/PointNet2_tcls.py:99-148`), restructured for the
+hardware instead of for torch's operator set:
+
+  * BatchNorm (eval) is folded into the 1x1-conv weights once:
+    W' = W * gamma / sqrt(var + eps),  b' = beta - mean * gamma / sqrt(var + eps)
+    (reference nn_utils/conv.py:28-34: conv -> bn -> relu);
+  * every activation is channels-last and every layer is ONE launch of the
+    fp32-MFMA contraction `s4g_mlp_gemm_f32` with a fused loader (grouping +
+    centroid subtraction + concat, or 3-NN interpolation + concat) and a fused
+    epilogue (bias, ReLU, max over the K neighbours, or the channel-first head
+    outputs with the movable-head sigmoid);  the (B,C,M,K) grouped tensors and
+    the (B,C,N) interpolated tensors are never materialised;
+  * the four heads share their input, so their first layers run as one
+    256 -> 4x512 contraction, the middle layers as 4-group launches and the
+    four logit layers as one block-diagonal 512 -> 21 contraction;
+  * FPS also emits the centroid coordinates (no gather launch), ball query and
+    3-NN emit int32 indices, 3-NN emits the interpolation weights directly.
+
+The geometry (FPS / ball query / 3-NN) uses exactly the kernels behind the
+operator API, so indices are bit-identical to `functions.py`.
+"""
+import ctypes
+
+import torch
+
+from . import _cabi
+from . import functions as _F
+
+_i32 = ctypes.c_int32
+_fp = ctypes.c_void_p
+GemmDesc = _cabi.GemmDesc
+
+LOAD_PLAIN, LOAD_GATHER, LOAD_INTERP = 0, 1, 2
+EPI_STORE, EPI_MAX, EPI_CF = 0, 1, 2
+
+
+def fold_conv_bn(block):
+    """(W', b') of one conv->bn(->relu) block, fp64 folding rounded once to fp32."""
+    w = block.conv.weight.detach().double().flatten(1)      # (Cout, Cin)
+    if block.bn is None:
+        b = block.conv.bias.detach().double() if block.conv.bias is not None else \
+            torch.zeros(w.shape[0], dtype=torch.float64, device=w.device)
+        return w.float(), b.float()
+    bn = block.bn
+    scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+    wf = w * scale[:, None]
+    bf = bn.bias.detach().double() - bn.running_mean.detach().double() * scale
+    if block.conv.bias is not None:
+        bf = bf + block.conv.bias.detach().double() * scale
+    return wf.float(), bf.float()
+
+
+def _pad_k(w, mult=8):
+    cout, k = w.shape
+    kpad = (k + mult - 1) // mult * mult
+    if kpad == k:
+        return w.contiguous()
+    out = w.new_zeros((cout, kpad))
+    out[:, :k] = w
+    return out
+
+
+class _Layer:
+    """Folded weights of one launch: W (groups, Cout, Kpad), bias (groups, Cout)."""
+
+    def __init__(self, W, bias, cin, groups=1):
+        self.W = W.contiguous()
+        self.bias = bias.contiguous()
+        self.groups = groups
+        self.cout = self.W.shape[-2]
+        self.kpad = self.W.shape[-1]
+        self.cin = cin
+
+
+class FusedPointNet2:
+    """Callable with the reference forward's signature: {"scene_points": (B,3,N)} -> dict."""
+
+    def __init__(self, net):
+        p = next(net.parameters())
+        if not p.is_cuda:
+            raise RuntimeError("FusedPointNet2 needs the model on a HIP device (no CPU fallback)")
+        if net.training:
+            raise RuntimeError("FusedPointNet2 is inference-only: call net.eval() first")
+        self.dev = p.device
+        _cabi.lib()
+        self.sa = []
+        for sa in net.sa_modules:
+            if sa.sampler is None or sa.grouper is None:
+                raise NotImplementedError("fast path covers sampled + grouped SA modules only")
+            if sa.grouper.num_neighbours not in (16, 32, 64):
+                raise NotImplementedError("fast path needs num_neighbours in {16, 32, 64}")
+            layers = []
+            for li, blk in enumerate(sa.mlp):
+                w, b = fold_conv_bn(blk)
+                if li == 0:
+                    # reference K order [xyz(3), feat(C)] (modules.py:50) -> ours [feat, xyz]
+                    w = torch.cat([w[:, 3:], w[:, :3]], dim=1)
+                    cin = w.shape[1]
+                else:
+                    cin = w.shape[1]
+                layers.append(_Layer(_pad_k(w), b, cin))
+            self.sa.append(dict(M=sa.num_centroids, radius=float(sa.grouper.radius),
+                                K=int(sa.grouper.num_neighbours), layers=layers,
+                                cf=sa.in_channels))
+        self.fp = []
+        for fp in net.fp_modules:
+            if fp.interpolator is None:
+                raise NotImplementedError("fast path covers 3-NN FP modules only")
+            layers = []
+            for blk in fp.mlp:
+                w, b = fold_conv_bn(blk)
+                layers.append(_Layer(_pad_k(w), b, w.shape[1]))
+            self.fp.append(dict(layers=layers, eps=float(fp.interpolator._eps)))
+        # heads: order score, R, t, movable (PointNet2_tcls.py:126-140)
+        heads = [(net.mlp_seg, net.seg_logit), (net.mlp_R, net.R_logit), (net.mlp_t, net.t_logit),
+                 (net.mlp_movable, net.movable_logit[0])]
+        depth = len(net.mlp_seg)
+        self.head_layers = []
+        folded = [[fold_conv_bn(blk) for blk in mlp] for mlp, _ in heads]
+        w0 = torch.cat([f[0][0] for f in folded], dim=0)          # (4*C1, Cin) shared input
+        b0 = torch.cat([f[0][1] for f in folded], dim=0)
+        self.head_layers.append(_Layer(_pad_k(w0), b0, w0.shape[1]))
+        for li in range(1, depth):
+            W = torch.stack([_pad_k(f[li][0]) for f in folded], dim=0)
+            bias = torch.stack([f[li][1] for f in folded], dim=0)
+            self.head_layers.append(_Layer(W, bias, folded[0][li][0].shape[1], groups=4))
+        chans = [lg.weight.shape[0] for _, lg in heads]
+        self.head_channels = chans
+        cl = heads[0][1].weight.shape[1]
+        wl = torch.zeros((sum(chans), 4 * cl), dtype=torch.float32, device=self.dev)
+        bl = torch.zeros((sum(chans),), dtype=torch.float32, device=self.dev)
+        r = 0
+        for h, (_, lg) in enumerate(heads):
+            c = lg.weight.shape[0]
+            wl[r:r + c, h * cl:(h + 1) * cl] = lg.weight.detach().flatten(1)
+            bl[r:r + c] = lg.bias.detach()
+            r += c
+        self.logit_layer = _Layer(_pad_k(wl), bl, 4 * cl)
+        self.sigmoid_from = sum(chans[:3])
+
+    # ------------------------------------------------------------------ launches
+    def _gemm(self, name, layer, P, loader, epi, relu=True, **kw):
+        d = GemmDesc()
+        d.loader, d.epilogue, d.groups, d.relu = loader, epi, layer.groups, int(relu)
+        d.P, d.Cin, d.Kpad, d.Cout = P, layer.cin, layer.kpad, layer.cout
+        d.W, d.bias = layer.W.data_ptr(), layer.bias.data_ptr()
+        d.w_gstride, d.b_gstride = layer.cout * layer.kpad, layer.cout
+        for k, v in kw.items():
+            if isinstance(v, torch.Tensor):
+                v = v.data_ptr()
+            setattr(d, k, v)
+        flops = 2.0 * P * layer.cout * layer.cin * layer.groups
+        with _F._timed("gemm[%s P=%d K=%d N=%dx%d]" % (name, P, layer.cin, layer.groups, layer.cout),
+                       0, flops):
+            rc = _cabi.lib().s4g_mlp_gemm_f32(ctypes.byref(d), _F._stream())
+        _cabi.check(rc, "mlp_gemm " + name)
+
+    def _fps_gather(self, xyz, M):
+        B, _, N = xyz.shape
+        idx = torch.empty((B, M), dtype=torch.int32, device=xyz.device)
+        ctr = torch.empty((B, 3, M), dtype=torch.float32, device=xyz.device)
+        ws, nbytes = _F._workspace(_cabi.S4G_OP_FPS, xyz.device, B, N, M, 0)
+        with _F._timed("fps[N=%d,M=%d]" % (N, M), B * (12 * N + 8 * M)):
+            rc = _cabi.lib().s4g_fps_gather_i32(xyz.data_ptr(), B, N, M, idx.data_ptr(),
+                                                ctr.data_ptr(), _F._ptr(ws), nbytes,
+                                                _F._DIST_FLAGS, _F._stream())
+        _cabi.check(rc, "fps_gather")
+        return idx, ctr
+
+    def _ball_query(self, xyz, ctr, radius, K):
+        B, _, N = xyz.shape
+        M = ctr.shape[2]
+        idx = torch.empty((B, M, K), dtype=torch.int32, device=xyz.device)
+        cnt = torch.empty((B, M), dtype=torch.int32, device=xyz.device)
+        ws, nbytes = _F._workspace(_cabi.S4G_OP_BALL_QUERY, xyz.device, B, N, M, K)
+        with _F._timed("ball_query[N=%d,M=%d,K=%d]" % (N, M, K),
+                       B * (12 * N + 12 * M + 8 * M * K + 8 * M)):
+            rc = _cabi.lib().s4g_ball_query_i32(xyz.data_ptr(), ctr.data_ptr(), B, N, M, radius, K,
+                                                idx.data_ptr(), cnt.data_ptr(), _F._ptr(ws), nbytes,
+                                                _F._DIST_FLAGS, _F._stream())
+        _cabi.check(rc, "ball_query_i32")
+        return idx, cnt
+
+    def _three_nn(self, q, k, eps):
+        B, _, N1 = q.shape
+        N2 = k.shape[2]
+        idx = torch.empty((B, N1, 3), dtype=torch.int32, device=q.device)
+        w = torch.empty((B, N1, 3), dtype=torch.float32, device=q.device)
+        with _F._timed("three_nn[N1=%d,N2=%d]" % (N1, N2), B * (12 * N2 + 12 * N1 + 24 * N1 + 12 * N1)):
+            rc = _cabi.lib().s4g_three_nn_weights_i32(q.data_ptr(), k.data_ptr(), B, N1, N2, eps,
+                                                      idx.data_ptr(), w.data_ptr(), None, 0,
+                                                      _F._DIST_FLAGS, _F._stream())
+        _cabi.check(rc, "three_nn_weights_i32")
+        return idx, w
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def __call__(self, data_batch, return_intermediates=False):
+        xyz = _F._f32c(data_batch["scene_points"], "scene_points")
+        if xyz.dim() != 3 or xyz.size(1) != 3:
+            raise RuntimeError("scene_points must be (B, 3, N)")
+        B, _, N0 = xyz.shape
+        dev = xyz.device
+        inter = {}
+        with torch.cuda.device(dev):
+            level_xyz, level_feat, level_n = [xyz], [None], [N0]
+            feat, n_cur = None, N0
+            for li, sa in enumerate(self.sa):
+                M, K = sa["M"], sa["K"]
+                if not n_cur >= M:
+                    raise RuntimeError("num_points is not greater than or equal to num_centroids")
+                idx, ctr = self._fps_gather(level_xyz[-1], M)
+                gidx, gcnt = self._ball_query(level_xyz[-1], ctr, sa["radius"], K)
+                inter["fps%d" % li], inter["ball%d" % li], inter["cnt%d" % li] = idx, gidx, gcnt
+                P = B * M * K
+                layers = sa["layers"]
+                x = None
+                for l, layer in enumerate(layers):
+                    last = l == len(layers) - 1
+                    rows = B * M if last else P
+                    out = torch.empty((rows, layer.cout), dtype=torch.float32, device=dev)
+                    kw = dict(out=out, ldc=layer.cout, K=K)
+                    if l == 0:
+                        kw.update(gidx=gidx, feat=feat, xyz=level_xyz[-1], ctr=ctr,
+                                  Cf=sa["cf"], N=n_cur, M=M)
+                        loader = LOAD_GATHER
+                    else:
+                        kw.update(A=x, lda=x.shape[1])
+                        loader = LOAD_PLAIN
+                    self._gemm("sa%d.%d" % (li, l), layer, P, loader, EPI_MAX if last else EPI_STORE,
+                               **kw)
+                    x = out
+                feat, n_cur = x, M
+                level_xyz.append(ctr)
+                level_feat.append(feat)
+                level_n.append(M)
+
+            sparse_xyz, sparse_feat, n_sparse = level_xyz[-1], level_feat[-1], level_n[-1]
+            for fi, fp in enumerate(self.fp):
+                dense_xyz, dense_feat, n_dense = level_xyz[-2 - fi], level_feat[-2 - fi], level_n[-2 - fi]
+                nidx, nw = self._three_nn(dense_xyz, sparse_xyz, fp["eps"])
+                inter["nn%d" % fi], inter["nnw%d" % fi] = nidx, nw
+                P = B * n_dense
+                x = None
+                for l, layer in enumerate(fp["layers"]):
+                    out = torch.empty((P, layer.cout), dtype=torch.float32, device=dev)
+                    if l == 0:
+                        c1 = 0 if dense_feat is None else dense_feat.shape[1]
+                        self._gemm("fp%d.%d" % (fi, l), layer, P, LOAD_INTERP, EPI_STORE, out=out,
+                                   ldc=layer.cout, nidx=nidx, nw=nw, sparse=sparse_feat,
+                                   dense=dense_feat, C2=sparse_feat.shape[1], C1=c1, N2=n_sparse,
+                                   N1=n_dense)
+                    else:
+                        self._gemm("fp%d.%d" % (fi, l), layer, P, LOAD_PLAIN, EPI_STORE, out=out,
+                                   ldc=layer.cout, A=x, lda=x.shape[1])
+                    x = out
+                sparse_xyz, sparse_feat, n_sparse = dense_xyz, x, n_dense
+
+            # heads
+            P = B * N0
+            x = sparse_feat
+            l0 = self.head_layers[0]
+            h = torch.empty((P, l0.cout), dtype=torch.float32, device=dev)
+            self._gemm("heads.0", l0, P, LOAD_PLAIN, EPI_STORE, out=h, ldc=l0.cout, A=x,
+                       lda=x.shape[1])
+            x = h
+            for l, layer in enumerate(self.head_layers[1:], start=1):
+                h = torch.empty((P, 4 * layer.cout), dtype=torch.float32, device=dev)
+                self._gemm("heads.%d" % l, layer, P, LOAD_PLAIN, EPI_STORE, out=h,
+                           ldc=4 * layer.cout, c_gcol=layer.cout, A=x, lda=x.shape[1],
+                           a_gcol=layer.cin)
+                x = h
+            names = ("score", "frame_R", "frame_t", "movable_logits")
+            outs = [torch.empty((B, c, N0), dtype=torch.float32, device=dev)
+                    for c in self.head_channels]
+            starts = [0]
+            for c in self.head_channels:
+                starts.append(starts[-1] + c)
+            cf_ptr = (_fp * 4)(*[o.data_ptr() for o in outs])
+            cf_start = (_i32 * 5)(*starts)
+            self._gemm("heads.logits", self.logit_layer, P, LOAD_PLAIN, EPI_CF, relu=False, A=x,
+                       lda=x.shape[1], cf_ptr=cf_ptr, cf_start=cf_start,
+                       cf_sigmoid_from=self.sigmoid_from, cf_N=N0)
+        pred = dict(zip(names, outs))
+        if return_intermediates:
+            return pred, inter
+        return pred

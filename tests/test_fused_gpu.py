@@ -1,0 +1,214 @@
+"""GPU tests of the inference fast path (fp32-MFMA shared-MLP contraction with
+fused group / interpolate / max / head epilogues).  Unit tests compare each
+loader x epilogue against a plain fp32 torch restatement of the same layer;
+model tests compare against the golden fixtures captured from the reference's
+Python network (1e-4 abs; indices bit-exact)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as GU
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _run(desc_kwargs, dev):
+    from s4g_release_amd import _cabi
+    d = _cabi.GemmDesc()
+    keep = []
+    for k, v in desc_kwargs.items():
+        if isinstance(v, torch.Tensor):
+            keep.append(v)
+            v = v.data_ptr()
+        setattr(d, k, v)
+    rc = _cabi.lib().s4g_mlp_gemm_f32(ctypes.byref(d), torch.cuda.current_stream().cuda_stream)
+    _cabi.check(rc, "gemm")
+    torch.cuda.synchronize()
+
+
+def _padk(w):
+    k = w.shape[-1]
+    kp = (k + 7) // 8 * 8
+    out = w.new_zeros(w.shape[:-1] + (kp,))
+    out[..., :k] = w
+    return out.contiguous()
+
+
+@pytest.mark.parametrize("P,Cin,Cout,relu", [(128, 32, 128, True), (1000, 128, 256, True),
+                                             (77, 260, 21, False), (4096, 1536, 1024, True),
+                                             (300, 8, 130, True)])
+def test_gemm_plain_store(dev, P, Cin, Cout, relu):
+    g = torch.Generator(device="cpu").manual_seed(P + Cin)
+    A = torch.randn(P, Cin, generator=g).to(dev)
+    W = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    out = torch.full((P, Cout), float("nan"), device=dev)
+    Wp = _padk(W)
+    _run(dict(loader=0, epilogue=0, groups=1, relu=int(relu), P=P, Cin=Cin, Kpad=Wp.shape[1],
+              Cout=Cout, W=Wp, bias=b, A=A, lda=Cin, out=out, ldc=Cout), dev)
+    ref = A.double() @ W.double().t() + b.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_grouped_column_slices(dev):
+    g = torch.Generator(device="cpu").manual_seed(3)
+    P, G, Cin, Cout = 700, 4, 64, 48
+    A = torch.randn(P, G * Cin, generator=g).to(dev)
+    W = (torch.randn(G, Cout, Cin, generator=g) / 8).to(dev)
+    b = torch.randn(G, Cout, generator=g).to(dev)
+    out = torch.full((P, G * Cout), float("nan"), device=dev)
+    _run(dict(loader=0, epilogue=0, groups=G, relu=1, P=P, Cin=Cin, Kpad=Cin, Cout=Cout, W=W,
+              bias=b, w_gstride=Cout * Cin, b_gstride=Cout, A=A, lda=G * Cin, a_gcol=Cin, out=out,
+              ldc=G * Cout, c_gcol=Cout), dev)
+    for i in range(G):
+        ref = (A[:, i * Cin:(i + 1) * Cin].double() @ W[i].double().t() + b[i].double()).clamp_min(0)
+        assert (out[:, i * Cout:(i + 1) * Cout].double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("K", [16, 32, 64])
+@pytest.mark.parametrize("Cf", [0, 64])
+def test_gemm_gather_max(dev, K, Cf):
+    g = torch.Generator(device="cpu").manual_seed(K + Cf)
+    B, N, M, Cout = 2, 500, 37, 96
+    xyz = torch.randn(B, 3, N, generator=g).to(dev)
+    cidx = torch.randint(0, N, (B, M), generator=g)
+    ctr = torch.stack([xyz[b][:, cidx[b]] for b in range(B)]).contiguous()
+    gidx = torch.randint(0, N, (B, M, K), generator=g).int().to(dev)
+    feat = torch.randn(B * N, Cf, generator=g).to(dev) if Cf else None
+    Cin = Cf + 3
+    W = (torch.randn(Cout, Cin, generator=g) / 2).to(dev)      # K order [feat, xyz]
+    b = torch.randn(Cout, generator=g).to(dev)
+    Wp = _padk(W)
+    P = B * M * K
+    out = torch.full((B * M, Cout), float("nan"), device=dev)
+    _run(dict(loader=1, epilogue=1, groups=1, relu=1, P=P, Cin=Cin, Kpad=Wp.shape[1], Cout=Cout,
+              W=Wp, bias=b, gidx=gidx, feat=feat, xyz=xyz, ctr=ctr, Cf=Cf, N=N, M=M, K=K, out=out,
+              ldc=Cout), dev)
+    rows = []
+    for bi in range(B):
+        gi = gidx[bi].long()                                        # (M,K)
+        rel = xyz[bi][:, gi] - ctr[bi][:, :, None]                  # (3,M,K)
+        r = rel.permute(1, 2, 0)
+        if Cf:
+            f = feat.view(B, N, Cf)[bi][gi]                         # (M,K,Cf)
+            r = torch.cat([f, r], dim=2)
+        rows.append(r)
+    A = torch.stack(rows).double()                                  # (B,M,K,Cin)
+    ref = (A @ W.double().t() + b.double()).clamp_min(0).max(dim=2)[0].view(B * M, Cout)
+    assert (out.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_interp_store(dev):
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B, N1, N2, C2, C1, Cout = 2, 333, 50, 64, 32, 72
+    sparse = torch.randn(B * N2, C2, generator=g).to(dev)
+    dense = torch.randn(B * N1, C1, generator=g).to(dev)
+    nidx = torch.randint(0, N2, (B, N1, 3), generator=g).int().to(dev)
+    nw = torch.rand(B, N1, 3, generator=g).to(dev)
+    W = (torch.randn(Cout, C2 + C1, generator=g) / 8).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    P = B * N1
+    for c1, dn in ((C1, dense), (0, None)):
+        Wc = W[:, :C2 + c1].contiguous()
+        out = torch.full((P, Cout), float("nan"), device=dev)
+        _run(dict(loader=2, epilogue=0, groups=1, relu=1, P=P, Cin=C2 + c1, Kpad=C2 + c1, Cout=Cout,
+                  W=Wc, bias=b, nidx=nidx, nw=nw, sparse=sparse, dense=dn, C2=C2, C1=c1, N2=N2,
+                  N1=N1, out=out, ldc=Cout), dev)
+        sp = sparse.view(B, N2, C2)
+        interp = torch.stack([(sp[bi][nidx[bi].long()] * nw[bi][:, :, None]).sum(1)
+                              for bi in range(B)]).view(P, C2)
+        A = interp if c1 == 0 else torch.cat([interp, dense], dim=1)
+        ref = (A.double() @ Wc.double().t() + b.double()).clamp_min(0)
+        assert (out.double() - ref).abs().max().item() < 3e-5
+
+
+def test_gemm_channel_first_heads(dev):
+    g = torch.Generator(device="cpu").manual_seed(6)
+    B, N, Cin = 2, 404, 64
+    A = torch.randn(B * N, Cin, generator=g).to(dev)
+    chans = [3, 9, 4, 5]
+    W = (torch.randn(sum(chans), Cin, generator=g) / 8).to(dev)
+    b = torch.randn(sum(chans), generator=g).to(dev)
+    outs = [torch.full((B, c, N), float("nan"), device=dev) for c in chans]
+    starts = [0, 3, 12, 16, 21]
+    _run(dict(loader=0, epilogue=2, groups=1, relu=0, P=B * N, Cin=Cin, Kpad=Cin, Cout=21, W=W,
+              bias=b, A=A, lda=Cin, cf_ptr=(ctypes.c_void_p * 4)(*[o.data_ptr() for o in outs]),
+              cf_start=(ctypes.c_int32 * 5)(*starts), cf_sigmoid_from=16, cf_N=N), dev)
+    ref = (A.double() @ W.double().t() + b.double()).view(B, N, 21).permute(0, 2, 1)
+    for h, o in enumerate(outs):
+        r = ref[:, starts[h]:starts[h + 1]]
+        if h == 3:
+            r = torch.sigmoid(r)
+        assert (o.double() - r).abs().max().item() < 2e-5
+
+
+def _check_model(dev, g, net, pts, full):
+    from s4g_release_amd.fused import FusedPointNet2
+    fused = FusedPointNet2(net.to(dev).eval())
+    pred, inter = fused({"scene_points": torch.from_numpy(pts).to(dev)}, return_intermediates=True)
+    for li in range(3):
+        fps = inter["fps%d" % li].cpu().numpy().astype(np.int64)
+        ball = inter["ball%d" % li].cpu().numpy().astype(np.int64)
+        cnt = inter["cnt%d" % li].cpu().numpy().astype(np.int64)
+        nn = inter["nn%d" % li].cpu().numpy().astype(np.int64)
+        if full:
+            assert GU.sha(fps) == str(g["fps%d_sha256" % li])
+            assert GU.sha(ball) == str(g["ball%d_sha256" % li])
+            assert GU.sha(cnt) == str(g["cnt%d_sha256" % li])
+            assert GU.sha(nn) == str(g["nn%d_sha256" % li])
+        else:
+            assert np.array_equal(fps, g["fps%d" % li])
+            assert np.array_equal(ball, g["ball%d" % li])
+            assert np.array_equal(cnt, g["cnt%d" % li])
+            assert np.array_equal(nn, g["nn%d" % li])
+    return pred
+
+
+def test_fused_model_small_golden(dev):
+    from s4g_release_amd.model import PointNet2
+    g = GU.load("pn2_small.npz")
+    net = PointNet2(**GU.small_config(g))
+    net.load_state_dict(GU.small_state_dict(g), strict=True)
+    pred = _check_model(dev, g, net, g["points"], full=False)
+    for k in ("score", "frame_R", "frame_t", "movable_logits"):
+        assert pred[k].is_contiguous()
+        err = np.max(np.abs(pred[k].cpu().numpy() - g["out/" + k]))
+        assert err < TOL, (k, err)
+
+
+def test_fused_model_full_golden(dev):
+    from s4g_release_amd import synth
+    g = GU.load("pn2_full.npz")
+    net = GU.build_full_model(int(g["seed"]))
+    pts = synth.make_batch([int(g["scene_id"])], 25600)
+    pred = _check_model(dev, g, net, pts, full=True)
+    pos = torch.from_numpy(g["positions"]).to(dev)
+    for k in ("score", "frame_R", "frame_t", "movable_logits"):
+        got = pred[k][:, :, pos].cpu().numpy()
+        err = np.max(np.abs(got - g["out/" + k]))
+        assert err < TOL, (k, err)
+
+
+def test_fused_equals_modules_path_batch(dev):
+    """Same model, both product paths, a batch of 3 dup-heavy scenes."""
+    from s4g_release_amd import synth
+    from s4g_release_amd.fused import FusedPointNet2
+    from s4g_release_amd.model import PointNet2, randomize_bn_
+    cfg = dict(score_classes=3, num_centroids=(300, 70, 20), radius=(0.05, 0.12, 0.4),
+               num_neighbours=(32, 16, 64), sa_channels=((32, 32, 64), (64, 64, 96), (96, 96, 128)),
+               fp_channels=((128, 128), (64, 64), (32, 32, 32)), num_fp_neighbours=(3, 3, 3),
+               seg_channels=(64, 32, 32, 16), num_removal_directions=5, dropout_prob=0.5)
+    torch.manual_seed(99)
+    net = randomize_bn_(PointNet2(**cfg), 100).to(dev).eval()
+    pts = torch.from_numpy(synth.make_batch([1, 2, 3], 1500, variant="dup-heavy")).to(dev)
+    with torch.no_grad():
+        a = net({"scene_points": pts})
+    b = FusedPointNet2(net)({"scene_points": pts})
+    for k in a:
+        assert (a[k] - b[k]).abs().max().item() < TOL, k
