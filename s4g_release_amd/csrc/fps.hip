@@ -19,12 +19,14 @@
 //     and an ascending-p strict '>' scan resolves ties inside a thread.
 //   * larger clouds fall back to a streaming kernel (xyz from L2, min-distance
 //     in a global workspace).
+#include <stdlib.h>
+
 #include "s4g_common.h"
 
 namespace s4g {
 
-constexpr int FPS_THREADS = 1024;
-constexpr int FPS_WAVES = FPS_THREADS / 64;
+constexpr int FPS_THREADS = 1024;  // streaming fallback
+constexpr int FPS_MAX_WAVES = 16;
 constexpr uint32_t FPS_JMASK = 0x7FFFFFu;  // 23 bits of point index
 
 struct FpsSlot {
@@ -36,6 +38,7 @@ struct FpsSlot {
 
 // Block-wide argmax exchange.  Input: this wave's (wmax, wtie) and the
 // coordinates of its candidate (wave-uniform values).  Output: block winner.
+template <int WAVES>
 __device__ __forceinline__ void fps_block_exchange(FpsSlot* slots, int wave,
                                                    int lane, uint32_t wmax,
                                                    uint32_t wtie, float sx,
@@ -53,7 +56,7 @@ __device__ __forceinline__ void fps_block_exchange(FpsSlot* slots, int wave,
     slots[wave] = s;
   }
   __syncthreads();
-  const FpsSlot s = slots[lane & (FPS_WAVES - 1)];
+  const FpsSlot s = slots[lane & (WAVES - 1)];
   const uint32_t bmax = row16_max_u32(s.d);
   const uint32_t cand = (s.d == bmax) ? s.tie : 0xFFFFFFFFu;
   const uint32_t btie = row16_min_u32(cand);
@@ -86,11 +89,14 @@ __device__ __forceinline__ void fps_pick(const float (&x)[PPT],
   }
 }
 
-template <int PPT, bool FMAD, typename IdxT>
-__global__ __launch_bounds__(FPS_THREADS) void fps_reg_kernel(
+// THREADS must be a multiple of the reference block size bs (<= 512) so that a
+// thread's points share j mod bs; launch_fps only picks such combinations.
+template <int THREADS, int PPT, bool FMAD, typename IdxT>
+__global__ __launch_bounds__(THREADS) void fps_reg_kernel(
     const float* __restrict__ xyz, int N, int M, IdxT* __restrict__ idx,
     float* __restrict__ ctr, int lg_bs) {
-  __shared__ FpsSlot slots[2][FPS_WAVES];
+  constexpr int WAVES = THREADS / 64;
+  __shared__ FpsSlot slots[2][FPS_MAX_WAVES];
   const int b = blockIdx.x;
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_reg_kernel(
   float x[PPT], y[PPT], z[PPT], md[PPT];
 #pragma unroll
   for (int p = 0; p < PPT; ++p) {
-    const int j = t + FPS_THREADS * p;
+    const int j = t + THREADS * p;
     const bool ok = j < N;
     const int jj = ok ? j : 0;
     x[p] = px[jj];
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_reg_kernel(
       }
     }
     const uint32_t jbest =
-        (bestp < 0) ? (uint32_t)cur : (uint32_t)(t + FPS_THREADS * bestp);
+        (bestp < 0) ? (uint32_t)cur : (uint32_t)(t + THREADS * bestp);
     const uint32_t tie = rkey | jbest;
     const uint32_t dbits = __float_as_uint(best);
     const uint32_t wmax = wave_max_u32(dbits);
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_reg_kernel(
     // coordinates of this wave's candidate: static register index per case.
     float sx = cx, sy = cy, sz = cz;
     if (pw >= 0) fps_pick<PPT, 0, PPT>(x, y, z, pw, wl, sx, sy, sz);
-    fps_block_exchange(slots[i & 1], wave, lane, wmax, wtie, sx, sy, sz, cur,
+    fps_block_exchange<WAVES>(slots[i & 1], wave, lane, wmax, wtie, sx, sy, sz, cur,
                        cx, cy, cz);
     if (t == 0) {
       out[i] = (IdxT)cur;
@@ -170,7 +176,7 @@ template <bool FMAD, typename IdxT>
 __global__ __launch_bounds__(FPS_THREADS) void fps_stream_kernel(
     const float* __restrict__ xyz, int N, int M, IdxT* __restrict__ idx,
     float* __restrict__ ctr, float* __restrict__ temp, int lg_bs) {
-  __shared__ FpsSlot slots[2][FPS_WAVES];
+  __shared__ FpsSlot slots[2][FPS_MAX_WAVES];
   const int b = blockIdx.x;
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_stream_kernel(
     const uint32_t wtie = wave_min_u32((dbits == wmax) ? tie : 0xFFFFFFFFu);
     const int jw = (int)(wtie & FPS_JMASK);  // uniform
     const float sx = px[jw], sy = py[jw], sz = pz[jw];
-    fps_block_exchange(slots[i & 1], wave, lane, wmax, wtie, sx, sy, sz, cur,
+    fps_block_exchange<FPS_THREADS / 64>(slots[i & 1], wave, lane, wmax, wtie, sx, sy, sz, cur,
                        cx, cy, cz);
     if (t == 0) {
       out[i] = (IdxT)cur;
@@ -248,31 +254,36 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
                       IdxT* idx, float* ctr, void* ws, size_t ws_bytes,
                       hipStream_t stream) {
   const int lg = ref_block_lg(N);
-  const dim3 grid((unsigned)B), block(FPS_THREADS);
-#define S4G_FPS_CASE(P)                                                      \
-  if (N <= (int64_t)FPS_THREADS * P) {                                       \
-    hipLaunchKernelGGL((fps_reg_kernel<P, FMAD, IdxT>), grid, block, 0,      \
+  const dim3 grid((unsigned)B);
+  int variant = 0;  // S4G_FPS_VARIANT=1024x25 | 512x50 | 256x100 (tuning knob)
+  if (const char* e = getenv("S4G_FPS_THREADS")) variant = atoi(e);
+#define S4G_FPS_CASE(T, P)                                                   \
+  if (N <= (int64_t)T * P) {                                                 \
+    hipLaunchKernelGGL((fps_reg_kernel<T, P, FMAD, IdxT>), grid, dim3(T), 0, \
                        stream, xyz, (int)N, (int)M, idx, ctr, lg);           \
     S4G_LAUNCH_CHECK();                                                      \
     return S4G_OK;                                                           \
   }
-  S4G_FPS_CASE(1)
-  S4G_FPS_CASE(2)
-  S4G_FPS_CASE(5)
-  S4G_FPS_CASE(10)
-  S4G_FPS_CASE(16)
-  S4G_FPS_CASE(25)
+  if (variant == 1024) {
+    S4G_FPS_CASE(1024, 25)
+  }
+  S4G_FPS_CASE(1024, 1)
+  S4G_FPS_CASE(1024, 2)
+  S4G_FPS_CASE(512, 10)
+  S4G_FPS_CASE(512, 20)
+  S4G_FPS_CASE(512, 32)
+  S4G_FPS_CASE(512, 50)
 #undef S4G_FPS_CASE
   if (ws_bytes < (size_t)B * (size_t)N * sizeof(float) || ws == nullptr)
     return S4G_EWORKSPACE;
-  hipLaunchKernelGGL((fps_stream_kernel<FMAD, IdxT>), grid, block, 0, stream,
+  hipLaunchKernelGGL((fps_stream_kernel<FMAD, IdxT>), grid, dim3(FPS_THREADS), 0, stream,
                      xyz, (int)N, (int)M, idx, ctr, (float*)ws, lg);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }
 
 size_t fps_workspace_bytes(int64_t B, int64_t N) {
-  if (N <= (int64_t)FPS_THREADS * 25) return 0;
+  if (N <= (int64_t)512 * 50) return 0;
   return (size_t)B * (size_t)N * sizeof(float);
 }
 
