@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--points", type=int, default=25600)
     ap.add_argument("--impl", default="auto", choices=["auto", "fused", "modules"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="collect each batch before submitting the next")
     ap.add_argument("--variant", default="tabletop-v1")
     return ap.parse_args()
 
@@ -51,7 +53,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from s4g_release_amd import _cabi, functions as F, synth
+    from s4g_release_amd import _cabi, dist as sdist, functions as F, synth
     from s4g_release_amd.model import S4GConfig, build_pointnet2_cls, randomize_bn_
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,18 +100,34 @@ def main():
     batch = {"scene_points": pts}
     heads = ("score", "frame_R", "frame_t", "movable_logits")
 
-    def step():
-        with torch.no_grad():
-            pred = runner(batch)
-            if world > 1:
-                local = torch.cat([pred[k] for k in heads], dim=1).contiguous()   # (B,21,N)
-                gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=dev)
-                dist.all_gather_into_tensor(gathered, local)
-                return gathered
-            return pred
+    pipelined = impl == "fused" and not args.no_pipeline
 
-    for _ in range(args.warmup):
-        step()
+    def finish(pred):
+        if world > 1:
+            return sdist.all_gather_outputs(pred)   # one RCCL all-gather of (B,21,N)
+        return pred
+
+    def run_steps(n):
+        """n forward passes over the batch.  Pipelined mode keeps ONE batch in
+        flight: batch i+1 is submitted (its FPS chain starts on the geometry
+        stream) before batch i's outputs are collected; every batch is complete
+        when the trailing fence returns."""
+        if n <= 0:
+            return
+        with torch.no_grad():
+            if not pipelined:
+                for _ in range(n):
+                    finish(runner(batch))
+                return
+            pending = None
+            for _ in range(n):
+                h = runner.submit(batch)
+                if pending is not None:
+                    finish(pending.result())
+                pending = h
+            finish(pending.result())
+
+    run_steps(args.warmup)
 
     def fence():
         torch.cuda.synchronize()
@@ -120,8 +138,7 @@ def main():
     F.OpTimer.reset(enabled=True)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     F.OpTimer.enabled = False
@@ -151,26 +168,32 @@ def main():
             kernels[name] = {"launches": n, "ms": round(ms, 5), "bytes": int(nbytes),
                              "GBps": round(nbytes / ms / 1e6, 2) if ms > 0 else None}
 
-    # north-star roofline: ball_query + group_points(xyz) at SA1 size
+    # north-star roofline: the operator pair ball_query + group_points(xyz) at SA1
+    # size on this step's batch, through the public operator API (int64 indices),
+    # HIP events around each launch on the launch stream.
     N, M, K = args.points, cfg.num_centroids[0], cfg.num_neighbours[0]
-    bq = kernels.get("ball_query[N=%d,M=%d,K=%d]" % (N, M, K))
-    gp = kernels.get("group_points[C=3,N=%d,M=%d,K=%d]" % (N, M, K))
-    fq = kernels.get("query_group[N=%d,M=%d,K=%d]" % (N, M, K))
-    roofline = None
-    if bq and gp:
-        nbytes = bq["bytes"] + gp["bytes"]
-        ms = bq["ms"] + gp["ms"]
-        roofline = {"kernel": "ball_query + group_points(xyz), SA1", "bound": "hbm",
-                    "achieved": round(nbytes / ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
-                    "bytes_per_launch": nbytes, "ms_per_launch": round(ms, 5),
-                    "scenes_per_launch": B}
-    elif fq:
-        roofline = {"kernel": "fused ball_query+group_points(xyz), SA1", "bound": "hbm",
-                    "achieved": fq["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(fq["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
-                    "bytes_per_launch": fq["bytes"], "ms_per_launch": fq["ms"],
-                    "scenes_per_launch": B}
+    with torch.no_grad():
+        ctr = F.gather_points(pts, F.farthest_point_sample(pts, M))
+        for rep in range(2 + 10):
+            if rep == 2:
+                torch.cuda.synchronize()
+                F.OpTimer.reset(enabled=True)
+            gidx, _ = F.ball_query(pts, ctr, cfg.radius[0], K)
+            F.group_points(pts, gidx)
+        torch.cuda.synchronize()
+        F.OpTimer.enabled = False
+    probe = F.OpTimer.summary()
+    bq = probe["ball_query[N=%d,M=%d,K=%d]" % (N, M, K)]
+    gp = probe["group_points[C=3,N=%d,M=%d,K=%d]" % (N, M, K)]
+    nbytes = bq[2] + gp[2]
+    ms = bq[1] + gp[1]
+    roofline = {"kernel": "ball_query + group_points(xyz) at SA1 size (N=%d, M=%d, K=%d), "
+                          "operator API" % (N, M, K), "bound": "hbm",
+                "achieved": round(nbytes / ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_launch_pair": int(nbytes), "ms_ball_query": round(bq[1], 5),
+                "ms_group_points": round(gp[1], 5), "scenes_per_launch": B,
+                "note": "algorithmic bytes = B*(12N+12M+8MK+8M) + B*(4CN+8MK+4CMK), C=3"}
     if gemm_ms > 0:
         dense_tf = gemm_flops / gemm_ms / 1e9
         roofline_dense = {"kernel": "mlp_gemm_kernel (fp32 MFMA), all launches of one step",
@@ -211,7 +234,8 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "S4G PN2_CLS forward (3 SA + 3 FP + 4 heads), %d scenes/GPU/step, "
-                               "%d-pt %s clouds, fp32, impl=%s" % (B, args.points, args.variant, impl),
+                               "%d-pt %s clouds, fp32, impl=%s%s" % (B, args.points, args.variant, impl,
+                                                                    ", 1 batch in flight" if pipelined else ""),
                    "scenes_per_gpu": B, "num_points": args.points, "global_batch": world * B,
                    "parallelism": "scenes sharded over %d GPU(s), all-gather of 21 ch/point" % world},
         "roofline": roofline, "roofline_dense": roofline_dense, "kernels": kernels,

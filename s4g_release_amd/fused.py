@@ -140,6 +140,7 @@ class FusedPointNet2:
             r += c
         self.logit_layer = _Layer(_pad_k(wl), bl, 4 * cl)
         self.sigmoid_from = sum(chans[:3])
+        self._streams = None
 
     # ------------------------------------------------------------------ launches
     def _gemm(self, name, layer, P, loader, epi, relu=True, **kw):
@@ -197,94 +198,175 @@ class FusedPointNet2:
         return idx, w
 
     # ------------------------------------------------------------------ forward
+    def _geometry(self, xyz):
+        """Everything that depends on coordinates only: the FPS pyramid, the ball
+        queries and the 3-NN searches + weights of all levels."""
+        B, _, N0 = xyz.shape
+        geo = dict(level_xyz=[xyz], level_n=[N0], sa=[], fp=[])
+        n_cur = N0
+        for sa in self.sa:
+            M, K = sa["M"], sa["K"]
+            if not n_cur >= M:
+                raise RuntimeError("num_points is not greater than or equal to num_centroids")
+            idx, ctr = self._fps_gather(geo["level_xyz"][-1], M)
+            gidx, gcnt = self._ball_query(geo["level_xyz"][-1], ctr, sa["radius"], K)
+            geo["sa"].append((idx, ctr, gidx, gcnt))
+            geo["level_xyz"].append(ctr)
+            geo["level_n"].append(M)
+            n_cur = M
+        sparse_xyz = geo["level_xyz"][-1]
+        for fi, fp in enumerate(self.fp):
+            dense_xyz = geo["level_xyz"][-2 - fi]
+            geo["fp"].append(self._three_nn(dense_xyz, sparse_xyz, fp["eps"]))
+            sparse_xyz = dense_xyz
+        return geo
+
+    def _dense(self, xyz, geo):
+        """The shared-MLP contractions of every layer (fp32 MFMA)."""
+        B, _, N0 = xyz.shape
+        dev = xyz.device
+        level_xyz, level_n = geo["level_xyz"], geo["level_n"]
+        level_feat = [None]
+        feat = None
+        for li, sa in enumerate(self.sa):
+            M, K = sa["M"], sa["K"]
+            _, ctr, gidx, _ = geo["sa"][li]
+            P = B * M * K
+            layers = sa["layers"]
+            x = None
+            for l, layer in enumerate(layers):
+                last = l == len(layers) - 1
+                rows = B * M if last else P
+                out = torch.empty((rows, layer.cout), dtype=torch.float32, device=dev)
+                kw = dict(out=out, ldc=layer.cout, K=K)
+                if l == 0:
+                    kw.update(gidx=gidx, feat=feat, xyz=level_xyz[li], ctr=ctr, Cf=sa["cf"],
+                              N=level_n[li], M=M)
+                    loader = LOAD_GATHER
+                else:
+                    kw.update(A=x, lda=x.shape[1])
+                    loader = LOAD_PLAIN
+                self._gemm("sa%d.%d" % (li, l), layer, P, loader, EPI_MAX if last else EPI_STORE,
+                           **kw)
+                x = out
+            feat = x
+            level_feat.append(feat)
+
+        sparse_feat, n_sparse = level_feat[-1], level_n[-1]
+        for fi, fp in enumerate(self.fp):
+            dense_feat, n_dense = level_feat[-2 - fi], level_n[-2 - fi]
+            nidx, nw = geo["fp"][fi]
+            P = B * n_dense
+            x = None
+            for l, layer in enumerate(fp["layers"]):
+                out = torch.empty((P, layer.cout), dtype=torch.float32, device=dev)
+                if l == 0:
+                    c1 = 0 if dense_feat is None else dense_feat.shape[1]
+                    self._gemm("fp%d.%d" % (fi, l), layer, P, LOAD_INTERP, EPI_STORE, out=out,
+                               ldc=layer.cout, nidx=nidx, nw=nw, sparse=sparse_feat,
+                               dense=dense_feat, C2=sparse_feat.shape[1], C1=c1, N2=n_sparse,
+                               N1=n_dense)
+                else:
+                    self._gemm("fp%d.%d" % (fi, l), layer, P, LOAD_PLAIN, EPI_STORE, out=out,
+                               ldc=layer.cout, A=x, lda=x.shape[1])
+                x = out
+            sparse_feat, n_sparse = x, n_dense
+
+        # heads
+        P = B * N0
+        x = sparse_feat
+        l0 = self.head_layers[0]
+        h = torch.empty((P, l0.cout), dtype=torch.float32, device=dev)
+        self._gemm("heads.0", l0, P, LOAD_PLAIN, EPI_STORE, out=h, ldc=l0.cout, A=x,
+                   lda=x.shape[1])
+        x = h
+        for l, layer in enumerate(self.head_layers[1:], start=1):
+            h = torch.empty((P, 4 * layer.cout), dtype=torch.float32, device=dev)
+            self._gemm("heads.%d" % l, layer, P, LOAD_PLAIN, EPI_STORE, out=h,
+                       ldc=4 * layer.cout, c_gcol=layer.cout, A=x, lda=x.shape[1],
+                       a_gcol=layer.cin)
+            x = h
+        names = ("score", "frame_R", "frame_t", "movable_logits")
+        outs = [torch.empty((B, c, N0), dtype=torch.float32, device=dev)
+                for c in self.head_channels]
+        starts = [0]
+        for c in self.head_channels:
+            starts.append(starts[-1] + c)
+        cf_ptr = (_fp * 4)(*[o.data_ptr() for o in outs])
+        cf_start = (_i32 * 5)(*starts)
+        self._gemm("heads.logits", self.logit_layer, P, LOAD_PLAIN, EPI_CF, relu=False, A=x,
+                   lda=x.shape[1], cf_ptr=cf_ptr, cf_start=cf_start,
+                   cf_sigmoid_from=self.sigmoid_from, cf_N=N0)
+        return dict(zip(names, outs))
+
     @torch.no_grad()
-    def __call__(self, data_batch, return_intermediates=False):
+    def submit(self, data_batch):
+        """Enqueue one forward pass and return a `Handle` without waiting.
+
+        The coordinate-only work (FPS pyramid, ball queries, 3-NN) runs on a
+        high-priority geometry stream, the contractions on a dense stream that
+        waits for it.  FPS is a latency chain on one CU per scene; submitting
+        batch i+1 before collecting batch i lets that chain run underneath the
+        previous batch's contractions instead of in front of its own."""
         xyz = _F._f32c(data_batch["scene_points"], "scene_points")
         if xyz.dim() != 3 or xyz.size(1) != 3:
             raise RuntimeError("scene_points must be (B, 3, N)")
-        B, _, N0 = xyz.shape
         dev = xyz.device
-        inter = {}
+        if self._streams is None or self._streams[0].device != dev:
+            self._streams = (torch.cuda.Stream(device=dev, priority=-1),
+                             torch.cuda.Stream(device=dev))
+        gs, ds = self._streams
         with torch.cuda.device(dev):
-            level_xyz, level_feat, level_n = [xyz], [None], [N0]
-            feat, n_cur = None, N0
-            for li, sa in enumerate(self.sa):
-                M, K = sa["M"], sa["K"]
-                if not n_cur >= M:
-                    raise RuntimeError("num_points is not greater than or equal to num_centroids")
-                idx, ctr = self._fps_gather(level_xyz[-1], M)
-                gidx, gcnt = self._ball_query(level_xyz[-1], ctr, sa["radius"], K)
-                inter["fps%d" % li], inter["ball%d" % li], inter["cnt%d" % li] = idx, gidx, gcnt
-                P = B * M * K
-                layers = sa["layers"]
-                x = None
-                for l, layer in enumerate(layers):
-                    last = l == len(layers) - 1
-                    rows = B * M if last else P
-                    out = torch.empty((rows, layer.cout), dtype=torch.float32, device=dev)
-                    kw = dict(out=out, ldc=layer.cout, K=K)
-                    if l == 0:
-                        kw.update(gidx=gidx, feat=feat, xyz=level_xyz[-1], ctr=ctr,
-                                  Cf=sa["cf"], N=n_cur, M=M)
-                        loader = LOAD_GATHER
-                    else:
-                        kw.update(A=x, lda=x.shape[1])
-                        loader = LOAD_PLAIN
-                    self._gemm("sa%d.%d" % (li, l), layer, P, loader, EPI_MAX if last else EPI_STORE,
-                               **kw)
-                    x = out
-                feat, n_cur = x, M
-                level_xyz.append(ctr)
-                level_feat.append(feat)
-                level_n.append(M)
+            cur = torch.cuda.current_stream(dev)
+            ev_in = cur.record_event()
+            gs.wait_event(ev_in)
+            with torch.cuda.stream(gs):
+                geo = self._geometry(xyz)
+                ev_geo = gs.record_event()
+            ds.wait_event(ev_geo)
+            with torch.cuda.stream(ds):
+                pred = self._dense(xyz, geo)
+                ev_out = ds.record_event()
+            # tensors cross streams: tell the caching allocator
+            xyz.record_stream(gs)
+            xyz.record_stream(ds)
+            for idx, ctr, gidx, gcnt in geo["sa"]:
+                for t in (idx, ctr, gidx, gcnt):
+                    t.record_stream(ds)
+            for nidx, nw in geo["fp"]:
+                nidx.record_stream(ds)
+                nw.record_stream(ds)
+        return Handle(pred, geo, ev_out)
 
-            sparse_xyz, sparse_feat, n_sparse = level_xyz[-1], level_feat[-1], level_n[-1]
-            for fi, fp in enumerate(self.fp):
-                dense_xyz, dense_feat, n_dense = level_xyz[-2 - fi], level_feat[-2 - fi], level_n[-2 - fi]
-                nidx, nw = self._three_nn(dense_xyz, sparse_xyz, fp["eps"])
-                inter["nn%d" % fi], inter["nnw%d" % fi] = nidx, nw
-                P = B * n_dense
-                x = None
-                for l, layer in enumerate(fp["layers"]):
-                    out = torch.empty((P, layer.cout), dtype=torch.float32, device=dev)
-                    if l == 0:
-                        c1 = 0 if dense_feat is None else dense_feat.shape[1]
-                        self._gemm("fp%d.%d" % (fi, l), layer, P, LOAD_INTERP, EPI_STORE, out=out,
-                                   ldc=layer.cout, nidx=nidx, nw=nw, sparse=sparse_feat,
-                                   dense=dense_feat, C2=sparse_feat.shape[1], C1=c1, N2=n_sparse,
-                                   N1=n_dense)
-                    else:
-                        self._gemm("fp%d.%d" % (fi, l), layer, P, LOAD_PLAIN, EPI_STORE, out=out,
-                                   ldc=layer.cout, A=x, lda=x.shape[1])
-                    x = out
-                sparse_xyz, sparse_feat, n_sparse = dense_xyz, x, n_dense
-
-            # heads
-            P = B * N0
-            x = sparse_feat
-            l0 = self.head_layers[0]
-            h = torch.empty((P, l0.cout), dtype=torch.float32, device=dev)
-            self._gemm("heads.0", l0, P, LOAD_PLAIN, EPI_STORE, out=h, ldc=l0.cout, A=x,
-                       lda=x.shape[1])
-            x = h
-            for l, layer in enumerate(self.head_layers[1:], start=1):
-                h = torch.empty((P, 4 * layer.cout), dtype=torch.float32, device=dev)
-                self._gemm("heads.%d" % l, layer, P, LOAD_PLAIN, EPI_STORE, out=h,
-                           ldc=4 * layer.cout, c_gcol=layer.cout, A=x, lda=x.shape[1],
-                           a_gcol=layer.cin)
-                x = h
-            names = ("score", "frame_R", "frame_t", "movable_logits")
-            outs = [torch.empty((B, c, N0), dtype=torch.float32, device=dev)
-                    for c in self.head_channels]
-            starts = [0]
-            for c in self.head_channels:
-                starts.append(starts[-1] + c)
-            cf_ptr = (_fp * 4)(*[o.data_ptr() for o in outs])
-            cf_start = (_i32 * 5)(*starts)
-            self._gemm("heads.logits", self.logit_layer, P, LOAD_PLAIN, EPI_CF, relu=False, A=x,
-                       lda=x.shape[1], cf_ptr=cf_ptr, cf_start=cf_start,
-                       cf_sigmoid_from=self.sigmoid_from, cf_N=N0)
-        pred = dict(zip(names, outs))
+    def __call__(self, data_batch, return_intermediates=False):
+        h = self.submit(data_batch)
+        pred = h.result()
         if return_intermediates:
+            inter = {}
+            for li, (idx, ctr, gidx, gcnt) in enumerate(h.geo["sa"]):
+                inter["fps%d" % li], inter["ball%d" % li], inter["cnt%d" % li] = idx, gidx, gcnt
+            for fi, (nidx, nw) in enumerate(h.geo["fp"]):
+                inter["nn%d" % fi], inter["nnw%d" % fi] = nidx, nw
             return pred, inter
         return pred
+
+
+class Handle:
+    """An in-flight forward pass (see `FusedPointNet2.submit`)."""
+
+    def __init__(self, pred, geo, event):
+        self.pred, self.geo, self.event = pred, geo, event
+
+    def result(self):
+        """Make the caller's current stream wait for the outputs and return them."""
+        cur = torch.cuda.current_stream(next(iter(self.pred.values())).device)
+        cur.wait_event(self.event)
+        for t in self.pred.values():
+            t.record_stream(cur)
+        for li, (idx, ctr, gidx, gcnt) in enumerate(self.geo["sa"]):
+            for t in (idx, ctr, gidx, gcnt):
+                t.record_stream(cur)
+        for nidx, nw in self.geo["fp"]:
+            nidx.record_stream(cur)
+            nw.record_stream(cur)
+        return self.pred
