@@ -205,6 +205,15 @@ int s4g_three_nn_weights_i32(const float *q_b3n1, const float *k_b3n2, int64_t B
                              int64_t N1, int64_t N2, float eps, int32_t *idx_bn3,
                              float *w_bn3, void *ws, size_t ws_bytes, int flags,
                              s4g_stream_t stream);
+/* QueryGrouper's operator pair in one pass (modules.py:39-42):
+ * ball_query + group_points(xyz, index).  Same outputs as calling
+ * s4g_ball_query_f32 then s4g_group_points_f32 with C = 3: index (B,M,K) int64,
+ * count (B,M) int64, grouped (B,3,M,K) fp32 (NOT centroid-subtracted). */
+int s4g_query_group_f32(const float *xyz_b3n, const float *ctr_b3m, int64_t B,
+                        int64_t N, int64_t M, float radius, int64_t K,
+                        int64_t *idx_bmk, int64_t *cnt_bm, float *grouped_b3mk,
+                        void *ws, size_t ws_bytes, int flags, s4g_stream_t stream);
+
 /* FPS + centroid gather in one call: idx (B,M) int32 and ctr (B,3,M) planar. */
 int s4g_fps_gather_i32(const float *xyz_b3n, int64_t B, int64_t N, int64_t M,
                        int32_t *idx_bm, float *ctr_b3m, void *ws, size_t ws_bytes,

@@ -6,13 +6,40 @@
 // first K with d < r2 (strict); slots cnt..K-1 hold the first hit; rows
 // without a hit stay zero; count = min(hits, K).
 //
-// Kernel in this file: index-order scan, one WAVE per centroid with the 64
-// lanes on 64 consecutive points.  A ballot gives the hit mask, mbcnt the rank
-// of each hit inside the mask, so hits land in their output slot already in
-// index order and the wave leaves the scan as soon as K are found (the
-// reference's thread-per-centroid loop cannot exit a wave early and reads xyz
-// as AoS).  xyz is consumed as the (B,3,N) SoA planes it arrives in: each
-// plane load is one fully coalesced 256-byte request per wave.
+// Two exact implementations, chosen per call:
+//
+//  SCAN  index-order scan, one WAVE per centroid with the 64 lanes on 64
+//        consecutive points.  A ballot gives the hit mask, mbcnt the rank of
+//        each hit, so hits land in their slot already in index order and the
+//        wave leaves as soon as K are found.  O(M*N) pair tests: right for the
+//        small, dense levels (SA2/SA3: K hits appear after ~N*K/hits points).
+//
+//  GRID  for big sparse levels (SA1: 25 600 points, 76 % of the balls never
+//        reach K = 64, so a scan reads everything).  Per call:
+//        1. build: a 32x32x32 *toroidal* cell grid with cell edge h = r*(1+2^-8)
+//           (slot = z5|y5|x5 of the cell coordinates mod 32; clouds wider than
+//           32 cells alias, which only adds candidates).  One launch, 8
+//           workgroups per scene, each owning a z-slab of 4096 slots: LDS
+//           histogram -> scan -> scatter of (x,y,z,index) records.  No global
+//           atomics, no cross-workgroup exchange, no bounding-box pass (cell
+//           coordinates are relative to the scene's first point).
+//        2. query: one wave per centroid visits the 9 rows of 3 x-adjacent
+//           cells around it (each row is ONE contiguous record range), tests
+//           the ~150-350 candidates, and marks hits in an LDS *bitmap over the
+//           point index*.  Reading the bitmap back in order yields exactly the
+//           reference's "first K in index order" -- candidates may arrive in any
+//           order, be duplicated by aliasing, or exceed K, without affecting
+//           the result.  Output rows are staged in LDS and stored coalesced.
+//        Exactness: a point with fp32 d < r2 has |dx| <= r(1+1e-6) in every
+//        axis, so its cell coordinate differs by at most 1 from the
+//        centroid's as long as the fp32 error of (p-o)/h stays below the 2^-8
+//        margin; scenes with |cell coordinate| >= 4096 raise a flag and their
+//        centroids take the SCAN path inside the same kernel.
+//        The query kernel can also emit the grouped xyz (group_points of the
+//        same indices, grouping_kernel.cu:32-54) so the operator pair
+//        QueryGrouper uses (modules.py:39-42) costs one pass over the output.
+#include <stdlib.h>
+
 #include "s4g_common.h"
 
 namespace s4g {
@@ -20,21 +47,12 @@ namespace s4g {
 constexpr int BQ_WAVES_PER_BLOCK = 4;
 constexpr int BQ_UNROLL = 4;
 
+// ---------------------------------------------------------------- SCAN path
 template <bool FMAD, typename IdxT>
-__global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void ball_query_scan_kernel(
-    const float* __restrict__ xyz, const float* __restrict__ ctr, int N, int M,
-    float r2, int K, IdxT* __restrict__ idx, IdxT* __restrict__ cnt_out) {
-  const int b = blockIdx.y;
-  const int lane = threadIdx.x & 63;
-  const int m = blockIdx.x * BQ_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-  if (m >= M) return;
-  const float* __restrict__ px = xyz + (size_t)b * 3 * N;
-  const float* __restrict__ py = px + N;
-  const float* __restrict__ pz = py + N;
-  const float* __restrict__ c = ctr + (size_t)b * 3 * M;
-  const float cx = c[m], cy = c[M + m], cz = c[2 * M + m];
-  IdxT* __restrict__ row = idx + ((size_t)b * M + m) * K;
-
+__device__ __forceinline__ void bq_scan_centroid(
+    const float* __restrict__ px, const float* __restrict__ py,
+    const float* __restrict__ pz, int N, float cx, float cy, float cz, float r2,
+    int K, int lane, IdxT* __restrict__ row, IdxT* __restrict__ cnt_slot) {
   int cnt = 0;    // wave-uniform
   int first = 0;  // index of the first hit
   for (int j0 = 0; j0 < N && cnt < K; j0 += 64 * BQ_UNROLL) {
@@ -64,35 +82,324 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void ball_query_scan_kerne
   if (cnt > K) cnt = K;
   const IdxT fill = (IdxT)first;  // 0 when there was no hit
   for (int k = cnt + lane; k < K; k += 64) row[k] = fill;
-  if (lane == 0) cnt_out[(size_t)b * M + m] = (IdxT)cnt;
+  if (lane == 0) *cnt_slot = (IdxT)cnt;
 }
 
-}  // namespace s4g
+template <bool FMAD, typename IdxT>
+__global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void ball_query_scan_kernel(
+    const float* __restrict__ xyz, const float* __restrict__ ctr, int N, int M,
+    float r2, int K, IdxT* __restrict__ idx, IdxT* __restrict__ cnt_out) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * BQ_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float* __restrict__ px = xyz + (size_t)b * 3 * N;
+  const float* __restrict__ c = ctr + (size_t)b * 3 * M;
+  bq_scan_centroid<FMAD, IdxT>(px, px + N, px + 2 * N, N, c[m], c[M + m], c[2 * M + m], r2, K,
+                               lane, idx + ((size_t)b * M + m) * K, cnt_out + (size_t)b * M + m);
+}
 
-namespace s4g {
+// ---------------------------------------------------------------- GRID path
+constexpr int GR_DIM = 32;            // cells per axis (toroidal)
+constexpr int GR_RANGES = 8;          // z-slabs = build workgroups per scene
+constexpr int GR_RANGE_SLOTS = 4096;  // slots per slab
+constexpr int GR_START_STRIDE = GR_RANGE_SLOTS + 4;  // +1 end entry, padded to 16 B
+constexpr int GR_BUILD_THREADS = 1024;
+constexpr int GR_COORD_LIMIT = 4096;  // |cell coordinate| bound of the exactness argument
+constexpr int GR_MAX_POINTS = 65536;  // bitmap of N bits per wave must fit LDS
+
+struct GridWs {
+  float4* sorted;  // [B][GR_RANGES * N] records (x, y, z, index bits)
+  int* starts;     // [B][GR_RANGES][GR_START_STRIDE], absolute record offsets
+  int* flags;      // [B] 1 = scene out of the exactness range -> SCAN path
+};
+
+static size_t grid_ws_bytes(int64_t B, int64_t N) {
+  return (size_t)B * ((size_t)GR_RANGES * N * sizeof(float4) +
+                      (size_t)GR_RANGES * GR_START_STRIDE * sizeof(int) + 64);
+}
+
+static GridWs grid_ws_carve(void* ws, int64_t B, int64_t N) {
+  GridWs g;
+  char* p = (char*)ws;
+  g.sorted = (float4*)p;
+  p += (size_t)B * GR_RANGES * N * sizeof(float4);
+  g.starts = (int*)p;
+  p += (size_t)B * GR_RANGES * GR_START_STRIDE * sizeof(int);
+  g.flags = (int*)p;
+  return g;
+}
+
+__device__ __forceinline__ int grid_coord(float v, float o, float inv_h) {
+  return (int)floorf(__fmul_rn(__fsub_rn(v, o), inv_h));
+}
+// false for NaN / inf / anything outside the exactness range (checked in float:
+// the int conversion saturates and abs(INT_MIN) would slip through).
+__device__ __forceinline__ bool grid_coord_ok(float v, float o, float inv_h) {
+  return fabsf(__fmul_rn(__fsub_rn(v, o), inv_h)) < (float)(GR_COORD_LIMIT - 1);
+}
+__device__ __forceinline__ int grid_slot(int cx, int cy, int cz) {
+  return ((cz & 31) << 10) | ((cy & 31) << 5) | (cx & 31);
+}
+
+__global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
+    const float* __restrict__ xyz, int N, float inv_h, GridWs ws) {
+  __shared__ uint32_t hist[GR_RANGE_SLOTS];
+  __shared__ uint32_t wsum[GR_BUILD_THREADS / 64];
+  const int b = blockIdx.y;
+  const int g = blockIdx.x;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const float* __restrict__ px = xyz + (size_t)b * 3 * N;
+  const float* __restrict__ py = px + N;
+  const float* __restrict__ pz = py + N;
+  const float ox = px[0], oy = py[0], oz = pz[0];
+
+  for (int s = t; s < GR_RANGE_SLOTS; s += GR_BUILD_THREADS) hist[s] = 0;
+  __syncthreads();
+
+  int bad = 0;
+  for (int j = t; j < N; j += GR_BUILD_THREADS) {
+    const int cx = grid_coord(px[j], ox, inv_h);
+    const int cy = grid_coord(py[j], oy, inv_h);
+    const int cz = grid_coord(pz[j], oz, inv_h);
+    if (!(grid_coord_ok(px[j], ox, inv_h) && grid_coord_ok(py[j], oy, inv_h) &&
+          grid_coord_ok(pz[j], oz, inv_h)))
+      bad = 1;
+    const int slot = grid_slot(cx, cy, cz);
+    if ((slot >> 12) == g) atomicAdd(&hist[slot & (GR_RANGE_SLOTS - 1)], 1u);
+  }
+  bad = __syncthreads_or(bad);
+  if (g == 0 && t == 0) ws.flags[b] = bad ? 1 : 0;
+
+  // exclusive scan of the 4096 counts: 4 consecutive entries per thread
+  const uint32_t v0 = hist[4 * t], v1 = hist[4 * t + 1], v2 = hist[4 * t + 2], v3 = hist[4 * t + 3];
+  const uint32_t s = v0 + v1 + v2 + v3;
+  uint32_t incl = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int w = 0; w < wave; ++w) wbase += wsum[w];
+  const uint32_t base = (uint32_t)g * (uint32_t)N + wbase + (incl - s);
+  hist[4 * t] = base;  // each thread rewrites only the four entries it read
+  hist[4 * t + 1] = base + v0;
+  hist[4 * t + 2] = base + v0 + v1;
+  hist[4 * t + 3] = base + v0 + v1 + v2;
+  int* __restrict__ st = ws.starts + ((size_t)b * GR_RANGES + g) * GR_START_STRIDE;
+  *reinterpret_cast<int4*>(st + 4 * t) =
+      make_int4((int)base, (int)(base + v0), (int)(base + v0 + v1), (int)(base + v0 + v1 + v2));
+  if (t == GR_BUILD_THREADS - 1) st[GR_RANGE_SLOTS] = (int)(base + s);
+  __syncthreads();
+
+  float4* __restrict__ rec = ws.sorted + (size_t)b * GR_RANGES * N;
+  for (int j = t; j < N; j += GR_BUILD_THREADS) {
+    const float x = px[j], y = py[j], z = pz[j];
+    const int slot = grid_slot(grid_coord(x, ox, inv_h), grid_coord(y, oy, inv_h),
+                               grid_coord(z, oz, inv_h));
+    if ((slot >> 12) == g) {
+      const uint32_t pos = atomicAdd(&hist[slot & (GR_RANGE_SLOTS - 1)], 1u);
+      rec[pos] = make_float4(x, y, z, __int_as_float(j));
+    }
+  }
+}
+
+// One wave per centroid.  Dynamic LDS per wave: bitmap of N bits + K-entry row.
+template <bool FMAD, typename IdxT, bool GROUP>
+__global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void bq_grid_query_kernel(
+    const float* __restrict__ xyz, const float* __restrict__ ctr, int N, int M,
+    float r2, float inv_h, int K, GridWs ws, IdxT* __restrict__ idx,
+    IdxT* __restrict__ cnt_out, float* __restrict__ grouped, int words_per_lane) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int m = blockIdx.x * BQ_WAVES_PER_BLOCK + wave;
+  if (m >= M) return;
+  const int wave_words = 64 * words_per_lane + K;
+  uint32_t* __restrict__ bm = lds + wave * wave_words;
+  int* __restrict__ row = (int*)(bm + 64 * words_per_lane);
+
+  const float* __restrict__ px = xyz + (size_t)b * 3 * N;
+  const float* __restrict__ py = px + N;
+  const float* __restrict__ pz = py + N;
+  const float* __restrict__ c = ctr + (size_t)b * 3 * M;
+  const float cx = c[m], cy = c[M + m], cz = c[2 * M + m];
+  IdxT* __restrict__ out_row = idx + ((size_t)b * M + m) * K;
+  IdxT* __restrict__ out_cnt = cnt_out + (size_t)b * M + m;
+
+  const int icx = grid_coord(cx, px[0], inv_h);
+  const int icy = grid_coord(cy, py[0], inv_h);
+  const int icz = grid_coord(cz, pz[0], inv_h);
+  const bool exact = (ws.flags[b] == 0) && grid_coord_ok(cx, px[0], inv_h) &&
+                     grid_coord_ok(cy, py[0], inv_h) && grid_coord_ok(cz, pz[0], inv_h);
+  bool in_lds = false;
+  if (!exact) {
+    // out of the grid's exactness range: index-order scan, straight to global
+    bq_scan_centroid<FMAD, IdxT>(px, py, pz, N, cx, cy, cz, r2, K, lane, out_row, out_cnt);
+    if constexpr (!GROUP) return;
+    __threadfence_block();  // the row is re-read below by other lanes of this wave
+  } else {
+    in_lds = true;
+    for (int w = lane; w < 64 * words_per_lane; w += 64) bm[w] = 0;
+
+    // lanes 0..8 fetch the record ranges of the 9 (dy, dz) rows in parallel
+    int beg0 = 0, end0 = 0, beg1 = 0, end1 = 0;
+    if (lane < 9) {
+      const int dz = lane / 3 - 1, dy = lane % 3 - 1;
+      const int zz = (icz + dz) & 31, yy = (icy + dy) & 31;
+      const int* __restrict__ st = ws.starts +
+          ((size_t)b * GR_RANGES + (zz >> 2)) * GR_START_STRIDE + (((zz & 3) << 10) | (yy << 5));
+      const int x0 = (icx - 1) & 31;
+      if (x0 <= GR_DIM - 3) {
+        beg0 = st[x0];
+        end0 = st[x0 + 3];
+      } else {  // the 3 cells wrap around the row
+        beg0 = st[x0];
+        end0 = st[GR_DIM];
+        beg1 = st[0];
+        end1 = st[(x0 + 3) & 31];
+      }
+    }
+    const float4* __restrict__ rec = ws.sorted + (size_t)b * GR_RANGES * N;
+    for (int r = 0; r < 9; ++r) {
+      const int b0 = __builtin_amdgcn_readlane(beg0, r), e0 = __builtin_amdgcn_readlane(end0, r);
+      for (int j = b0 + lane; j < e0; j += 64) {
+        const float4 p = rec[j];
+        if (dist2<FMAD>(cx, cy, cz, p.x, p.y, p.z) < r2) {
+          const int pi = __float_as_int(p.w);
+          atomicOr(&bm[pi >> 5], 1u << (pi & 31));
+        }
+      }
+      const int b1 = __builtin_amdgcn_readlane(beg1, r), e1 = __builtin_amdgcn_readlane(end1, r);
+      for (int j = b1 + lane; j < e1; j += 64) {
+        const float4 p = rec[j];
+        if (dist2<FMAD>(cx, cy, cz, p.x, p.y, p.z) < r2) {
+          const int pi = __float_as_int(p.w);
+          atomicOr(&bm[pi >> 5], 1u << (pi & 31));
+        }
+      }
+    }
+    // read the bitmap back in index order: lane l owns words [l*W, (l+1)*W)
+    const uint32_t* mine = bm + lane * words_per_lane;
+    int local = 0;
+    for (int w = 0; w < words_per_lane; ++w) local += __popc(mine[w]);
+    int incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    int pos = incl - local;
+    if (local > 0 && pos < K) {
+      for (int w = 0; w < words_per_lane && pos < K; ++w) {
+        uint32_t bits = mine[w];
+        while (bits && pos < K) {
+          const int bit = __ffs(bits) - 1;
+          row[pos++] = (lane * words_per_lane + w) * 32 + bit;
+          bits &= bits - 1;
+        }
+      }
+    }
+    const int cnt = total < K ? total : K;
+    const int first = cnt > 0 ? row[0] : 0;
+    for (int k = lane; k < K; k += 64) {
+      const int v = k < cnt ? row[k] : first;
+      out_row[k] = (IdxT)v;
+      if constexpr (GROUP) row[k] = v;
+    }
+    if (lane == 0) *out_cnt = (IdxT)cnt;
+  }
+  if constexpr (GROUP) {
+    // group_points(xyz, index) for this centroid: out[b][c][m][k] = xyz[b][c][idx]
+    const size_t MK = (size_t)M * K;
+    float* __restrict__ gx = grouped + (size_t)b * 3 * MK + (size_t)m * K;
+    for (int k = lane; k < K; k += 64) {
+      const int v = in_lds ? row[k] : (int)out_row[k];  // (fenced below for the scan path)
+      gx[k] = px[v];
+      gx[MK + k] = py[v];
+      gx[2 * MK + k] = pz[v];
+    }
+  }
+}
+
+enum { BQ_AUTO = 0, BQ_SCAN = 1, BQ_GRID = 2 };
+
+static int bq_mode() {  // S4G_BQ_MODE=scan|grid|auto (tuning / test knob, read per call)
+  const char* e = getenv("S4G_BQ_MODE");
+  if (e && e[0] == 's') return BQ_SCAN;
+  if (e && e[0] == 'g') return BQ_GRID;
+  return BQ_AUTO;
+}
+
+static bool bq_use_grid(int64_t N, int64_t K) {
+  if (N > GR_MAX_POINTS || K > 1024) return false;
+  const int mode = bq_mode();
+  if (mode == BQ_SCAN) return false;
+  if (mode == BQ_GRID) return true;
+  return N >= 8192;
+}
+
+size_t ball_query_workspace_bytes(int64_t B, int64_t N, int64_t M, int64_t K) {
+  (void)M;
+  return bq_use_grid(N, K) ? grid_ws_bytes(B, N) : 0;
+}
+
 template <typename IdxT>
 static int ball_query_dispatch(const float* xyz, const float* ctr, int64_t B,
                                int64_t N, int64_t M, float radius, int64_t K,
-                               IdxT* idx, IdxT* cnt, int flags,
-                               hipStream_t st) {
+                               IdxT* idx, IdxT* cnt, float* grouped, void* ws,
+                               size_t ws_bytes, int flags, hipStream_t st) {
   if (B < 0 || N <= 0 || M < 0 || K <= 0 || N >= (1ll << 31) || B > 65535)
     return S4G_EINVAL;
   if (B == 0 || M == 0) return S4G_OK;
   if (!xyz || !ctr || !idx || !cnt) return S4G_EINVAL;
   // r2 exactly as ball_query_kernel.cu:49 computes it: fp32 product.
   const float r2 = radius * radius;
+  const bool fmad = (flags & S4G_FLAG_FMAD) != 0;
   const dim3 block(64 * BQ_WAVES_PER_BLOCK);
-  const dim3 grid((unsigned)((M + BQ_WAVES_PER_BLOCK - 1) / BQ_WAVES_PER_BLOCK),
-                  (unsigned)B);
-  if (flags & S4G_FLAG_FMAD)
-    hipLaunchKernelGGL((ball_query_scan_kernel<true, IdxT>), grid, block, 0, st,
-                       xyz, ctr, (int)N, (int)M, r2, (int)K, idx, cnt);
-  else
-    hipLaunchKernelGGL((ball_query_scan_kernel<false, IdxT>), grid, block, 0, st,
-                       xyz, ctr, (int)N, (int)M, r2, (int)K, idx, cnt);
+  const dim3 grid((unsigned)((M + BQ_WAVES_PER_BLOCK - 1) / BQ_WAVES_PER_BLOCK), (unsigned)B);
+  const bool use_grid = bq_use_grid(N, K) && ws && ws_bytes >= grid_ws_bytes(B, N) &&
+                        radius > 0.f && radius < 1e18f;
+  if (!use_grid) {
+    if (fmad)
+      hipLaunchKernelGGL((ball_query_scan_kernel<true, IdxT>), grid, block, 0, st, xyz, ctr,
+                         (int)N, (int)M, r2, (int)K, idx, cnt);
+    else
+      hipLaunchKernelGGL((ball_query_scan_kernel<false, IdxT>), grid, block, 0, st, xyz, ctr,
+                         (int)N, (int)M, r2, (int)K, idx, cnt);
+    S4G_LAUNCH_CHECK();
+    if (grouped) return S4G_EUNSUPPORTED;  // callers group separately on this path
+    return S4G_OK;
+  }
+  const GridWs g = grid_ws_carve(ws, B, N);
+  const float h = radius * (1.0f + 1.0f / 256.0f);
+  const float inv_h = 1.0f / h;
+  hipLaunchKernelGGL(bq_grid_build_kernel, dim3(GR_RANGES, (unsigned)B), dim3(GR_BUILD_THREADS),
+                     0, st, xyz, (int)N, inv_h, g);
+  S4G_LAUNCH_CHECK();
+  const int words = (int)((N + 31) / 32);
+  int wpl = (words + 63) / 64;
+  if ((wpl & 1) == 0) ++wpl;  // odd stride: conflict-free per-lane word runs
+  const size_t lds = sizeof(uint32_t) * BQ_WAVES_PER_BLOCK * (size_t)(64 * wpl + K);
+#define S4G_BQ_LAUNCH(F, G)                                                          \
+  hipLaunchKernelGGL((bq_grid_query_kernel<F, IdxT, G>), grid, block, lds, st, xyz,  \
+                     ctr, (int)N, (int)M, r2, inv_h, (int)K, g, idx, cnt, grouped, wpl)
+  if (grouped) {
+    if (fmad) S4G_BQ_LAUNCH(true, true); else S4G_BQ_LAUNCH(false, true);
+  } else {
+    if (fmad) S4G_BQ_LAUNCH(true, false); else S4G_BQ_LAUNCH(false, false);
+  }
+#undef S4G_BQ_LAUNCH
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }
+
 }  // namespace s4g
 
 extern "C" int s4g_ball_query_f32(const float* xyz_b3n, const float* ctr_b3m,
@@ -100,11 +407,8 @@ extern "C" int s4g_ball_query_f32(const float* xyz_b3n, const float* ctr_b3m,
                                   int64_t K, int64_t* idx_bmk, int64_t* cnt_bm,
                                   void* ws, size_t ws_bytes, int flags,
                                   s4g_stream_t stream) {
-  (void)ws;
-  (void)ws_bytes;
-  return s4g::ball_query_dispatch<int64_t>(xyz_b3n, ctr_b3m, B, N, M, radius, K,
-                                           idx_bmk, cnt_bm, flags,
-                                           (hipStream_t)stream);
+  return s4g::ball_query_dispatch<int64_t>(xyz_b3n, ctr_b3m, B, N, M, radius, K, idx_bmk, cnt_bm,
+                                           nullptr, ws, ws_bytes, flags, (hipStream_t)stream);
 }
 
 extern "C" int s4g_ball_query_i32(const float* xyz_b3n, const float* ctr_b3m,
@@ -112,13 +416,20 @@ extern "C" int s4g_ball_query_i32(const float* xyz_b3n, const float* ctr_b3m,
                                   int64_t K, int32_t* idx_bmk, int32_t* cnt_bm,
                                   void* ws, size_t ws_bytes, int flags,
                                   s4g_stream_t stream) {
-  (void)ws;
-  (void)ws_bytes;
-  return s4g::ball_query_dispatch<int32_t>(xyz_b3n, ctr_b3m, B, N, M, radius, K,
-                                           idx_bmk, cnt_bm, flags,
-                                           (hipStream_t)stream);
+  return s4g::ball_query_dispatch<int32_t>(xyz_b3n, ctr_b3m, B, N, M, radius, K, idx_bmk, cnt_bm,
+                                           nullptr, ws, ws_bytes, flags, (hipStream_t)stream);
 }
 
-namespace s4g {
-size_t ball_query_workspace_bytes(int64_t, int64_t, int64_t, int64_t) { return 0; }
-}  // namespace s4g
+extern "C" int s4g_query_group_f32(const float* xyz_b3n, const float* ctr_b3m,
+                                   int64_t B, int64_t N, int64_t M, float radius,
+                                   int64_t K, int64_t* idx_bmk, int64_t* cnt_bm,
+                                   float* grouped_b3mk, void* ws, size_t ws_bytes,
+                                   int flags, s4g_stream_t stream) {
+  if (!grouped_b3mk) return S4G_EINVAL;
+  int rc = s4g::ball_query_dispatch<int64_t>(xyz_b3n, ctr_b3m, B, N, M, radius, K, idx_bmk,
+                                             cnt_bm, grouped_b3mk, ws, ws_bytes, flags,
+                                             (hipStream_t)stream);
+  if (rc == S4G_EUNSUPPORTED)  // SCAN path: indices are done, group with the plain kernel
+    rc = s4g_group_points_f32(xyz_b3n, idx_bmk, B, 3, N, M, K, grouped_b3mk, stream);
+  return rc;
+}

@@ -162,6 +162,35 @@ def _ball_query(points, centroids, radius, num_neighbours):
     return index, count
 
 
+def query_and_group(points, centroids, radius, num_neighbours):
+    """ball_query + group_points(points, index) in one pass over the outputs.
+
+    Returns (index (B,M,K) int64, count (B,M) int64, grouped xyz (B,3,M,K) fp32),
+    identical to the two reference operators called in sequence
+    (QueryGrouper.forward, modules.py:39-42)."""
+    points = _f32c(points, "points")
+    centroids = _f32c(centroids, "centroids")
+    if points.dim() != 3 or points.size(1) != 3 or centroids.dim() != 3 or centroids.size(1) != 3:
+        raise RuntimeError("points / centroids must be (B, 3, N)")
+    B, _, N = points.shape
+    M = centroids.size(2)
+    K = int(num_neighbours)
+    index = torch.empty((B, M, K), dtype=torch.int64, device=points.device)
+    count = torch.empty((B, M), dtype=torch.int64, device=points.device)
+    grouped = torch.empty((B, 3, M, K), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        ws, nbytes = _workspace(_cabi.S4G_OP_BALL_QUERY, points.device, B, N, M, K)
+        with _timed("query_group[N=%d,M=%d,K=%d]" % (N, M, K),
+                    B * (12 * N + 12 * M + 8 * M * K + 8 * M) +
+                    B * (4 * 3 * N + 8 * M * K + 4 * 3 * M * K)):
+            rc = _cabi.lib().s4g_query_group_f32(_ptr(points), _ptr(centroids), B, N, M,
+                                                 float(radius), K, _ptr(index), _ptr(count),
+                                                 _ptr(grouped), _ptr(ws), nbytes, _DIST_FLAGS,
+                                                 _stream())
+    _cabi.check(rc, "query_group")
+    return index, count, grouped
+
+
 def _group_points_forward(points, index):
     points = _f32c(points, "input")
     index = _i64c(index, "index")

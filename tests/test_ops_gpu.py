@@ -85,6 +85,64 @@ def test_ball_query_matches_oracle(F, oracle, dev, variant, N, M, r, K):
     assert np.array_equal(idx.cpu().numpy(), ridx)
 
 
+@pytest.fixture
+def bq_mode(monkeypatch):
+    def set_mode(mode):
+        monkeypatch.setenv("S4G_BQ_MODE", mode)
+    return set_mode
+
+
+@pytest.mark.parametrize("mode", ["grid", "scan"])
+@pytest.mark.parametrize("variant,N,M,r,K", [
+    ("tabletop-v1", 25600, 5120, 0.02, 64),    # SA1
+    ("tabletop-v1", 25600, 2000, 0.01, 32),    # scene wider than 32 cells: toroidal aliasing
+    ("dup-heavy", 25600, 5120, 0.02, 64),      # exact ties, > K hits
+    ("uniform-box", 25600, 5120, 0.02, 64),    # ~1 hit per ball, all padded
+    ("tabletop-v1", 3000, 777, 0.05, 16),      # small cloud forced through the grid
+    ("tabletop-v1", 51200, 1024, 0.02, 100),   # K > 64, 51 200 points
+    ("tabletop-v1", 4096, 512, 0.6, 64),       # ball as big as the scene
+])
+def test_ball_query_grid_and_scan_paths(F, oracle, dev, bq_mode, mode, variant, N, M, r, K):
+    bq_mode(mode)
+    pts = synth.make_batch([2, 9], N, variant=variant)
+    ctr = oracle.gather_points(pts, oracle.fps(pts, M))
+    ctr[0, :, 0] += 5.0                      # one centroid far from every point: empty ball
+    idx, cnt = F.ball_query(_t(pts, dev), _t(ctr, dev), r, K)
+    ridx, rcnt = oracle.ball_query(pts, ctr, r, K)
+    assert np.array_equal(cnt.cpu().numpy(), rcnt)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert cnt[0, 0].item() == 0 and (idx[0, 0] == 0).all()
+
+
+def test_ball_query_grid_out_of_range_scene_falls_back(F, oracle, dev, bq_mode):
+    """A scene spanning > 4096 cells trips the exactness flag: its centroids take
+    the index-order scan inside the grid kernel; the other scene stays on the grid."""
+    bq_mode("grid")
+    pts = synth.make_batch([0, 1], 9000)
+    pts[1, 0, 17] += 500.0                   # 500 m / 0.02 m = 25 000 cells
+    pts[1, 2, 4000] = np.float32(-3e30)
+    ctr = oracle.gather_points(pts, oracle.fps(pts, 300))
+    idx, cnt = F.ball_query(_t(pts, dev), _t(ctr, dev), 0.02, 48)
+    ridx, rcnt = oracle.ball_query(pts, ctr, 0.02, 48)
+    assert np.array_equal(cnt.cpu().numpy(), rcnt) and np.array_equal(idx.cpu().numpy(), ridx)
+    i2, c2, g2 = F.query_and_group(_t(pts, dev), _t(ctr, dev), 0.02, 48)
+    assert np.array_equal(i2.cpu().numpy(), ridx)
+    assert np.array_equal(g2.cpu().numpy(), oracle.group_points(pts, ridx))
+
+
+@pytest.mark.parametrize("mode", ["auto", "scan"])
+@pytest.mark.parametrize("N,M,r", [(25600, 5120, 0.02), (5120, 1024, 0.08)])
+def test_query_and_group_equals_operator_pair(F, oracle, dev, bq_mode, mode, N, M, r):
+    bq_mode(mode)
+    pts = synth.make_batch([3, 4], N)
+    ctr = oracle.gather_points(pts, oracle.fps(pts, M))
+    idx, cnt, grouped = F.query_and_group(_t(pts, dev), _t(ctr, dev), r, 64)
+    ridx, rcnt = oracle.ball_query(pts, ctr, r, 64)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(cnt.cpu().numpy(), rcnt)
+    assert np.array_equal(grouped.cpu().numpy(), oracle.group_points(pts, ridx))
+    assert tuple(grouped.shape) == (2, 3, M, 64) and grouped.is_contiguous()
+
+
 def test_ball_query_empty_balls_and_padding(F, oracle, dev):
     pts = np.zeros((1, 3, 10), dtype=np.float32)
     pts[0, 0, :] = np.arange(10)
