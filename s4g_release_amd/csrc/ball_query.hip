@@ -105,6 +105,7 @@ constexpr int GR_RANGES = 8;          // z-slabs = build workgroups per scene
 constexpr int GR_RANGE_SLOTS = 4096;  // slots per slab
 constexpr int GR_START_STRIDE = GR_RANGE_SLOTS + 4;  // +1 end entry, padded to 16 B
 constexpr int GR_BUILD_THREADS = 1024;
+constexpr int GR_BUILD_U = 8;         // independent point loads in flight per lane
 constexpr int GR_COORD_LIMIT = 4096;  // |cell coordinate| bound of the exactness argument
 constexpr int GR_MAX_POINTS = 65536;  // bitmap of N bits per wave must fit LDS
 
@@ -158,16 +159,30 @@ __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
   for (int s = t; s < GR_RANGE_SLOTS; s += GR_BUILD_THREADS) hist[s] = 0;
   __syncthreads();
 
+  // The point loops issue GR_BUILD_U independent plane loads per lane before
+  // touching them: the slab workgroups are latency-, not bandwidth-bound.
   int bad = 0;
-  for (int j = t; j < N; j += GR_BUILD_THREADS) {
-    const int cx = grid_coord(px[j], ox, inv_h);
-    const int cy = grid_coord(py[j], oy, inv_h);
-    const int cz = grid_coord(pz[j], oz, inv_h);
-    if (!(grid_coord_ok(px[j], ox, inv_h) && grid_coord_ok(py[j], oy, inv_h) &&
-          grid_coord_ok(pz[j], oz, inv_h)))
-      bad = 1;
-    const int slot = grid_slot(cx, cy, cz);
-    if ((slot >> 12) == g) atomicAdd(&hist[slot & (GR_RANGE_SLOTS - 1)], 1u);
+  for (int j0 = t; j0 < N; j0 += GR_BUILD_THREADS * GR_BUILD_U) {
+    float x[GR_BUILD_U], y[GR_BUILD_U], z[GR_BUILD_U];
+#pragma unroll
+    for (int u = 0; u < GR_BUILD_U; ++u) {
+      const int j = j0 + u * GR_BUILD_THREADS;
+      const int jj = j < N ? j : 0;
+      x[u] = px[jj];
+      y[u] = py[jj];
+      z[u] = pz[jj];
+    }
+#pragma unroll
+    for (int u = 0; u < GR_BUILD_U; ++u) {
+      if (j0 + u * GR_BUILD_THREADS < N) {
+        if (!(grid_coord_ok(x[u], ox, inv_h) && grid_coord_ok(y[u], oy, inv_h) &&
+              grid_coord_ok(z[u], oz, inv_h)))
+          bad = 1;
+        const int slot = grid_slot(grid_coord(x[u], ox, inv_h), grid_coord(y[u], oy, inv_h),
+                                   grid_coord(z[u], oz, inv_h));
+        if ((slot >> 12) == g) atomicAdd(&hist[slot & (GR_RANGE_SLOTS - 1)], 1u);
+      }
+    }
   }
   bad = __syncthreads_or(bad);
   if (g == 0 && t == 0) ws.flags[b] = bad ? 1 : 0;
@@ -197,19 +212,35 @@ __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
   __syncthreads();
 
   float4* __restrict__ rec = ws.sorted + (size_t)b * GR_RANGES * N;
-  for (int j = t; j < N; j += GR_BUILD_THREADS) {
-    const float x = px[j], y = py[j], z = pz[j];
-    const int slot = grid_slot(grid_coord(x, ox, inv_h), grid_coord(y, oy, inv_h),
-                               grid_coord(z, oz, inv_h));
-    if ((slot >> 12) == g) {
-      const uint32_t pos = atomicAdd(&hist[slot & (GR_RANGE_SLOTS - 1)], 1u);
-      rec[pos] = make_float4(x, y, z, __int_as_float(j));
+  for (int j0 = t; j0 < N; j0 += GR_BUILD_THREADS * GR_BUILD_U) {
+    float x[GR_BUILD_U], y[GR_BUILD_U], z[GR_BUILD_U];
+#pragma unroll
+    for (int u = 0; u < GR_BUILD_U; ++u) {
+      const int j = j0 + u * GR_BUILD_THREADS;
+      const int jj = j < N ? j : 0;
+      x[u] = px[jj];
+      y[u] = py[jj];
+      z[u] = pz[jj];
+    }
+#pragma unroll
+    for (int u = 0; u < GR_BUILD_U; ++u) {
+      const int j = j0 + u * GR_BUILD_THREADS;
+      if (j < N) {
+        const int slot = grid_slot(grid_coord(x[u], ox, inv_h), grid_coord(y[u], oy, inv_h),
+                                   grid_coord(z[u], oz, inv_h));
+        if ((slot >> 12) == g) {
+          const uint32_t pos = atomicAdd(&hist[slot & (GR_RANGE_SLOTS - 1)], 1u);
+          rec[pos] = make_float4(x[u], y[u], z[u], __int_as_float(j));
+        }
+      }
     }
   }
 }
 
 // One wave per centroid.  Dynamic LDS per wave: bitmap of N bits + K-entry row.
-template <bool FMAD, typename IdxT, bool GROUP>
+// WPL > 0: words per lane known at compile time (bitmap kept in registers
+// between the counting and the emission pass); WPL == 0: runtime value.
+template <bool FMAD, typename IdxT, bool GROUP, int WPL>
 __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void bq_grid_query_kernel(
     const float* __restrict__ xyz, const float* __restrict__ ctr, int N, int M,
     float r2, float inv_h, int K, GridWs ws, IdxT* __restrict__ idx,
@@ -265,44 +296,70 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void bq_grid_query_kernel(
         end1 = st[(x0 + 3) & 31];
       }
     }
+    // All 9 rows advance together: lanes 7r..7r+6 stride through row r, so the
+    // record loads of every row are in flight at once (a wave per centroid is
+    // latency-bound, not throughput-bound).  Lane 63 idles.
     const float4* __restrict__ rec = ws.sorted + (size_t)b * GR_RANGES * N;
-    for (int r = 0; r < 9; ++r) {
-      const int b0 = __builtin_amdgcn_readlane(beg0, r), e0 = __builtin_amdgcn_readlane(end0, r);
-      for (int j = b0 + lane; j < e0; j += 64) {
-        const float4 p = rec[j];
-        if (dist2<FMAD>(cx, cy, cz, p.x, p.y, p.z) < r2) {
-          const int pi = __float_as_int(p.w);
+    const int grp = lane / 7, sub = lane - grp * 7;
+    const int src = grp < 9 ? grp : 0;
+#pragma unroll
+    for (int piece = 0; piece < 2; ++piece) {
+      int j = __shfl(piece == 0 ? beg0 : beg1, src) + sub;
+      const int je = grp < 9 ? __shfl(piece == 0 ? end0 : end1, src) : 0;
+      if (grp >= 9) j = 0;
+      while (__any(j < je)) {
+        const bool a0 = j < je, a1 = j + 7 < je;
+        float4 p0, p1;
+        if (a0) p0 = rec[j];
+        if (a1) p1 = rec[j + 7];
+        if (a0 && dist2<FMAD>(cx, cy, cz, p0.x, p0.y, p0.z) < r2) {
+          const int pi = __float_as_int(p0.w);
           atomicOr(&bm[pi >> 5], 1u << (pi & 31));
         }
-      }
-      const int b1 = __builtin_amdgcn_readlane(beg1, r), e1 = __builtin_amdgcn_readlane(end1, r);
-      for (int j = b1 + lane; j < e1; j += 64) {
-        const float4 p = rec[j];
-        if (dist2<FMAD>(cx, cy, cz, p.x, p.y, p.z) < r2) {
-          const int pi = __float_as_int(p.w);
+        if (a1 && dist2<FMAD>(cx, cy, cz, p1.x, p1.y, p1.z) < r2) {
+          const int pi = __float_as_int(p1.w);
           atomicOr(&bm[pi >> 5], 1u << (pi & 31));
         }
+        j += 14;
       }
     }
     // read the bitmap back in index order: lane l owns words [l*W, (l+1)*W)
     const uint32_t* mine = bm + lane * words_per_lane;
     int local = 0;
-    for (int w = 0; w < words_per_lane; ++w) local += __popc(mine[w]);
-    int incl = local;
+    int pos, total;
+    if constexpr (WPL > 0) {
+      uint32_t wv[WPL];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int o = __shfl_up(incl, off);
-      if (lane >= off) incl += o;
-    }
-    const int total = __builtin_amdgcn_readlane(incl, 63);
-    int pos = incl - local;
-    if (local > 0 && pos < K) {
-      for (int w = 0; w < words_per_lane && pos < K; ++w) {
-        uint32_t bits = mine[w];
-        while (bits && pos < K) {
-          const int bit = __ffs(bits) - 1;
-          row[pos++] = (lane * words_per_lane + w) * 32 + bit;
-          bits &= bits - 1;
+      for (int w = 0; w < WPL; ++w) wv[w] = mine[w];
+#pragma unroll
+      for (int w = 0; w < WPL; ++w) local += __popc(wv[w]);
+      const int incl = (int)wave_inclusive_scan_u32((uint32_t)local);
+      total = __builtin_amdgcn_readlane(incl, 63);
+      pos = incl - local;
+      if (local > 0 && pos < K) {
+#pragma unroll
+        for (int w = 0; w < WPL; ++w) {
+          uint32_t bits = wv[w];
+          while (bits && pos < K) {
+            const int bit = __ffs(bits) - 1;
+            row[pos++] = (lane * WPL + w) * 32 + bit;
+            bits &= bits - 1;
+          }
+        }
+      }
+    } else {
+      for (int w = 0; w < words_per_lane; ++w) local += __popc(mine[w]);
+      const int incl = (int)wave_inclusive_scan_u32((uint32_t)local);
+      total = __builtin_amdgcn_readlane(incl, 63);
+      pos = incl - local;
+      if (local > 0 && pos < K) {
+        for (int w = 0; w < words_per_lane && pos < K; ++w) {
+          uint32_t bits = mine[w];
+          while (bits && pos < K) {
+            const int bit = __ffs(bits) - 1;
+            row[pos++] = (lane * words_per_lane + w) * 32 + bit;
+            bits &= bits - 1;
+          }
         }
       }
     }
@@ -387,15 +444,22 @@ static int ball_query_dispatch(const float* xyz, const float* ctr, int64_t B,
   int wpl = (words + 63) / 64;
   if ((wpl & 1) == 0) ++wpl;  // odd stride: conflict-free per-lane word runs
   const size_t lds = sizeof(uint32_t) * BQ_WAVES_PER_BLOCK * (size_t)(64 * wpl + K);
-#define S4G_BQ_LAUNCH(F, G)                                                          \
-  hipLaunchKernelGGL((bq_grid_query_kernel<F, IdxT, G>), grid, block, lds, st, xyz,  \
+#define S4G_BQ_LAUNCH3(F, G, W)                                                         \
+  hipLaunchKernelGGL((bq_grid_query_kernel<F, IdxT, G, W>), grid, block, lds, st, xyz,  \
                      ctr, (int)N, (int)M, r2, inv_h, (int)K, g, idx, cnt, grouped, wpl)
+#define S4G_BQ_LAUNCH(F, G)                      \
+  do {                                           \
+    if (wpl == 13) S4G_BQ_LAUNCH3(F, G, 13);     \
+    else if (wpl == 25) S4G_BQ_LAUNCH3(F, G, 25);\
+    else S4G_BQ_LAUNCH3(F, G, 0);                \
+  } while (0)
   if (grouped) {
     if (fmad) S4G_BQ_LAUNCH(true, true); else S4G_BQ_LAUNCH(false, true);
   } else {
     if (fmad) S4G_BQ_LAUNCH(true, false); else S4G_BQ_LAUNCH(false, false);
   }
 #undef S4G_BQ_LAUNCH
+#undef S4G_BQ_LAUNCH3
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }

@@ -79,6 +79,22 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   return min(min(a, b), min(c, d));
 }
 
+// Inclusive prefix sum over the 64 lanes: Hillis-Steele inside each row of 16
+// (row_shr 1,2,4,8 with zero fill), then row_bcast15 / row_bcast31 carry the
+// row totals across (6 DPP adds, no LDS crossbar traffic).
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
+#define S4G_DPP0(CTRL, RM) \
+  (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, RM, 0xF, true)
+  v += S4G_DPP0(0x111, 0xF);
+  v += S4G_DPP0(0x112, 0xF);
+  v += S4G_DPP0(0x114, 0xF);
+  v += S4G_DPP0(0x118, 0xF);
+  v += S4G_DPP0(0x142, 0xA);
+  v += S4G_DPP0(0x143, 0xC);
+#undef S4G_DPP0
+  return v;
+}
+
 __device__ __forceinline__ int lane_id() {
   return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
 }
