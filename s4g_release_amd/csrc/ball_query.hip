@@ -17,16 +17,16 @@
 //  GRID  for big sparse levels (SA1: 25 600 points, 76 % of the balls never
 //        reach K = 64, so a scan reads everything).  Per call:
 //        1. build: a 32x32x32 *toroidal* cell grid with cell edge h = r*(1+2^-8)
-//           (slot = z5|y5|x5 of the cell coordinates mod 32; clouds wider than
-//           32 cells alias, which only adds candidates).  One launch, 8
-//           workgroups per scene, each owning a z-slab of 4096 slots: LDS
+//           (cell coordinates mod 32; clouds wider than 32 cells alias, which
+//           only adds candidates).  One launch, 8 workgroups per scene, each
+//           owning the 4096 slots of one y-stripe class (y mod 8): LDS
 //           histogram -> scan -> scatter of (x,y,z,index) records.  No global
 //           atomics, no cross-workgroup exchange, no bounding-box pass (cell
 //           coordinates are relative to the scene's first point).
-//        2. query: one wave per centroid visits the 9 rows of 3 x-adjacent
-//           cells around it (each row is ONE contiguous record range), tests
-//           the ~150-350 candidates, and marks hits in an LDS *bitmap over the
-//           point index*.  Reading the bitmap back in order yields exactly the
+//        2. query: a wave walks 8 centroids; for each it visits the 9 rows of 3
+//           x-adjacent cells around it (each row is ONE contiguous record
+//           range, all rows in flight at once), tests the ~100-350 candidates,
+//           and marks hits in an LDS *bitmap over the point index*.  Reading the bitmap back in order yields exactly the
 //           reference's "first K in index order" -- candidates may arrive in any
 //           order, be duplicated by aliasing, or exceed K, without affecting
 //           the result.  Output rows are staged in LDS and stored coalesced.
@@ -139,8 +139,14 @@ __device__ __forceinline__ int grid_coord(float v, float o, float inv_h) {
 __device__ __forceinline__ bool grid_coord_ok(float v, float o, float inv_h) {
   return fabsf(__fmul_rn(__fsub_rn(v, o), inv_h)) < (float)(GR_COORD_LIMIT - 1);
 }
+// slot = (range, local): range = y mod 8 (interleaved stripes balance thin,
+// table-top shaped clouds over the 8 build workgroups), local = z5 | y-high2 | x5.
+// Any function of (y, z) keeps the 32 x-cells of a row contiguous.
+__device__ __forceinline__ int grid_range(int yy, int zz) { (void)zz; return yy & 7; }
+__device__ __forceinline__ int grid_local_row(int yy, int zz) { return (zz << 7) | ((yy >> 3) << 5); }
 __device__ __forceinline__ int grid_slot(int cx, int cy, int cz) {
-  return ((cz & 31) << 10) | ((cy & 31) << 5) | (cx & 31);
+  const int yy = cy & 31, zz = cz & 31;
+  return (grid_range(yy, zz) << 12) | grid_local_row(yy, zz) | (cx & 31);
 }
 
 __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
@@ -238,53 +244,61 @@ __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
 }
 
 // One wave per centroid.  Dynamic LDS per wave: bitmap of N bits + K-entry row.
-// WPL > 0: words per lane known at compile time (bitmap kept in registers
-// between the counting and the emission pass); WPL == 0: runtime value.
+// Each wave owns BQ_CPW consecutive centroids and one LDS bitmap that it keeps
+// clean (touched words are cleared while they are read back).  Lane l < BQ_CPW
+// fetches centroid l up front, the 9 row ranges of centroid c+1 are fetched
+// while centroid c is processed, and a lane keeps BQ_REC record loads in
+// flight: a wave is latency-bound, so dependent round trips are what is
+// minimised.  WPL = bitmap words per lane (compile time; 0 = runtime value).
+constexpr int BQ_CPW = 8;
+constexpr int BQ_REC = 4;
+
 template <bool FMAD, typename IdxT, bool GROUP, int WPL>
 __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void bq_grid_query_kernel(
     const float* __restrict__ xyz, const float* __restrict__ ctr, int N, int M,
     float r2, float inv_h, int K, GridWs ws, IdxT* __restrict__ idx,
-    IdxT* __restrict__ cnt_out, float* __restrict__ grouped, int words_per_lane) {
+    IdxT* __restrict__ cnt_out, float* __restrict__ grouped, int words_per_lane_rt) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int words_per_lane = WPL > 0 ? WPL : words_per_lane_rt;
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int m = blockIdx.x * BQ_WAVES_PER_BLOCK + wave;
-  if (m >= M) return;
-  const int wave_words = 64 * words_per_lane + K;
+  const int m0 = (blockIdx.x * BQ_WAVES_PER_BLOCK + wave) * BQ_CPW;
+  if (m0 >= M) return;
+  const int nc = min(BQ_CPW, M - m0);
+  const int bm_words = 64 * words_per_lane;          // multiple of 4
+  const int wave_words = bm_words + ((K + 3) & ~3);
   uint32_t* __restrict__ bm = lds + wave * wave_words;
-  int* __restrict__ row = (int*)(bm + 64 * words_per_lane);
+  int* __restrict__ row = (int*)(bm + bm_words);
+  for (int w = lane * 4; w < bm_words; w += 256)
+    *reinterpret_cast<uint4*>(bm + w) = make_uint4(0u, 0u, 0u, 0u);
 
   const float* __restrict__ px = xyz + (size_t)b * 3 * N;
   const float* __restrict__ py = px + N;
   const float* __restrict__ pz = py + N;
   const float* __restrict__ c = ctr + (size_t)b * 3 * M;
-  const float cx = c[m], cy = c[M + m], cz = c[2 * M + m];
-  IdxT* __restrict__ out_row = idx + ((size_t)b * M + m) * K;
-  IdxT* __restrict__ out_cnt = cnt_out + (size_t)b * M + m;
+  const float ox = px[0], oy = py[0], oz = pz[0];
+  const bool scene_ok = ws.flags[b] == 0;
+  const float4* __restrict__ rec = ws.sorted + (size_t)b * GR_RANGES * N;
+  const int* __restrict__ starts_b = ws.starts + (size_t)b * GR_RANGES * GR_START_STRIDE;
 
-  const int icx = grid_coord(cx, px[0], inv_h);
-  const int icy = grid_coord(cy, py[0], inv_h);
-  const int icz = grid_coord(cz, pz[0], inv_h);
-  const bool exact = (ws.flags[b] == 0) && grid_coord_ok(cx, px[0], inv_h) &&
-                     grid_coord_ok(cy, py[0], inv_h) && grid_coord_ok(cz, pz[0], inv_h);
-  bool in_lds = false;
-  if (!exact) {
-    // out of the grid's exactness range: index-order scan, straight to global
-    bq_scan_centroid<FMAD, IdxT>(px, py, pz, N, cx, cy, cz, r2, K, lane, out_row, out_cnt);
-    if constexpr (!GROUP) return;
-    __threadfence_block();  // the row is re-read below by other lanes of this wave
-  } else {
-    in_lds = true;
-    for (int w = lane; w < 64 * words_per_lane; w += 64) bm[w] = 0;
+  // lane l holds centroid m0 + l
+  const int ml = m0 + (lane < nc ? lane : 0);
+  const float lcx = c[ml], lcy = c[M + ml], lcz = c[2 * M + ml];
+  const int lix = grid_coord(lcx, ox, inv_h), liy = grid_coord(lcy, oy, inv_h),
+            liz = grid_coord(lcz, oz, inv_h);
+  const bool lexact = scene_ok && grid_coord_ok(lcx, ox, inv_h) &&
+                      grid_coord_ok(lcy, oy, inv_h) && grid_coord_ok(lcz, oz, inv_h);
 
-    // lanes 0..8 fetch the record ranges of the 9 (dy, dz) rows in parallel
-    int beg0 = 0, end0 = 0, beg1 = 0, end1 = 0;
+  // record ranges of the 9 (dy, dz) rows of centroid `ci`, fetched by lanes 0..8
+  auto fetch_rows = [&](int ci, int& beg0, int& end0, int& beg1, int& end1) {
+    const int icx = __shfl(lix, ci), icy = __shfl(liy, ci), icz = __shfl(liz, ci);
+    beg0 = end0 = beg1 = end1 = 0;
     if (lane < 9) {
       const int dz = lane / 3 - 1, dy = lane % 3 - 1;
       const int zz = (icz + dz) & 31, yy = (icy + dy) & 31;
-      const int* __restrict__ st = ws.starts +
-          ((size_t)b * GR_RANGES + (zz >> 2)) * GR_START_STRIDE + (((zz & 3) << 10) | (yy << 5));
+      const int* __restrict__ st = starts_b + grid_range(yy, zz) * GR_START_STRIDE +
+                                   grid_local_row(yy, zz);
       const int x0 = (icx - 1) & 31;
       if (x0 <= GR_DIM - 3) {
         beg0 = st[x0];
@@ -296,65 +310,82 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void bq_grid_query_kernel(
         end1 = st[(x0 + 3) & 31];
       }
     }
-    // All 9 rows advance together: lanes 7r..7r+6 stride through row r, so the
-    // record loads of every row are in flight at once (a wave per centroid is
-    // latency-bound, not throughput-bound).  Lane 63 idles.
-    const float4* __restrict__ rec = ws.sorted + (size_t)b * GR_RANGES * N;
-    const int grp = lane / 7, sub = lane - grp * 7;
-    const int src = grp < 9 ? grp : 0;
+  };
+
+  const int grp = lane / 7, sub = lane - grp * 7;  // lanes 7r..7r+6 walk row r; lane 63 idles
+  const int src = grp < 9 ? grp : 0;
+  int nb0, ne0, nb1, ne1;
+  fetch_rows(0, nb0, ne0, nb1, ne1);
+
+  for (int ci = 0; ci < nc; ++ci) {
+    const int m = m0 + ci;
+    const float cx = __shfl(lcx, ci), cy = __shfl(lcy, ci), cz = __shfl(lcz, ci);
+    const bool exact = __shfl((int)lexact, ci) != 0;
+    const int beg0 = nb0, end0 = ne0, beg1 = nb1, end1 = ne1;
+    if (ci + 1 < nc) fetch_rows(ci + 1, nb0, ne0, nb1, ne1);  // in flight during this centroid
+    IdxT* __restrict__ out_row = idx + ((size_t)b * M + m) * K;
+    IdxT* __restrict__ out_cnt = cnt_out + (size_t)b * M + m;
+    bool in_lds = false;
+    if (!exact) {
+      // out of the grid's exactness range: index-order scan, straight to global
+      bq_scan_centroid<FMAD, IdxT>(px, py, pz, N, cx, cy, cz, r2, K, lane, out_row, out_cnt);
+      if constexpr (GROUP) __threadfence_block();  // the row is re-read below by other lanes
+    } else {
+      in_lds = true;
 #pragma unroll
-    for (int piece = 0; piece < 2; ++piece) {
-      int j = __shfl(piece == 0 ? beg0 : beg1, src) + sub;
-      const int je = grp < 9 ? __shfl(piece == 0 ? end0 : end1, src) : 0;
-      if (grp >= 9) j = 0;
-      while (__any(j < je)) {
-        const bool a0 = j < je, a1 = j + 7 < je;
-        float4 p0, p1;
-        if (a0) p0 = rec[j];
-        if (a1) p1 = rec[j + 7];
-        if (a0 && dist2<FMAD>(cx, cy, cz, p0.x, p0.y, p0.z) < r2) {
-          const int pi = __float_as_int(p0.w);
-          atomicOr(&bm[pi >> 5], 1u << (pi & 31));
+      for (int piece = 0; piece < 2; ++piece) {
+        int j = __shfl(piece == 0 ? beg0 : beg1, src) + sub;
+        const int je = grp < 9 ? __shfl(piece == 0 ? end0 : end1, src) : 0;
+        if (grp >= 9) j = 0;
+        while (__any(j < je)) {
+          float4 p[BQ_REC];
+#pragma unroll
+          for (int u = 0; u < BQ_REC; ++u)
+            if (j + 7 * u < je) p[u] = rec[j + 7 * u];
+#pragma unroll
+          for (int u = 0; u < BQ_REC; ++u)
+            if (j + 7 * u < je && dist2<FMAD>(cx, cy, cz, p[u].x, p[u].y, p[u].z) < r2) {
+              const int pi = __float_as_int(p[u].w);
+              atomicOr(&bm[pi >> 5], 1u << (pi & 31));
+            }
+          j += 7 * BQ_REC;
         }
-        if (a1 && dist2<FMAD>(cx, cy, cz, p1.x, p1.y, p1.z) < r2) {
-          const int pi = __float_as_int(p1.w);
-          atomicOr(&bm[pi >> 5], 1u << (pi & 31));
-        }
-        j += 14;
       }
-    }
-    // read the bitmap back in index order: lane l owns words [l*W, (l+1)*W)
-    const uint32_t* mine = bm + lane * words_per_lane;
-    int local = 0;
-    int pos, total;
-    if constexpr (WPL > 0) {
-      uint32_t wv[WPL];
+      // read the bitmap back in index order: lane l owns words [l*W, (l+1)*W)
+      uint32_t* mine = bm + lane * words_per_lane;
+      int local = 0;
+      uint32_t nz = 0;  // which of this lane's words are non-zero
+      if constexpr (WPL > 0) {
+        uint32_t wv[WPL];
 #pragma unroll
-      for (int w = 0; w < WPL; ++w) wv[w] = mine[w];
-#pragma unroll
-      for (int w = 0; w < WPL; ++w) local += __popc(wv[w]);
-      const int incl = (int)wave_inclusive_scan_u32((uint32_t)local);
-      total = __builtin_amdgcn_readlane(incl, 63);
-      pos = incl - local;
-      if (local > 0 && pos < K) {
+        for (int w = 0; w < WPL; ++w) wv[w] = mine[w];
 #pragma unroll
         for (int w = 0; w < WPL; ++w) {
-          uint32_t bits = wv[w];
+          local += __popc(wv[w]);
+          nz |= (wv[w] != 0u ? 1u : 0u) << w;
+        }
+      } else {
+        for (int w = 0; w < words_per_lane; ++w) local += __popc(mine[w]);
+      }
+      const int incl = (int)wave_inclusive_scan_u32((uint32_t)local);
+      const int total = __builtin_amdgcn_readlane(incl, 63);
+      int pos = incl - local;
+      if constexpr (WPL > 0) {
+        while (nz) {  // only the touched words; clear them for the next centroid
+          const int w = __ffs(nz) - 1;
+          nz &= nz - 1;
+          uint32_t bits = mine[w];
+          mine[w] = 0u;
           while (bits && pos < K) {
             const int bit = __ffs(bits) - 1;
             row[pos++] = (lane * WPL + w) * 32 + bit;
             bits &= bits - 1;
           }
         }
-      }
-    } else {
-      for (int w = 0; w < words_per_lane; ++w) local += __popc(mine[w]);
-      const int incl = (int)wave_inclusive_scan_u32((uint32_t)local);
-      total = __builtin_amdgcn_readlane(incl, 63);
-      pos = incl - local;
-      if (local > 0 && pos < K) {
-        for (int w = 0; w < words_per_lane && pos < K; ++w) {
+      } else if (local > 0) {
+        for (int w = 0; w < words_per_lane; ++w) {
           uint32_t bits = mine[w];
+          if (bits) mine[w] = 0u;
           while (bits && pos < K) {
             const int bit = __ffs(bits) - 1;
             row[pos++] = (lane * words_per_lane + w) * 32 + bit;
@@ -362,25 +393,25 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void bq_grid_query_kernel(
           }
         }
       }
+      const int cnt = total < K ? total : K;
+      const int first = cnt > 0 ? row[0] : 0;
+      for (int k = lane; k < K; k += 64) {
+        const int v = k < cnt ? row[k] : first;
+        out_row[k] = (IdxT)v;
+        if constexpr (GROUP) row[k] = v;
+      }
+      if (lane == 0) *out_cnt = (IdxT)cnt;
     }
-    const int cnt = total < K ? total : K;
-    const int first = cnt > 0 ? row[0] : 0;
-    for (int k = lane; k < K; k += 64) {
-      const int v = k < cnt ? row[k] : first;
-      out_row[k] = (IdxT)v;
-      if constexpr (GROUP) row[k] = v;
-    }
-    if (lane == 0) *out_cnt = (IdxT)cnt;
-  }
-  if constexpr (GROUP) {
-    // group_points(xyz, index) for this centroid: out[b][c][m][k] = xyz[b][c][idx]
-    const size_t MK = (size_t)M * K;
-    float* __restrict__ gx = grouped + (size_t)b * 3 * MK + (size_t)m * K;
-    for (int k = lane; k < K; k += 64) {
-      const int v = in_lds ? row[k] : (int)out_row[k];  // (fenced below for the scan path)
-      gx[k] = px[v];
-      gx[MK + k] = py[v];
-      gx[2 * MK + k] = pz[v];
+    if constexpr (GROUP) {
+      // group_points(xyz, index) for this centroid: out[b][c][m][k] = xyz[b][c][idx]
+      const size_t MK = (size_t)M * K;
+      float* __restrict__ gx = grouped + (size_t)b * 3 * MK + (size_t)m * K;
+      for (int k = lane; k < K; k += 64) {
+        const int v = in_lds ? row[k] : (int)out_row[k];
+        gx[k] = px[v];
+        gx[MK + k] = py[v];
+        gx[2 * MK + k] = pz[v];
+      }
     }
   }
 }
@@ -421,6 +452,8 @@ static int ball_query_dispatch(const float* xyz, const float* ctr, int64_t B,
   const bool fmad = (flags & S4G_FLAG_FMAD) != 0;
   const dim3 block(64 * BQ_WAVES_PER_BLOCK);
   const dim3 grid((unsigned)((M + BQ_WAVES_PER_BLOCK - 1) / BQ_WAVES_PER_BLOCK), (unsigned)B);
+  const int cpb = BQ_WAVES_PER_BLOCK * BQ_CPW;
+  const dim3 qgrid((unsigned)((M + cpb - 1) / cpb), (unsigned)B);
   const bool use_grid = bq_use_grid(N, K) && ws && ws_bytes >= grid_ws_bytes(B, N) &&
                         radius > 0.f && radius < 1e18f;
   if (!use_grid) {
@@ -443,9 +476,9 @@ static int ball_query_dispatch(const float* xyz, const float* ctr, int64_t B,
   const int words = (int)((N + 31) / 32);
   int wpl = (words + 63) / 64;
   if ((wpl & 1) == 0) ++wpl;  // odd stride: conflict-free per-lane word runs
-  const size_t lds = sizeof(uint32_t) * BQ_WAVES_PER_BLOCK * (size_t)(64 * wpl + K);
+  const size_t lds = sizeof(uint32_t) * BQ_WAVES_PER_BLOCK * (size_t)(64 * wpl + ((K + 3) & ~3));
 #define S4G_BQ_LAUNCH3(F, G, W)                                                         \
-  hipLaunchKernelGGL((bq_grid_query_kernel<F, IdxT, G, W>), grid, block, lds, st, xyz,  \
+  hipLaunchKernelGGL((bq_grid_query_kernel<F, IdxT, G, W>), qgrid, block, lds, st, xyz, \
                      ctr, (int)N, (int)M, r2, inv_h, (int)K, g, idx, cnt, grouped, wpl)
 #define S4G_BQ_LAUNCH(F, G)                      \
   do {                                           \
