@@ -180,6 +180,7 @@ def main():
                 F.OpTimer.reset(enabled=True)
             gidx, _ = F.ball_query(pts, ctr, cfg.radius[0], K)
             F.group_points(pts, gidx)
+            F.query_and_group(pts, ctr, cfg.radius[0], K)
         torch.cuda.synchronize()
         F.OpTimer.enabled = False
     probe = F.OpTimer.summary()
@@ -194,6 +195,11 @@ def main():
                 "bytes_per_launch_pair": int(nbytes), "ms_ball_query": round(bq[1], 5),
                 "ms_group_points": round(gp[1], 5), "scenes_per_launch": B,
                 "note": "algorithmic bytes = B*(12N+12M+8MK+8M) + B*(4CN+8MK+4CMK), C=3"}
+    fq = probe.get("query_group[N=%d,M=%d,K=%d]" % (N, M, K))
+    if fq:   # the same pair as ONE pass (s4g_query_group_f32), same algorithmic bytes
+        roofline["fused_pair_ms"] = round(fq[1], 5)
+        roofline["fused_pair_achieved"] = round(fq[2] / fq[1] / 1e6, 2)
+        roofline["fused_pair_frac"] = round(fq[2] / fq[1] / 1e6 / HBM_PEAK_GBS, 4)
     if gemm_ms > 0:
         dense_tf = gemm_flops / gemm_ms / 1e9
         roofline_dense = {"kernel": "mlp_gemm_kernel (fp32 MFMA), all launches of one step",

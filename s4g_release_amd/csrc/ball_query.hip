@@ -244,16 +244,15 @@ __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
 }
 
 // One wave per centroid.  Dynamic LDS per wave: bitmap of N bits + K-entry row.
-// Each wave owns BQ_CPW consecutive centroids and one LDS bitmap that it keeps
+// Each wave owns BQ_CPW (template) consecutive centroids and one LDS bitmap that it keeps
 // clean (touched words are cleared while they are read back).  Lane l < BQ_CPW
 // fetches centroid l up front, the 9 row ranges of centroid c+1 are fetched
 // while centroid c is processed, and a lane keeps BQ_REC record loads in
 // flight: a wave is latency-bound, so dependent round trips are what is
 // minimised.  WPL = bitmap words per lane (compile time; 0 = runtime value).
-constexpr int BQ_CPW = 8;
 constexpr int BQ_REC = 4;
 
-template <bool FMAD, typename IdxT, bool GROUP, int WPL>
+template <bool FMAD, typename IdxT, bool GROUP, int WPL, int BQ_CPW>
 __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void bq_grid_query_kernel(
     const float* __restrict__ xyz, const float* __restrict__ ctr, int N, int M,
     float r2, float inv_h, int K, GridWs ws, IdxT* __restrict__ idx,
@@ -332,8 +331,8 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void bq_grid_query_kernel(
       if constexpr (GROUP) __threadfence_block();  // the row is re-read below by other lanes
     } else {
       in_lds = true;
-#pragma unroll
-      for (int piece = 0; piece < 2; ++piece) {
+      const int npiece = __any(end1 > beg1) ? 2 : 1;  // the wrapped second piece is rare
+      for (int piece = 0; piece < npiece; ++piece) {
         int j = __shfl(piece == 0 ? beg0 : beg1, src) + sub;
         const int je = grp < 9 ? __shfl(piece == 0 ? end0 : end1, src) : 0;
         if (grp >= 9) j = 0;
@@ -452,7 +451,10 @@ static int ball_query_dispatch(const float* xyz, const float* ctr, int64_t B,
   const bool fmad = (flags & S4G_FLAG_FMAD) != 0;
   const dim3 block(64 * BQ_WAVES_PER_BLOCK);
   const dim3 grid((unsigned)((M + BQ_WAVES_PER_BLOCK - 1) / BQ_WAVES_PER_BLOCK), (unsigned)B);
-  const int cpb = BQ_WAVES_PER_BLOCK * BQ_CPW;
+  int cpw = 1;  // centroids per wave (S4G_BQ_CPW=1|2|4|8 tuning knob; 1 measured best)
+  if (const char* e = getenv("S4G_BQ_CPW")) cpw = atoi(e);
+  if (cpw != 1 && cpw != 2 && cpw != 4 && cpw != 8) cpw = 1;
+  const int cpb = BQ_WAVES_PER_BLOCK * cpw;
   const dim3 qgrid((unsigned)((M + cpb - 1) / cpb), (unsigned)B);
   const bool use_grid = bq_use_grid(N, K) && ws && ws_bytes >= grid_ws_bytes(B, N) &&
                         radius > 0.f && radius < 1e18f;
@@ -477,9 +479,16 @@ static int ball_query_dispatch(const float* xyz, const float* ctr, int64_t B,
   int wpl = (words + 63) / 64;
   if ((wpl & 1) == 0) ++wpl;  // odd stride: conflict-free per-lane word runs
   const size_t lds = sizeof(uint32_t) * BQ_WAVES_PER_BLOCK * (size_t)(64 * wpl + ((K + 3) & ~3));
-#define S4G_BQ_LAUNCH3(F, G, W)                                                         \
-  hipLaunchKernelGGL((bq_grid_query_kernel<F, IdxT, G, W>), qgrid, block, lds, st, xyz, \
+#define S4G_BQ_LAUNCH4(F, G, W, C)                                                        \
+  hipLaunchKernelGGL((bq_grid_query_kernel<F, IdxT, G, W, C>), qgrid, block, lds, st, xyz, \
                      ctr, (int)N, (int)M, r2, inv_h, (int)K, g, idx, cnt, grouped, wpl)
+#define S4G_BQ_LAUNCH3(F, G, W)                  \
+  do {                                           \
+    if (cpw == 1) S4G_BQ_LAUNCH4(F, G, W, 1);    \
+    else if (cpw == 2) S4G_BQ_LAUNCH4(F, G, W, 2);\
+    else if (cpw == 4) S4G_BQ_LAUNCH4(F, G, W, 4);\
+    else S4G_BQ_LAUNCH4(F, G, W, 8);             \
+  } while (0)
 #define S4G_BQ_LAUNCH(F, G)                      \
   do {                                           \
     if (wpl == 13) S4G_BQ_LAUNCH3(F, G, 13);     \
@@ -493,6 +502,7 @@ static int ball_query_dispatch(const float* xyz, const float* ctr, int64_t B,
   }
 #undef S4G_BQ_LAUNCH
 #undef S4G_BQ_LAUNCH3
+#undef S4G_BQ_LAUNCH4
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }
