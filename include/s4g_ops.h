@@ -160,6 +160,8 @@ int s4g_interp_weights_f32(const float *d2_bn3, int64_t B, int64_t N1,
 #define S4G_GEMM_EPI_STORE 0
 #define S4G_GEMM_EPI_MAX 1
 #define S4G_GEMM_EPI_CHANNEL_FIRST 2
+#define S4G_GEMM_FP32 0
+#define S4G_GEMM_BF16X3 1
 
 typedef struct s4g_gemm_desc {
   int32_t loader, epilogue, groups, relu;
@@ -188,6 +190,13 @@ typedef struct s4g_gemm_desc {
   float *cf_ptr[4];
   int32_t cf_start[5];
   int32_t cf_sigmoid_from, cf_N;
+  /* arithmetic: S4G_GEMM_FP32 = v_mfma_f32_32x32x2_f32 on W (exact fp32 fma
+   * chain); S4G_GEMM_BF16X3 = each fp32 operand split exactly into three bf16
+   * numbers, six v_mfma_f32_32x32x16_bf16 per step, fp32 accumulate (drops
+   * only terms below 2^-24 |a||b|).  W_bf16x3 is [3][groups][Cout][Kpad16]
+   * bf16 (hi, mid, lo planes of W), Kpad16 % 16 == 0. */
+  int32_t precision, Kpad16;
+  const void *W_bf16x3;
 } s4g_gemm_desc_t;
 
 int s4g_mlp_gemm_f32(const s4g_gemm_desc_t *desc, s4g_stream_t stream);

@@ -76,6 +76,10 @@ struct GemmParams {
   int cf_sigmoid_from;  // channels >= this get a sigmoid
   int cf_N;             // points per batch element
   int mtiles, ntiles;
+  // bf16x3 path: W split into three bf16 planes [3][groups][Cout][Kpad16]
+  const uint16_t* W3;
+  int Kpad16;
+  size_t w3_plane;  // elements between planes
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -156,6 +160,116 @@ struct ALoader {
     }
   }
 };
+
+// Shared epilogue.  D layout of every 32x32 MFMA: col = lane & 31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][2],
+                                              const float* __restrict__ bg, int g, int p0,
+                                              int n0, int wr, int wc, int li, int lh) {
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int n = n0 + wc * 64 + cb * 32 + li;
+    const bool nok = n < p.Cout;
+    const float bias = nok ? bg[n] : 0.f;
+    if constexpr (EPI == EPI_STORE) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = p0 + wr * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          float v = acc[rb][cb][r] + bias;
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (nok && row < p.P)
+            p.out[(size_t)row * p.ldc + p.c_coff + g * p.c_gcol + n] = v;
+        }
+    } else if constexpr (EPI == EPI_MAX) {
+      // max over groups of K consecutive rows, K in {16, 32, 64}; then
+      // bias + ReLU (monotone, so max-then-activate == activate-then-max).
+      if (p.K == 64) {
+        float m = acc[0][cb][0];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[rb][cb][r]);
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float v = m + bias;
+        if (p.relu) v = fmaxf(v, 0.f);
+        const int grp = (p0 + wr * 64) >> 6;
+        if (nok && lh == 0 && p0 + wr * 64 < p.P)
+          p.out[(size_t)grp * p.ldc + p.c_coff + n] = v;
+      } else if (p.K == 32) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          float m = acc[rb][cb][0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rb][cb][r]);
+          m = fmaxf(m, __shfl_xor(m, 32));
+          float v = m + bias;
+          if (p.relu) v = fmaxf(v, 0.f);
+          const int row0 = p0 + wr * 64 + rb * 32;
+          if (nok && lh == 0 && row0 < p.P)
+            p.out[(size_t)(row0 >> 5) * p.ldc + p.c_coff + n] = v;
+        }
+      } else {  // K == 16: rows 0-15 are regs with (r>>2) in {0,1}, rows 16-31 {2,3}
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            float m = acc[rb][cb][8 * hh];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) m = fmaxf(m, acc[rb][cb][8 * hh + r]);
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float v = m + bias;
+            if (p.relu) v = fmaxf(v, 0.f);
+            const int row0 = p0 + wr * 64 + rb * 32 + 16 * hh;
+            if (nok && lh == 0 && row0 < p.P)
+              p.out[(size_t)(row0 >> 4) * p.ldc + p.c_coff + n] = v;
+          }
+      }
+    } else {  // EPI_CHANNEL_FIRST: out[b][c][n_pt], 4 consecutive points per store
+      int head = 0;
+#pragma unroll
+      for (int h2 = 1; h2 < 4; ++h2)
+        if (n >= p.cf_start[h2]) head = h2;
+      const int cl = n - p.cf_start[head];
+      const int ch = p.cf_start[head + 1] - p.cf_start[head];
+      float* base = p.cf_ptr[head];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int row = p0 + wr * 64 + rb * 32 + 8 * r4 + 4 * lh;
+          if (nok && n < p.cf_start[4] && row < p.P) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x = acc[rb][cb][4 * r4 + e] + bias;
+              if (p.relu) x = fmaxf(x, 0.f);
+              if (n >= p.cf_sigmoid_from) x = 1.0f / (1.0f + expf(-x));
+              v[e] = x;
+            }
+            const int b = row / p.cf_N;
+            const int pt = row - b * p.cf_N;
+            float* dst = base + ((size_t)b * ch + cl) * p.cf_N + pt;
+            if (pt + 3 < p.cf_N && (p.cf_N & 3) == 0) {
+              *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int row_e = row + e;
+                if (row_e < p.P) {
+                  const int be = row_e / p.cf_N;
+                  const int pe = row_e - be * p.cf_N;
+                  base[((size_t)be * ch + cl) * p.cf_N + pe] = v[e];
+                }
+              }
+            }
+          }
+        }
+    }
+  }
+}
 
 template <int LOADER, int EPI>
 __global__ __launch_bounds__(GM_THREADS, 2) void mlp_gemm_kernel(const GemmParams p) {
@@ -263,109 +377,188 @@ __global__ __launch_bounds__(GM_THREADS, 2) void mlp_gemm_kernel(const GemmParam
     __syncthreads();
   }
 
-  // ---- epilogue.  D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  gemm_epilogue<EPI>(p, acc, bg, g, p0, n0, wr, wc, li, lh);
+}
+
+// ---------------------------------------------------------------------------
+// bf16x3 variant: fp32-equivalent contraction at the bf16 matrix-core rate.
+//
+// Every fp32 operand is split EXACTLY into three bf16 numbers,
+//   x = x1 + x2 + x3,  x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)
+// (8 + 8 + 8 = 24 significand bits: nothing of the fp32 value is lost), and
+//   a*b ~= a1*b1 + (a1*b2 + a2*b1) + (a1*b3 + a2*b2 + a3*b1)
+// drops only the terms below 2^-24 |a||b| -- the size of one fp32 rounding.
+// Products of bf16 pairs are exact in fp32 and v_mfma_f32_32x32x16_bf16
+// accumulates in fp32, so the result carries fp32-class error (measured
+// against fp64 in tests/test_fused_gpu.py next to the exact-fp32 kernel) while
+// six bf16 MFMAs per 16-deep step cost 6 x 32 cycles against 8 x 64 for the
+// fp32-input MFMA: 2.67x less matrix-pipe time.  Weights are split once on the
+// host; activations stay fp32 in HBM and are split by the loader while it
+// stages them into LDS.
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int GB_LDS = 40;  // bf16 row stride: 32 + 8 pad (80 B: conflict-free ds_read_b128)
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// split 4 floats into three planes of 4 bf16 (packed as uint2 each)
+__device__ __forceinline__ void split3(const float4 v, uint2& h, uint2& m, uint2& l) {
+  h.x = cvt_pk_bf16(v.x, v.y);
+  h.y = cvt_pk_bf16(v.z, v.w);
+  const float r0 = v.x - __uint_as_float(h.x << 16), r1 = v.y - __uint_as_float(h.x & 0xFFFF0000u);
+  const float r2 = v.z - __uint_as_float(h.y << 16), r3 = v.w - __uint_as_float(h.y & 0xFFFF0000u);
+  m.x = cvt_pk_bf16(r0, r1);
+  m.y = cvt_pk_bf16(r2, r3);
+  const float s0 = r0 - __uint_as_float(m.x << 16), s1 = r1 - __uint_as_float(m.x & 0xFFFF0000u);
+  const float s2 = r2 - __uint_as_float(m.y << 16), s3 = r3 - __uint_as_float(m.y & 0xFFFF0000u);
+  l.x = cvt_pk_bf16(s0, s1);
+  l.y = cvt_pk_bf16(s2, s3);
+}
+
+template <int LOADER, int EPI>
+__global__ __launch_bounds__(GM_THREADS, 2) void mlp_gemm_bf16x3_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem16[];
+  uint16_t* As = smem16;                            // [3][BM][40]
+  uint16_t* Ws = smem16 + 3 * GM_BM * GB_LDS;       // [3][BN][40]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int g = blockIdx.y;
+  const int nb = p.mtiles * p.ntiles;
+  int id = blockIdx.x;
+  {
+    const int q = nb >> 3, r = nb & 7, xcd = id & 7;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int mt = id / p.ntiles;
+  const int nt = id - mt * p.ntiles;
+  const int p0 = mt * GM_BM;
+  const int n0 = nt * GM_BN;
+  const float* __restrict__ bg = p.bias + (size_t)g * p.b_gstride;
+  const uint16_t* __restrict__ W3g = p.W3 + (size_t)g * p.Cout * p.Kpad16;
+
+  ALoader<LOADER> ld;
+  ld.init(p, p0, g, t);
+  const int chunk = t & 7;    // A: 4-float chunk of the 32-wide K tile
+  const int srow = t >> 3;    // A: rows srow + 32 s
+  const int wchunk = t & 3;   // W: 8-bf16 chunk
+  const int wrow = t >> 2;    // W: rows wrow + 64 s
+  bool wok[2];
+  size_t woff[2];
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
-    const int n = n0 + wc * 64 + cb * 32 + li;
-    const bool nok = n < p.Cout;
-    const float bias = nok ? bg[n] : 0.f;
-    if constexpr (EPI == EPI_STORE) {
+  for (int s = 0; s < 2; ++s) {
+    const int n = n0 + wrow + 64 * s;
+    wok[s] = n < p.Cout;
+    woff[s] = (size_t)(wok[s] ? n : 0) * p.Kpad16 + wchunk * 8;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int a_off = (wr * 64 + li) * GB_LDS + 8 * lh;
+  const int b_off = (wc * 64 + li) * GB_LDS + 8 * lh;
+
+  float4 ra[4];
+  uint4 rw[3][2];
+  const int ntile_k = (p.Kpad16 + GM_BK - 1) / GM_BK;
+
+  auto gload = [&](int kt) {
+    const int k0 = kt * GM_BK + chunk * 4;
+    const bool live = k0 < p.Kpad16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ra[s] = live ? ld.load(p, s, k0, t) : f4zero();
+    const int kw = kt * GM_BK + wchunk * 8;
+    const bool wlive = kw < p.Kpad16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        rw[pl][s] = (wlive && wok[s])
+                        ? *reinterpret_cast<const uint4*>(W3g + pl * p.w3_plane + woff[s] + kt * GM_BK)
+                        : make_uint4(0u, 0u, 0u, 0u);
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint2 h, m, l;
+      split3(ra[s], h, m, l);
+      uint16_t* a = As + (srow + 32 * s) * GB_LDS + chunk * 4;
+      *reinterpret_cast<uint2*>(a) = h;
+      *reinterpret_cast<uint2*>(a + GM_BM * GB_LDS) = m;
+      *reinterpret_cast<uint2*>(a + 2 * GM_BM * GB_LDS) = l;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        *reinterpret_cast<uint4*>(Ws + pl * GM_BN * GB_LDS + (wrow + 64 * s) * GB_LDS + wchunk * 8) =
+            rw[pl][s];
+  };
+
+  gload(0);
+  for (int kt = 0; kt < ntile_k; ++kt) {
+    lstore();
+    __syncthreads();
+    if (kt + 1 < ntile_k) gload(kt + 1);
+    const int krem = p.Kpad16 - kt * GM_BK;
+    const int nks = krem >= GM_BK ? 2 : 1;
+    for (int ks = 0; ks < nks; ++ks) {
+      bf16x8 af[2][3], bf[2][3];
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = p0 + wr * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          float v = acc[rb][cb][r] + bias;
-          if (p.relu) v = fmaxf(v, 0.f);
-          if (nok && row < p.P)
-            p.out[(size_t)row * p.ldc + p.c_coff + g * p.c_gcol + n] = v;
+        for (int pl = 0; pl < 3; ++pl) {
+          af[rb][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
+              As + pl * GM_BM * GB_LDS + a_off + rb * 32 * GB_LDS + ks * 16));
+          bf[rb][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
+              Ws + pl * GM_BN * GB_LDS + b_off + rb * 32 * GB_LDS + ks * 16));
         }
-    } else if constexpr (EPI == EPI_MAX) {
-      // max over groups of K consecutive rows, K in {16, 32, 64}; then
-      // bias + ReLU (monotone, so max-then-activate == activate-then-max).
-      if (p.K == 64) {
-        float m = acc[0][cb][0];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[rb][cb][r]);
-        m = fmaxf(m, __shfl_xor(m, 32));
-        float v = m + bias;
-        if (p.relu) v = fmaxf(v, 0.f);
-        const int grp = (p0 + wr * 64) >> 6;
-        if (nok && lh == 0 && p0 + wr * 64 < p.P)
-          p.out[(size_t)grp * p.ldc + p.c_coff + n] = v;
-      } else if (p.K == 32) {
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-          float m = acc[rb][cb][0];
-#pragma unroll
-          for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rb][cb][r]);
-          m = fmaxf(m, __shfl_xor(m, 32));
-          float v = m + bias;
-          if (p.relu) v = fmaxf(v, 0.f);
-          const int row0 = p0 + wr * 64 + rb * 32;
-          if (nok && lh == 0 && row0 < p.P)
-            p.out[(size_t)(row0 >> 5) * p.ldc + p.c_coff + n] = v;
-        }
-      } else {  // K == 16: rows 0-15 are regs with (r>>2) in {0,1}, rows 16-31 {2,3}
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            float m = acc[rb][cb][8 * hh];
-#pragma unroll
-            for (int r = 1; r < 8; ++r) m = fmaxf(m, acc[rb][cb][8 * hh + r]);
-            m = fmaxf(m, __shfl_xor(m, 32));
-            float v = m + bias;
-            if (p.relu) v = fmaxf(v, 0.f);
-            const int row0 = p0 + wr * 64 + rb * 32 + 16 * hh;
-            if (nok && lh == 0 && row0 < p.P)
-              p.out[(size_t)(row0 >> 4) * p.ldc + p.c_coff + n] = v;
-          }
-      }
-    } else {  // EPI_CHANNEL_FIRST: out[b][c][n_pt], 4 consecutive points per store
-      int head = 0;
-#pragma unroll
-      for (int h2 = 1; h2 < 4; ++h2)
-        if (n >= p.cf_start[h2]) head = h2;
-      const int cl = n - p.cf_start[head];
-      const int ch = p.cf_start[head + 1] - p.cf_start[head];
-      float* base = p.cf_ptr[head];
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int row = p0 + wr * 64 + rb * 32 + 8 * r4 + 4 * lh;
-          if (nok && n < p.cf_start[4] && row < p.P) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float x = acc[rb][cb][4 * r4 + e] + bias;
-              if (p.relu) x = fmaxf(x, 0.f);
-              if (n >= p.cf_sigmoid_from) x = 1.0f / (1.0f + expf(-x));
-              v[e] = x;
-            }
-            const int b = row / p.cf_N;
-            const int pt = row - b * p.cf_N;
-            float* dst = base + ((size_t)b * ch + cl) * p.cf_N + pt;
-            if (pt + 3 < p.cf_N && (p.cf_N & 3) == 0) {
-              *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int row_e = row + e;
-                if (row_e < p.P) {
-                  const int be = row_e / p.cf_N;
-                  const int pe = row_e - be * p.cf_N;
-                  base[((size_t)be * ch + cl) * p.cf_N + pe] = v[e];
-                }
-              }
-            }
-          }
+        for (int cb = 0; cb < 2; ++cb) {
+          // smallest terms first
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][0], bf[cb][2], acc[rb][cb], 0, 0, 0);
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][1], bf[cb][1], acc[rb][cb], 0, 0, 0);
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][2], bf[cb][0], acc[rb][cb], 0, 0, 0);
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][0], bf[cb][1], acc[rb][cb], 0, 0, 0);
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][1], bf[cb][0], acc[rb][cb], 0, 0, 0);
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][0], bf[cb][0], acc[rb][cb], 0, 0, 0);
         }
     }
+    __syncthreads();
   }
+  gemm_epilogue<EPI>(p, acc, bg, g, p0, n0, wr, wc, li, lh);
+}
+
+template <int LOADER, int EPI>
+static int launch_gemm_bf16x3(const GemmParams& p, int groups, hipStream_t st) {
+  const size_t lds = sizeof(uint16_t) * 3 * (GM_BM + GM_BN) * GB_LDS;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&mlp_gemm_bf16x3_kernel<LOADER, EPI>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  const dim3 grid((unsigned)(p.mtiles * p.ntiles), (unsigned)groups);
+  hipLaunchKernelGGL((mlp_gemm_bf16x3_kernel<LOADER, EPI>), grid, dim3(GM_THREADS), lds, st, p);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
 }
 
 template <int LOADER, int EPI>
@@ -389,9 +582,15 @@ static int launch_gemm(const GemmParams& p, int groups, hipStream_t st) {
 
 extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   using namespace s4g;
-  if (!d || d->P < 0 || d->Cout <= 0 || d->Kpad <= 0 || (d->Kpad & 7) || d->groups <= 0 ||
-      !d->W || !d->bias)
+  if (!d || d->P < 0 || d->Cout <= 0 || d->groups <= 0 || !d->bias) return S4G_EINVAL;
+  const bool split = d->precision == S4G_GEMM_BF16X3;
+  if (split) {
+    if (!d->W_bf16x3 || d->Kpad16 <= 0 || (d->Kpad16 & 15)) return S4G_EINVAL;
+  } else if (d->precision == S4G_GEMM_FP32) {
+    if (!d->W || d->Kpad <= 0 || (d->Kpad & 7)) return S4G_EINVAL;
+  } else {
     return S4G_EINVAL;
+  }
   if (d->P == 0) return S4G_OK;
   GemmParams p;
   p.P = d->P; p.Cin = d->Cin; p.Kpad = d->Kpad; p.Cout = d->Cout; p.relu = d->relu;
@@ -406,6 +605,9 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   for (int i = 0; i < 4; ++i) p.cf_ptr[i] = d->cf_ptr[i];
   for (int i = 0; i < 5; ++i) p.cf_start[i] = d->cf_start[i];
   p.cf_sigmoid_from = d->cf_sigmoid_from; p.cf_N = d->cf_N;
+  p.W3 = (const uint16_t*)d->W_bf16x3;
+  p.Kpad16 = d->Kpad16;
+  p.w3_plane = (size_t)d->groups * (size_t)d->Cout * (size_t)d->Kpad16;
   p.mtiles = (d->P + GM_BM - 1) / GM_BM;
   p.ntiles = (d->Cout + GM_BN - 1) / GM_BN;
   hipStream_t st = (hipStream_t)stream;
@@ -436,7 +638,8 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
 
 #define S4G_GEMM_CASE(L, E)                                            \
   if (d->loader == L && d->epilogue == E)                              \
-    return launch_gemm<L, E>(p, d->groups, st);
+    return split ? launch_gemm_bf16x3<L, E>(p, d->groups, st)          \
+                 : launch_gemm<L, E>(p, d->groups, st);
   S4G_GEMM_CASE(LOAD_PLAIN, EPI_STORE)
   S4G_GEMM_CASE(LOAD_PLAIN, EPI_MAX)
   S4G_GEMM_CASE(LOAD_PLAIN, EPI_CHANNEL_FIRST)

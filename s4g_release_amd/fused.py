@@ -23,6 +23,7 @@ The geometry (FPS / ball query / 3-NN) uses exactly the kernels behind the
 operator API, so indices are bit-identical to `functions.py`.
 """
 import ctypes
+import os
 
 import torch
 
@@ -63,8 +64,20 @@ def _pad_k(w, mult=8):
     return out
 
 
+def split_bf16x3(w):
+    """Exact 3-way bf16 split of an fp32 tensor: w == w1 + w2 + w3 (24 significand
+    bits).  Returns a (3, ...) bfloat16 tensor (hi, mid, lo planes)."""
+    w1 = w.to(torch.bfloat16)
+    r1 = w - w1.float()
+    w2 = r1.to(torch.bfloat16)
+    r2 = r1 - w2.float()
+    w3 = r2.to(torch.bfloat16)
+    return torch.stack([w1, w2, w3], dim=0).contiguous()
+
+
 class _Layer:
-    """Folded weights of one launch: W (groups, Cout, Kpad), bias (groups, Cout)."""
+    """Folded weights of one launch: W (groups, Cout, Kpad), bias (groups, Cout),
+    plus the bf16x3 planes (3, groups, Cout, Kpad16) for the split-precision kernel."""
 
     def __init__(self, W, bias, cin, groups=1):
         self.W = W.contiguous()
@@ -73,12 +86,24 @@ class _Layer:
         self.cout = self.W.shape[-2]
         self.kpad = self.W.shape[-1]
         self.cin = cin
+        self.kpad16 = (self.kpad + 15) // 16 * 16
+        w16 = self.W.new_zeros(self.W.shape[:-1] + (self.kpad16,))
+        w16[..., :self.kpad] = self.W
+        self.W3 = split_bf16x3(w16)
 
 
 class FusedPointNet2:
     """Callable with the reference forward's signature: {"scene_points": (B,3,N)} -> dict."""
 
-    def __init__(self, net):
+    def __init__(self, net, precision=None):
+        """precision: "bf16x3" (default; fp32-equivalent split on the bf16 matrix
+        cores) or "fp32" (fp32-input MFMA, an exact fma chain).  S4G_GEMM_MODE
+        overrides the default."""
+        if precision is None:
+            precision = os.environ.get("S4G_GEMM_MODE", "bf16x3")
+        if precision not in ("bf16x3", "fp32"):
+            raise ValueError("precision must be 'bf16x3' or 'fp32'")
+        self.precision = precision
         p = next(net.parameters())
         if not p.is_cuda:
             raise RuntimeError("FusedPointNet2 needs the model on a HIP device (no CPU fallback)")
@@ -149,6 +174,8 @@ class FusedPointNet2:
         d.P, d.Cin, d.Kpad, d.Cout = P, layer.cin, layer.kpad, layer.cout
         d.W, d.bias = layer.W.data_ptr(), layer.bias.data_ptr()
         d.w_gstride, d.b_gstride = layer.cout * layer.kpad, layer.cout
+        d.precision = 1 if self.precision == "bf16x3" else 0
+        d.Kpad16, d.W_bf16x3 = layer.kpad16, layer.W3.data_ptr()
         for k, v in kw.items():
             if isinstance(v, torch.Tensor):
                 v = v.data_ptr()

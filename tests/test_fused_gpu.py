@@ -29,6 +29,19 @@ def _run(desc_kwargs, dev):
     torch.cuda.synchronize()
 
 
+def _w3(w):
+    """(Kpad16, bf16x3 planes) for a (.., Cout, K) fp32 weight."""
+    from s4g_release_amd.fused import split_bf16x3
+    k = w.shape[-1]
+    kp = (k + 15) // 16 * 16
+    w16 = w.new_zeros(w.shape[:-1] + (kp,))
+    w16[..., :k] = w
+    return kp, split_bf16x3(w16)
+
+
+PRECISIONS = [0, 1]   # S4G_GEMM_FP32, S4G_GEMM_BF16X3
+
+
 def _padk(w):
     k = w.shape[-1]
     kp = (k + 7) // 8 * 8
@@ -40,15 +53,18 @@ def _padk(w):
 @pytest.mark.parametrize("P,Cin,Cout,relu", [(128, 32, 128, True), (1000, 128, 256, True),
                                              (77, 260, 21, False), (4096, 1536, 1024, True),
                                              (300, 8, 130, True)])
-def test_gemm_plain_store(dev, P, Cin, Cout, relu):
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_gemm_plain_store(dev, P, Cin, Cout, relu, prec):
     g = torch.Generator(device="cpu").manual_seed(P + Cin)
     A = torch.randn(P, Cin, generator=g).to(dev)
     W = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).to(dev)
     b = torch.randn(Cout, generator=g).to(dev)
     out = torch.full((P, Cout), float("nan"), device=dev)
     Wp = _padk(W)
+    k16, w3 = _w3(W)
     _run(dict(loader=0, epilogue=0, groups=1, relu=int(relu), P=P, Cin=Cin, Kpad=Wp.shape[1],
-              Cout=Cout, W=Wp, bias=b, A=A, lda=Cin, out=out, ldc=Cout), dev)
+              Cout=Cout, W=Wp, bias=b, A=A, lda=Cin, out=out, ldc=Cout, precision=prec,
+              Kpad16=k16, W_bf16x3=w3), dev)
     ref = A.double() @ W.double().t() + b.double()
     if relu:
         ref = ref.clamp_min(0)
@@ -56,16 +72,18 @@ def test_gemm_plain_store(dev, P, Cin, Cout, relu):
     assert (out.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
-def test_gemm_grouped_column_slices(dev):
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_gemm_grouped_column_slices(dev, prec):
     g = torch.Generator(device="cpu").manual_seed(3)
     P, G, Cin, Cout = 700, 4, 64, 48
     A = torch.randn(P, G * Cin, generator=g).to(dev)
     W = (torch.randn(G, Cout, Cin, generator=g) / 8).to(dev)
     b = torch.randn(G, Cout, generator=g).to(dev)
     out = torch.full((P, G * Cout), float("nan"), device=dev)
+    k16, w3 = _w3(W)
     _run(dict(loader=0, epilogue=0, groups=G, relu=1, P=P, Cin=Cin, Kpad=Cin, Cout=Cout, W=W,
               bias=b, w_gstride=Cout * Cin, b_gstride=Cout, A=A, lda=G * Cin, a_gcol=Cin, out=out,
-              ldc=G * Cout, c_gcol=Cout), dev)
+              ldc=G * Cout, c_gcol=Cout, precision=prec, Kpad16=k16, W_bf16x3=w3), dev)
     for i in range(G):
         ref = (A[:, i * Cin:(i + 1) * Cin].double() @ W[i].double().t() + b[i].double()).clamp_min(0)
         assert (out[:, i * Cout:(i + 1) * Cout].double() - ref).abs().max().item() < 2e-5
@@ -73,7 +91,8 @@ def test_gemm_grouped_column_slices(dev):
 
 @pytest.mark.parametrize("K", [16, 32, 64])
 @pytest.mark.parametrize("Cf", [0, 64])
-def test_gemm_gather_max(dev, K, Cf):
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_gemm_gather_max(dev, K, Cf, prec):
     g = torch.Generator(device="cpu").manual_seed(K + Cf)
     B, N, M, Cout = 2, 500, 37, 96
     xyz = torch.randn(B, 3, N, generator=g).to(dev)
@@ -87,9 +106,10 @@ def test_gemm_gather_max(dev, K, Cf):
     Wp = _padk(W)
     P = B * M * K
     out = torch.full((B * M, Cout), float("nan"), device=dev)
+    k16, w3 = _w3(W)
     _run(dict(loader=1, epilogue=1, groups=1, relu=1, P=P, Cin=Cin, Kpad=Wp.shape[1], Cout=Cout,
               W=Wp, bias=b, gidx=gidx, feat=feat, xyz=xyz, ctr=ctr, Cf=Cf, N=N, M=M, K=K, out=out,
-              ldc=Cout), dev)
+              ldc=Cout, precision=prec, Kpad16=k16, W_bf16x3=w3), dev)
     rows = []
     for bi in range(B):
         gi = gidx[bi].long()                                        # (M,K)
@@ -104,7 +124,8 @@ def test_gemm_gather_max(dev, K, Cf):
     assert (out.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
-def test_gemm_interp_store(dev):
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_gemm_interp_store(dev, prec):
     g = torch.Generator(device="cpu").manual_seed(5)
     B, N1, N2, C2, C1, Cout = 2, 333, 50, 64, 32, 72
     sparse = torch.randn(B * N2, C2, generator=g).to(dev)
@@ -117,9 +138,10 @@ def test_gemm_interp_store(dev):
     for c1, dn in ((C1, dense), (0, None)):
         Wc = W[:, :C2 + c1].contiguous()
         out = torch.full((P, Cout), float("nan"), device=dev)
+        k16, w3 = _w3(Wc)
         _run(dict(loader=2, epilogue=0, groups=1, relu=1, P=P, Cin=C2 + c1, Kpad=C2 + c1, Cout=Cout,
                   W=Wc, bias=b, nidx=nidx, nw=nw, sparse=sparse, dense=dn, C2=C2, C1=c1, N2=N2,
-                  N1=N1, out=out, ldc=Cout), dev)
+                  N1=N1, out=out, ldc=Cout, precision=prec, Kpad16=k16, W_bf16x3=w3), dev)
         sp = sparse.view(B, N2, C2)
         interp = torch.stack([(sp[bi][nidx[bi].long()] * nw[bi][:, :, None]).sum(1)
                               for bi in range(B)]).view(P, C2)
@@ -128,7 +150,8 @@ def test_gemm_interp_store(dev):
         assert (out.double() - ref).abs().max().item() < 3e-5
 
 
-def test_gemm_channel_first_heads(dev):
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_gemm_channel_first_heads(dev, prec):
     g = torch.Generator(device="cpu").manual_seed(6)
     B, N, Cin = 2, 404, 64
     A = torch.randn(B * N, Cin, generator=g).to(dev)
@@ -137,9 +160,11 @@ def test_gemm_channel_first_heads(dev):
     b = torch.randn(sum(chans), generator=g).to(dev)
     outs = [torch.full((B, c, N), float("nan"), device=dev) for c in chans]
     starts = [0, 3, 12, 16, 21]
+    k16, w3 = _w3(W)
     _run(dict(loader=0, epilogue=2, groups=1, relu=0, P=B * N, Cin=Cin, Kpad=Cin, Cout=21, W=W,
               bias=b, A=A, lda=Cin, cf_ptr=(ctypes.c_void_p * 4)(*[o.data_ptr() for o in outs]),
-              cf_start=(ctypes.c_int32 * 5)(*starts), cf_sigmoid_from=16, cf_N=N), dev)
+              cf_start=(ctypes.c_int32 * 5)(*starts), cf_sigmoid_from=16, cf_N=N, precision=prec,
+              Kpad16=k16, W_bf16x3=w3), dev)
     ref = (A.double() @ W.double().t() + b.double()).view(B, N, 21).permute(0, 2, 1)
     for h, o in enumerate(outs):
         r = ref[:, starts[h]:starts[h + 1]]
@@ -148,9 +173,32 @@ def test_gemm_channel_first_heads(dev):
         assert (o.double() - r).abs().max().item() < 2e-5
 
 
-def _check_model(dev, g, net, pts, full):
+def test_bf16x3_error_is_fp32_class(dev):
+    """The split-precision kernel against fp64, next to the exact-fp32 MFMA kernel
+    on the same operands (K = 1024, |a|,|w| ~ 1): both must sit at fp32 round-off."""
+    g = torch.Generator(device="cpu").manual_seed(11)
+    P, Cin, Cout = 2048, 1024, 256
+    A = torch.randn(P, Cin, generator=g).to(dev)
+    W = torch.randn(Cout, Cin, generator=g).to(dev)
+    b = torch.zeros(Cout, device=dev)
+    ref = A.double() @ W.double().t()
+    scale = (A.double().abs() @ W.double().abs().t())       # sum |a||w|
+    errs = {}
+    k16, w3 = _w3(W)
+    for prec in PRECISIONS:
+        out = torch.empty(P, Cout, device=dev)
+        _run(dict(loader=0, epilogue=0, groups=1, relu=0, P=P, Cin=Cin, Kpad=Cin, Cout=Cout, W=W,
+                  bias=b, A=A, lda=Cin, out=out, ldc=Cout, precision=prec, Kpad16=k16,
+                  W_bf16x3=w3), dev)
+        errs[prec] = ((out.double() - ref).abs() / scale).max().item()
+    print("max |err| / sum|a||w|: fp32 MFMA %.3g, bf16x3 %.3g" % (errs[0], errs[1]))
+    assert errs[0] < 2e-7 and errs[1] < 2e-7          # fp32 unit round-off is 6e-8
+    assert errs[1] < 4 * errs[0] + 6e-8
+
+
+def _check_model(dev, g, net, pts, full, precision="bf16x3"):
     from s4g_release_amd.fused import FusedPointNet2
-    fused = FusedPointNet2(net.to(dev).eval())
+    fused = FusedPointNet2(net.to(dev).eval(), precision=precision)
     pred, inter = fused({"scene_points": torch.from_numpy(pts).to(dev)}, return_intermediates=True)
     for li in range(3):
         fps = inter["fps%d" % li].cpu().numpy().astype(np.int64)
@@ -170,24 +218,26 @@ def _check_model(dev, g, net, pts, full):
     return pred
 
 
-def test_fused_model_small_golden(dev):
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+def test_fused_model_small_golden(dev, precision):
     from s4g_release_amd.model import PointNet2
     g = GU.load("pn2_small.npz")
     net = PointNet2(**GU.small_config(g))
     net.load_state_dict(GU.small_state_dict(g), strict=True)
-    pred = _check_model(dev, g, net, g["points"], full=False)
+    pred = _check_model(dev, g, net, g["points"], full=False, precision=precision)
     for k in ("score", "frame_R", "frame_t", "movable_logits"):
         assert pred[k].is_contiguous()
         err = np.max(np.abs(pred[k].cpu().numpy() - g["out/" + k]))
         assert err < TOL, (k, err)
 
 
-def test_fused_model_full_golden(dev):
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+def test_fused_model_full_golden(dev, precision):
     from s4g_release_amd import synth
     g = GU.load("pn2_full.npz")
     net = GU.build_full_model(int(g["seed"]))
     pts = synth.make_batch([int(g["scene_id"])], 25600)
-    pred = _check_model(dev, g, net, pts, full=True)
+    pred = _check_model(dev, g, net, pts, full=True, precision=precision)
     pos = torch.from_numpy(g["positions"]).to(dev)
     for k in ("score", "frame_R", "frame_t", "movable_logits"):
         got = pred[k][:, :, pos].cpu().numpy()
