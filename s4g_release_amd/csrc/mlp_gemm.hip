@@ -163,10 +163,49 @@ struct ALoader {
 
 // Shared epilogue.  D layout of every 32x32 MFMA: col = lane & 31,
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+constexpr int GE_STRIDE = 68;  // floats per staged output row (64 + 4 pad)
+
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][2],
                                               const float* __restrict__ bg, int g, int p0,
-                                              int n0, int wr, int wc, int li, int lh) {
+                                              int n0, int wr, int wc, int li, int lh,
+                                              float* __restrict__ lds_stage) {
+  if constexpr (EPI == EPI_STORE) {
+    // Wide stores: each wave stages 32 rows x 64 channels of its tile in (now
+    // idle) LDS and writes them back as float4 -- 16 store instructions per
+    // wave instead of 64 dword stores (the tail is store-ISSUE bound).
+    const bool vec_ok = ((p.ldc | p.c_coff | p.c_gcol | p.Cout) & 3) == 0 &&
+                        ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
+    if (vec_ok) {
+      const int lane = li + 32 * lh;
+      float* st = lds_stage + (wr * 2 + wc) * 32 * GE_STRIDE;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          const int n = n0 + wc * 64 + cb * 32 + li;
+          const float bias = n < p.Cout ? bg[n] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[rb][cb][r] + bias;
+            if (p.relu) v = fmaxf(v, 0.f);
+            st[((r & 3) + 8 * (r >> 2) + 4 * lh) * GE_STRIDE + cb * 32 + li] = v;
+          }
+        }
+        const int c4 = (lane & 15) * 4;
+        const int col = n0 + wc * 64 + c4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int rl = (lane >> 4) + 4 * i;
+          const float4 v = *reinterpret_cast<const float4*>(st + rl * GE_STRIDE + c4);
+          const int row = p0 + wr * 64 + rb * 32 + rl;
+          if (row < p.P && col < p.Cout)
+            *reinterpret_cast<float4*>(p.out + (size_t)row * p.ldc + p.c_coff + g * p.c_gcol + col) = v;
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int n = n0 + wc * 64 + cb * 32 + li;
@@ -377,7 +416,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void mlp_gemm_kernel(const GemmParam
     __syncthreads();
   }
 
-  gemm_epilogue<EPI>(p, acc, bg, g, p0, n0, wr, wc, li, lh);
+  gemm_epilogue<EPI>(p, acc, bg, g, p0, n0, wr, wc, li, lh, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -420,11 +459,28 @@ __device__ __forceinline__ void split3(const float4 v, uint2& h, uint2& m, uint2
   l.y = cvt_pk_bf16(s2, s3);
 }
 
+// A stays fp32 in LDS (plain staging copy, no VALU in the synchronous part);
+// each wave splits its own A fragments in registers right before use, in the
+// issue shadow of the MFMAs.  W arrives pre-split (host).  One LDS stage of
+// 49 KB + ~168 VGPRs => three workgroups (12 waves) per CU, so while one
+// workgroup stages or waits at its barrier two others keep the matrix pipe fed.
+constexpr int GB_ALDS = 36;  // fp32 A row stride (floats): 32 + 4 pad
+
+__device__ __forceinline__ void split3_frag(const float4 lo, const float4 hi, bf16x8& h,
+                                            bf16x8& m, bf16x8& l) {
+  uint2 h0, m0, l0, h1, m1, l1;
+  split3(lo, h0, m0, l0);
+  split3(hi, h1, m1, l1);
+  h = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+  m = __builtin_bit_cast(bf16x8, make_uint4(m0.x, m0.y, m1.x, m1.y));
+  l = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+}
+
 template <int LOADER, int EPI>
 __global__ __launch_bounds__(GM_THREADS, 2) void mlp_gemm_bf16x3_kernel(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t smem16[];
-  uint16_t* As = smem16;                            // [3][BM][40]
-  uint16_t* Ws = smem16 + 3 * GM_BM * GB_LDS;       // [3][BN][40]
+  extern __shared__ __attribute__((aligned(16))) float smemf[];
+  float* Af = smemf;                                                     // [BM][36] fp32
+  uint16_t* Ws = reinterpret_cast<uint16_t*>(smemf + GM_BM * GB_ALDS);   // [3][BN][40] bf16
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -468,7 +524,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void mlp_gemm_bf16x3_kernel(const Ge
 
   const int wr = wave >> 1, wc = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
-  const int a_off = (wr * 64 + li) * GB_LDS + 8 * lh;
+  const int a_off = (wr * 64 + li) * GB_ALDS + 8 * lh;
   const int b_off = (wc * 64 + li) * GB_LDS + 8 * lh;
 
   float4 ra[4];
@@ -492,14 +548,8 @@ __global__ __launch_bounds__(GM_THREADS, 2) void mlp_gemm_bf16x3_kernel(const Ge
   };
   auto lstore = [&]() {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      uint2 h, m, l;
-      split3(ra[s], h, m, l);
-      uint16_t* a = As + (srow + 32 * s) * GB_LDS + chunk * 4;
-      *reinterpret_cast<uint2*>(a) = h;
-      *reinterpret_cast<uint2*>(a + GM_BM * GB_LDS) = m;
-      *reinterpret_cast<uint2*>(a + 2 * GM_BM * GB_LDS) = l;
-    }
+    for (int s = 0; s < 4; ++s)
+      *reinterpret_cast<float4*>(Af + (srow + 32 * s) * GB_ALDS + chunk * 4) = ra[s];
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -516,37 +566,41 @@ __global__ __launch_bounds__(GM_THREADS, 2) void mlp_gemm_bf16x3_kernel(const Ge
     const int krem = p.Kpad16 - kt * GM_BK;
     const int nks = krem >= GM_BK ? 2 : 1;
     for (int ks = 0; ks < nks; ++ks) {
-      bf16x8 af[2][3], bf[2][3];
+      bf16x8 af[2][3];
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
+      for (int rb = 0; rb < 2; ++rb) {
+        const float* ap = Af + a_off + rb * 32 * GB_ALDS + ks * 16;
+        split3_frag(*reinterpret_cast<const float4*>(ap), *reinterpret_cast<const float4*>(ap + 4),
+                    af[rb][0], af[rb][1], af[rb][2]);
+      }
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          af[rb][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
-              As + pl * GM_BM * GB_LDS + a_off + rb * 32 * GB_LDS + ks * 16));
-          bf[rb][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
-              Ws + pl * GM_BN * GB_LDS + b_off + rb * 32 * GB_LDS + ks * 16));
-        }
+      for (int cb = 0; cb < 2; ++cb) {
+        bf16x8 bf[3];
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-          // smallest terms first
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][0], bf[cb][2], acc[rb][cb], 0, 0, 0);
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][1], bf[cb][1], acc[rb][cb], 0, 0, 0);
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][2], bf[cb][0], acc[rb][cb], 0, 0, 0);
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][0], bf[cb][1], acc[rb][cb], 0, 0, 0);
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][1], bf[cb][0], acc[rb][cb], 0, 0, 0);
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][0], bf[cb][0], acc[rb][cb], 0, 0, 0);
-        }
+        for (int pl = 0; pl < 3; ++pl)
+          bf[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
+              Ws + pl * GM_BN * GB_LDS + b_off + cb * 32 * GB_LDS + ks * 16));
+        // six products per tile, smallest terms first, the two row blocks interleaved
+#define S4G_X3_TERM(PA, PB)                                                              \
+  acc[0][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][PA], bf[PB], acc[0][cb], 0, 0, 0); \
+  acc[1][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][PA], bf[PB], acc[1][cb], 0, 0, 0);
+        S4G_X3_TERM(0, 2)
+        S4G_X3_TERM(1, 1)
+        S4G_X3_TERM(2, 0)
+        S4G_X3_TERM(0, 1)
+        S4G_X3_TERM(1, 0)
+        S4G_X3_TERM(0, 0)
+#undef S4G_X3_TERM
+      }
     }
     __syncthreads();
   }
-  gemm_epilogue<EPI>(p, acc, bg, g, p0, n0, wr, wc, li, lh);
+  gemm_epilogue<EPI>(p, acc, bg, g, p0, n0, wr, wc, li, lh, smemf);
 }
 
 template <int LOADER, int EPI>
 static int launch_gemm_bf16x3(const GemmParams& p, int groups, hipStream_t st) {
-  const size_t lds = sizeof(uint16_t) * 3 * (GM_BM + GM_BN) * GB_LDS;
+  const size_t lds = sizeof(float) * GM_BM * GB_ALDS + sizeof(uint16_t) * 3 * GM_BN * GB_LDS;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(
