@@ -195,6 +195,16 @@ def main():
                 "bytes_per_launch_pair": int(nbytes), "ms_ball_query": round(bq[1], 5),
                 "ms_group_points": round(gp[1], 5), "scenes_per_launch": B,
                 "note": "algorithmic bytes = B*(12N+12M+8MK+8M) + B*(4CN+8MK+4CMK), C=3"}
+    # HBM-side traffic of the same pair comes from rocprofv3 PMC passes (cannot be
+    # collected from inside this process); the committed summary is attached.
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            tr = json.load(f).get("ball_query+group_points[N=%d,M=%d,K=%d,B=%d]" % (N, M, K, B))
+        if tr:
+            roofline["traffic"] = tr["traffic_bytes"]
+            roofline["traffic_source"] = tr["source"]
+    except (OSError, ValueError):
+        pass
     fq = probe.get("query_group[N=%d,M=%d,K=%d]" % (N, M, K))
     if fq:   # the same pair as ONE pass (s4g_query_group_f32), same algorithmic bytes
         roofline["fused_pair_ms"] = round(fq[1], 5)
