@@ -31,6 +31,8 @@
 // the current one).  LDS rows are padded to 36 floats: conflict-free
 // ds_read_b128 for the 16-lane groups of gfx950.  Workgroup ids are remapped
 // so that the N-tiles sharing an A panel run back to back on one XCD (L2).
+#include <stdlib.h>
+
 #include "s4g_common.h"
 
 namespace s4g {
@@ -84,22 +86,22 @@ struct GemmParams {
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-template <int LOADER>
+template <int LOADER, int RPT = 4, int RS = 32>
 struct ALoader {
-  // per-thread: 4 rows (t>>3)+32s, one 4-float chunk (t&7)
-  const float* src0[4];  // PLAIN: row base; GATHER: feat row base; INTERP: unused
-  bool ok[4];
+  // per-thread: RPT rows (t>>3)+RS*s, one 4-float chunk (t&7)
+  const float* src0[RPT];  // PLAIN: row base; GATHER: feat row base; INTERP: unused
+  bool ok[RPT];
   // GATHER tail
-  float rel[4][3];
+  float rel[RPT][3];
   // INTERP
-  int i3[4][3];
-  float w3[4][3];
-  size_t drow[4];
+  int i3[RPT][3];
+  float w3[RPT][3];
+  size_t drow[RPT];
 
   __device__ __forceinline__ void init(const GemmParams& p, int p0, int g, int t) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int r = (t >> 3) + 32 * s;
+    for (int s = 0; s < RPT; ++s) {
+      const int r = (t >> 3) + RS * s;
       const int pos = p0 + r;
       ok[s] = pos < p.P;
       const int pp = ok[s] ? pos : 0;
@@ -163,13 +165,16 @@ struct ALoader {
 
 // Shared epilogue.  D layout of every 32x32 MFMA: col = lane & 31,
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-constexpr int GE_STRIDE = 68;  // floats per staged output row (64 + 4 pad)
 
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][2],
+// NCB = 32-wide column blocks per wave (2: four waves as 2x2; 1: eight waves as 2x4).
+// `wave` indexes the staging slab, wr / wc the 64-row half and the column strip.
+template <int EPI, int NCB>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][NCB],
                                               const float* __restrict__ bg, int g, int p0,
-                                              int n0, int wr, int wc, int li, int lh,
+                                              int n0, int wave, int wr, int wc, int li, int lh,
                                               float* __restrict__ lds_stage) {
+  constexpr int WCOLS = 32 * NCB;        // columns per wave
+  constexpr int GE_STRIDE = WCOLS + 4;   // floats per staged output row
   if constexpr (EPI == EPI_STORE) {
     // Wide stores: each wave stages 32 rows x 64 channels of its tile in (now
     // idle) LDS and writes them back as float4 -- 16 store instructions per
@@ -178,12 +183,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                         ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
     if (vec_ok) {
       const int lane = li + 32 * lh;
-      float* st = lds_stage + (wr * 2 + wc) * 32 * GE_STRIDE;
+      float* st = lds_stage + wave * 32 * GE_STRIDE;
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-          const int n = n0 + wc * 64 + cb * 32 + li;
+        for (int cb = 0; cb < NCB; ++cb) {
+          const int n = n0 + wc * WCOLS + cb * 32 + li;
           const float bias = n < p.Cout ? bg[n] : 0.f;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -192,11 +197,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             st[((r & 3) + 8 * (r >> 2) + 4 * lh) * GE_STRIDE + cb * 32 + li] = v;
           }
         }
-        const int c4 = (lane & 15) * 4;
-        const int col = n0 + wc * 64 + c4;
+        constexpr int LPR = WCOLS / 4;   // lanes per staged row
+        const int c4 = (lane % LPR) * 4;
+        const int col = n0 + wc * WCOLS + c4;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int rl = (lane >> 4) + 4 * i;
+        for (int i = 0; i < 32 * LPR / 64; ++i) {
+          const int rl = lane / LPR + (64 / LPR) * i;
           const float4 v = *reinterpret_cast<const float4*>(st + rl * GE_STRIDE + c4);
           const int row = p0 + wr * 64 + rb * 32 + rl;
           if (row < p.P && col < p.Cout)
@@ -207,8 +213,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     }
   }
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
-    const int n = n0 + wc * 64 + cb * 32 + li;
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int n = n0 + wc * WCOLS + cb * 32 + li;
     const bool nok = n < p.Cout;
     const float bias = nok ? bg[n] : 0.f;
     if constexpr (EPI == EPI_STORE) {
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void mlp_gemm_kernel(const GemmParam
     __syncthreads();
   }
 
-  gemm_epilogue<EPI>(p, acc, bg, g, p0, n0, wr, wc, li, lh, smem);
+  gemm_epilogue<EPI, 2>(p, acc, bg, g, p0, n0, wave, wr, wc, li, lh, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -437,7 +443,6 @@ __global__ __launch_bounds__(GM_THREADS, 2) void mlp_gemm_kernel(const GemmParam
 // ---------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int GB_LDS = 40;  // bf16 row stride: 32 + 8 pad (80 B: conflict-free ds_read_b128)
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   uint32_t r;
@@ -464,7 +469,6 @@ __device__ __forceinline__ void split3(const float4 v, uint2& h, uint2& m, uint2
 // issue shadow of the MFMAs.  W arrives pre-split (host).  One LDS stage of
 // 49 KB + ~168 VGPRs => three workgroups (12 waves) per CU, so while one
 // workgroup stages or waits at its barrier two others keep the matrix pipe fed.
-constexpr int GB_ALDS = 36;  // fp32 A row stride (floats): 32 + 4 pad
 
 __device__ __forceinline__ void split3_frag(const float4 lo, const float4 hi, bf16x8& h,
                                             bf16x8& m, bf16x8& l) {
@@ -476,11 +480,21 @@ __device__ __forceinline__ void split3_frag(const float4 lo, const float4 hi, bf
   l = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
 }
 
-template <int LOADER, int EPI>
-__global__ __launch_bounds__(GM_THREADS, 2) void mlp_gemm_bf16x3_kernel(const GemmParams p) {
+template <int LOADER, int EPI, int NS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, NS == 1 ? WAVES / 2 : 1) void mlp_gemm_bf16x3_kernel(const GemmParams p) {
+  constexpr int THREADS = 64 * WAVES;
+  constexpr int WC = WAVES / 2;          // column strips (wave grid is 2 x WC)
+  constexpr int NCB = 4 / WC;            // 32-wide column blocks per wave
+  constexpr int RPT = 1024 / THREADS;    // A rows per thread
+  constexpr int RS = THREADS / 8;        // A row step between them
+  constexpr int WPT = 512 / THREADS;     // W rows per thread (per plane)
+  constexpr int WRS = THREADS / 4;
+  constexpr int BK = 32 * NS;
+  constexpr int ASTR = BK + 4;   // fp32 A row stride
+  constexpr int WSTR = BK + 8;   // bf16 W row stride
   extern __shared__ __attribute__((aligned(16))) float smemf[];
   float* Af = smemf;                                                     // [BM][36] fp32
-  uint16_t* Ws = reinterpret_cast<uint16_t*>(smemf + GM_BM * GB_ALDS);   // [3][BN][40] bf16
+  uint16_t* Ws = reinterpret_cast<uint16_t*>(smemf + GM_BM * ASTR);   // [3][BN][WSTR] bf16
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -499,63 +513,69 @@ __global__ __launch_bounds__(GM_THREADS, 2) void mlp_gemm_bf16x3_kernel(const Ge
   const float* __restrict__ bg = p.bias + (size_t)g * p.b_gstride;
   const uint16_t* __restrict__ W3g = p.W3 + (size_t)g * p.Cout * p.Kpad16;
 
-  ALoader<LOADER> ld;
+  ALoader<LOADER, RPT, RS> ld;
   ld.init(p, p0, g, t);
   const int chunk = t & 7;    // A: 4-float chunk of the 32-wide K tile
-  const int srow = t >> 3;    // A: rows srow + 32 s
+  const int srow = t >> 3;    // A: rows srow + RS s
   const int wchunk = t & 3;   // W: 8-bf16 chunk
-  const int wrow = t >> 2;    // W: rows wrow + 64 s
-  bool wok[2];
-  size_t woff[2];
+  const int wrow = t >> 2;    // W: rows wrow + WRS s
+  bool wok[WPT];
+  size_t woff[WPT];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int n = n0 + wrow + 64 * s;
+  for (int s = 0; s < WPT; ++s) {
+    const int n = n0 + wrow + WRS * s;
     wok[s] = n < p.Cout;
     woff[s] = (size_t)(wok[s] ? n : 0) * p.Kpad16 + wchunk * 8;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NCB];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NCB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WC, wc = wave % WC;
   const int li = lane & 31, lh = lane >> 5;
-  const int a_off = (wr * 64 + li) * GB_ALDS + 8 * lh;
-  const int b_off = (wc * 64 + li) * GB_LDS + 8 * lh;
+  const int a_off = (wr * 64 + li) * ASTR + 8 * lh;
+  const int b_off = (wc * 32 * NCB + li) * WSTR + 8 * lh;
 
-  float4 ra[4];
-  uint4 rw[3][2];
-  const int ntile_k = (p.Kpad16 + GM_BK - 1) / GM_BK;
+  float4 ra[NS][RPT];
+  uint4 rw[NS][3][WPT];
+  const int ntile_k = (p.Kpad16 + BK - 1) / BK;
 
   auto gload = [&](int kt) {
-    const int k0 = kt * GM_BK + chunk * 4;
-    const bool live = k0 < p.Kpad16;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) ra[s] = live ? ld.load(p, s, k0, t) : f4zero();
-    const int kw = kt * GM_BK + wchunk * 8;
-    const bool wlive = kw < p.Kpad16;
+    for (int u = 0; u < NS; ++u) {
+      const int k0 = kt * BK + u * 32 + chunk * 4;
+      const bool live = k0 < p.Kpad16;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+      for (int s = 0; s < RPT; ++s) ra[u][s] = live ? ld.load(p, s, k0, t) : f4zero();
+      const int kw = kt * BK + u * 32 + wchunk * 8;
+      const bool wlive = kw < p.Kpad16;
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-        rw[pl][s] = (wlive && wok[s])
-                        ? *reinterpret_cast<const uint4*>(W3g + pl * p.w3_plane + woff[s] + kt * GM_BK)
-                        : make_uint4(0u, 0u, 0u, 0u);
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int s = 0; s < WPT; ++s)
+          rw[u][pl][s] = (wlive && wok[s])
+                             ? *reinterpret_cast<const uint4*>(W3g + pl * p.w3_plane + woff[s] + kt * BK + u * 32)
+                             : make_uint4(0u, 0u, 0u, 0u);
+    }
   };
   auto lstore = [&]() {
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-      *reinterpret_cast<float4*>(Af + (srow + 32 * s) * GB_ALDS + chunk * 4) = ra[s];
+    for (int u = 0; u < NS; ++u) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+      for (int s = 0; s < RPT; ++s)
+        *reinterpret_cast<float4*>(Af + (srow + RS * s) * ASTR + u * 32 + chunk * 4) = ra[u][s];
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-        *reinterpret_cast<uint4*>(Ws + pl * GM_BN * GB_LDS + (wrow + 64 * s) * GB_LDS + wchunk * 8) =
-            rw[pl][s];
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int s = 0; s < WPT; ++s)
+          *reinterpret_cast<uint4*>(Ws + pl * GM_BN * WSTR + (wrow + WRS * s) * WSTR + u * 32 + wchunk * 8) =
+              rw[u][pl][s];
+    }
   };
 
   gload(0);
@@ -563,23 +583,23 @@ __global__ __launch_bounds__(GM_THREADS, 2) void mlp_gemm_bf16x3_kernel(const Ge
     lstore();
     __syncthreads();
     if (kt + 1 < ntile_k) gload(kt + 1);
-    const int krem = p.Kpad16 - kt * GM_BK;
-    const int nks = krem >= GM_BK ? 2 : 1;
+    const int krem = p.Kpad16 - kt * BK;
+    const int nks = krem >= BK ? 2 * NS : (krem + 15) / 16;
     for (int ks = 0; ks < nks; ++ks) {
       bf16x8 af[2][3];
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
-        const float* ap = Af + a_off + rb * 32 * GB_ALDS + ks * 16;
+        const float* ap = Af + a_off + rb * 32 * ASTR + ks * 16;
         split3_frag(*reinterpret_cast<const float4*>(ap), *reinterpret_cast<const float4*>(ap + 4),
                     af[rb][0], af[rb][1], af[rb][2]);
       }
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
+      for (int cb = 0; cb < NCB; ++cb) {
         bf16x8 bf[3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
           bf[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
-              Ws + pl * GM_BN * GB_LDS + b_off + cb * 32 * GB_LDS + ks * 16));
+              Ws + pl * GM_BN * WSTR + b_off + cb * 32 * WSTR + ks * 16));
         // six products per tile, smallest terms first, the two row blocks interleaved
 #define S4G_X3_TERM(PA, PB)                                                              \
   acc[0][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][PA], bf[PB], acc[0][cb], 0, 0, 0); \
@@ -595,24 +615,36 @@ __global__ __launch_bounds__(GM_THREADS, 2) void mlp_gemm_bf16x3_kernel(const Ge
     }
     __syncthreads();
   }
-  gemm_epilogue<EPI>(p, acc, bg, g, p0, n0, wr, wc, li, lh, smemf);
+  gemm_epilogue<EPI, NCB>(p, acc, bg, g, p0, n0, wave, wr, wc, li, lh, smemf);
 }
 
-template <int LOADER, int EPI>
-static int launch_gemm_bf16x3(const GemmParams& p, int groups, hipStream_t st) {
-  const size_t lds = sizeof(float) * GM_BM * GB_ALDS + sizeof(uint16_t) * 3 * GM_BN * GB_LDS;
+template <int LOADER, int EPI, int NS, int WAVES>
+static int launch_gemm_bf16x3_cfg(const GemmParams& p, int groups, hipStream_t st) {
+  constexpr int BK = 32 * NS;
+  size_t lds = sizeof(float) * GM_BM * (BK + 4) + sizeof(uint16_t) * 3 * GM_BN * (BK + 8);
+  const size_t epi = sizeof(float) * 4 * 32 * 68;   // staged epilogue stores (either layout)
+  if (lds < epi) lds = epi;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&mlp_gemm_bf16x3_kernel<LOADER, EPI>),
+        reinterpret_cast<const void*>(&mlp_gemm_bf16x3_kernel<LOADER, EPI, NS, WAVES>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
   const dim3 grid((unsigned)(p.mtiles * p.ntiles), (unsigned)groups);
-  hipLaunchKernelGGL((mlp_gemm_bf16x3_kernel<LOADER, EPI>), grid, dim3(GM_THREADS), lds, st, p);
+  hipLaunchKernelGGL((mlp_gemm_bf16x3_kernel<LOADER, EPI, NS, WAVES>), grid, dim3(64 * WAVES), lds,
+                     st, p);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
+}
+
+template <int LOADER, int EPI>
+static int launch_gemm_bf16x3(const GemmParams& p, int groups, hipStream_t st) {
+  // Measured on MI355X (tools/bench_gemm.py): 64-deep K tiles at one workgroup
+  // per CU lose 20 %, eight-wave workgroups at 4 waves/SIMD change nothing
+  // (-3 %); 128x128x32, four waves, two workgroups per CU is what ships.
+  return launch_gemm_bf16x3_cfg<LOADER, EPI, 1, 4>(p, groups, st);
 }
 
 template <int LOADER, int EPI>
