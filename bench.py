@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3      # fp32-in MFMA = fp32 vector peak
+BF16_MFMA_PEAK_TF = 2500.0     # dense bf16 MFMA (no sparsity)
 GFLOP_PER_SCENE = 203.48       # SURVEY.md Appendix B (BN folded, 2*MAC)
 
 
@@ -212,12 +213,25 @@ def main():
         roofline["fused_pair_frac"] = round(fq[2] / fq[1] / 1e6 / HBM_PEAK_GBS, 4)
     if gemm_ms > 0:
         dense_tf = gemm_flops / gemm_ms / 1e9
-        roofline_dense = {"kernel": "mlp_gemm_kernel (fp32 MFMA), all launches of one step",
-                          "bound": "mfma", "achieved": round(dense_tf, 2),
-                          "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                          "frac": round(dense_tf / FP32_MFMA_PEAK_TF, 4),
-                          "GFLOP_per_step": round(gemm_flops / 1e9, 1),
-                          "ms_per_step": round(gemm_ms, 3)}
+        if getattr(runner, "precision", "fp32") == "bf16x3":
+            # six bf16 MFMA products per fp32-equivalent product: price the flops the
+            # matrix cores actually execute against the dense bf16 peak.
+            roofline_dense = {"kernel": "mlp_gemm_bf16x3_kernel (v_mfma_f32_32x32x16_bf16, 6 products "
+                                        "per fp32-equivalent product), all launches of one step",
+                              "bound": "mfma", "achieved": round(6 * dense_tf, 1),
+                              "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                              "frac": round(6 * dense_tf / BF16_MFMA_PEAK_TF, 4),
+                              "fp32_equivalent_TFLOPs": round(dense_tf, 2),
+                              "fp32_equivalent_vs_fp32_mfma_peak": round(dense_tf / FP32_MFMA_PEAK_TF, 4),
+                              "GFLOP_per_step_fp32_equivalent": round(gemm_flops / 1e9, 1),
+                              "ms_per_step": round(gemm_ms, 3)}
+        else:
+            roofline_dense = {"kernel": "mlp_gemm_kernel (v_mfma_f32_32x32x2_f32), all launches of one step",
+                              "bound": "mfma", "achieved": round(dense_tf, 2),
+                              "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                              "frac": round(dense_tf / FP32_MFMA_PEAK_TF, 4),
+                              "GFLOP_per_step": round(gemm_flops / 1e9, 1),
+                              "ms_per_step": round(gemm_ms, 3)}
     else:
         dense_tf = GFLOP_PER_SCENE * value / world / 1e3
         roofline_dense = {"kernel": "whole forward (library GEMMs), dense flops / wall time",
@@ -250,7 +264,10 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "S4G PN2_CLS forward (3 SA + 3 FP + 4 heads), %d scenes/GPU/step, "
-                               "%d-pt %s clouds, fp32, impl=%s%s" % (B, args.points, args.variant, impl,
+                               "%d-pt %s clouds, fp32 (%s), impl=%s%s" % (B, args.points, args.variant,
+                                                                      "contraction as exact 3xbf16 split, fp32 accumulate"
+                                                                      if getattr(runner, "precision", "") == "bf16x3"
+                                                                      else "fp32 MFMA / library GEMM", impl,
                                                                     ", 1 batch in flight" if pipelined else ""),
                    "scenes_per_gpu": B, "num_points": args.points, "global_batch": world * B,
                    "parallelism": "scenes sharded over %d GPU(s), all-gather of 21 ch/point" % world},
