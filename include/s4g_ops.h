@@ -145,6 +145,9 @@ int s4g_interp_weights_f32(const float *d2_bn3, int64_t B, int64_t N1,
  *                                (K order [feat, xyz]; W permuted to match)
  *         S4G_GEMM_LOAD_INTERP  A row p = [ sum_k nw[p,k]*sparse[b*N2+nidx[p,k]] |
  *                                dense[p][0..C1) ]
+ *         S4G_GEMM_LOAD_GATHER_MLP1  first xyz-only SA layer folded into the loader:
+ *                                A row p = relu(W1 . (xyz[b,:,gidx[p]] - ctr[b,:,m]) + b1),
+ *                                mlp1_w = Cin x (wx, wy, wz, bias) fp32
  * epilogue S4G_GEMM_EPI_STORE   out[p*ldc + c_coff + g*c_gcol + n]
  *          S4G_GEMM_EPI_MAX     out[(p/K)*ldc + c_coff + n] = max over the K
  *                               consecutive rows of a group (K in 16,32,64)
@@ -157,11 +160,13 @@ int s4g_interp_weights_f32(const float *d2_bn3, int64_t B, int64_t N1,
 #define S4G_GEMM_LOAD_PLAIN 0
 #define S4G_GEMM_LOAD_GATHER 1
 #define S4G_GEMM_LOAD_INTERP 2
+#define S4G_GEMM_LOAD_GATHER_MLP1 3
 #define S4G_GEMM_EPI_STORE 0
 #define S4G_GEMM_EPI_MAX 1
 #define S4G_GEMM_EPI_CHANNEL_FIRST 2
 #define S4G_GEMM_FP32 0
 #define S4G_GEMM_BF16X3 1
+#define S4G_GEMM_BF16 2 /* reduced precision: one bf16 product, fp32 accumulate */
 
 typedef struct s4g_gemm_desc {
   int32_t loader, epilogue, groups, relu;
@@ -193,10 +198,13 @@ typedef struct s4g_gemm_desc {
   /* arithmetic: S4G_GEMM_FP32 = v_mfma_f32_32x32x2_f32 on W (exact fp32 fma
    * chain); S4G_GEMM_BF16X3 = each fp32 operand split exactly into three bf16
    * numbers, six v_mfma_f32_32x32x16_bf16 per step, fp32 accumulate (drops
-   * only terms below 2^-24 |a||b|).  W_bf16x3 is [3][groups][Cout][Kpad16]
+   * only terms below 2^-24 |a||b|); S4G_GEMM_BF16 = the hi planes only (plain
+   * bf16 inputs, fp32 accumulate: reduced precision, NOT within the 1e-4 bar,
+   * for the bf16 roofline configuration).  W_bf16x3 is [3][groups][Cout][Kpad16]
    * bf16 (hi, mid, lo planes of W), Kpad16 % 16 == 0. */
   int32_t precision, Kpad16;
   const void *W_bf16x3;
+  const float *mlp1_w; /* GATHER_MLP1: (Cin, 4) = wx, wy, wz, bias */
 } s4g_gemm_desc_t;
 
 int s4g_mlp_gemm_f32(const s4g_gemm_desc_t *desc, s4g_stream_t stream);

@@ -36,7 +36,7 @@ class GemmDesc(ctypes.Structure):
         ("C2", _i32), ("C1", _i32), ("N2", _i32), ("N1", _i32),
         ("out", _vp), ("ldc", _i32), ("c_coff", _i32), ("c_gcol", _i32),
         ("cf_ptr", _vp * 4), ("cf_start", _i32 * 5), ("cf_sigmoid_from", _i32), ("cf_N", _i32),
-        ("precision", _i32), ("Kpad16", _i32), ("W_bf16x3", _vp),
+        ("precision", _i32), ("Kpad16", _i32), ("W_bf16x3", _vp), ("mlp1_w", _vp),
     ]
 
 

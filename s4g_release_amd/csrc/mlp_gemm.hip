@@ -45,7 +45,7 @@ constexpr int GM_BK = 32;
 constexpr int GM_LDS = 36;  // padded row stride (floats)
 constexpr int GM_THREADS = 256;
 
-enum { LOAD_PLAIN = 0, LOAD_GATHER = 1, LOAD_INTERP = 2 };
+enum { LOAD_PLAIN = 0, LOAD_GATHER = 1, LOAD_INTERP = 2, LOAD_GATHER_MLP1 = 3 };
 enum { EPI_STORE = 0, EPI_MAX = 1, EPI_CHANNEL_FIRST = 2 };
 
 struct GemmParams {
@@ -62,6 +62,9 @@ struct GemmParams {
   const float* xyz;
   const float* ctr;
   int Cf, N, M, K;
+  // GATHER_MLP1: first SA layer (xyz only) evaluated in the loader:
+  // A[p][k] = relu(w1[k].x*rx + w1[k].y*ry + w1[k].z*rz + w1[k].w), k < Cin
+  const float4* mlp1;
   // INTERP: sparse (B*N2, C2), dense (B*N1, C1), nidx/nw (B*N1, 3)
   const int* nidx;
   const float* nw;
@@ -81,6 +84,7 @@ struct GemmParams {
   // bf16x3 path: W split into three bf16 planes [3][groups][Cout][Kpad16]
   const uint16_t* W3;
   int Kpad16;
+  int bf16_single;  // 1: plain bf16 contraction (hi planes only), reduced precision
   size_t w3_plane;  // elements between planes
 };
 
@@ -107,6 +111,16 @@ struct ALoader {
       const int pp = ok[s] ? pos : 0;
       if constexpr (LOADER == LOAD_PLAIN) {
         src0[s] = p.A + (size_t)pp * p.lda + p.a_coff + g * p.a_gcol;
+      } else if constexpr (LOADER == LOAD_GATHER_MLP1) {
+        const int MK = p.M * p.K;
+        const int b = pp / MK;
+        const int m = (pp - b * MK) / p.K;
+        const int j = p.gidx[pp];
+        const float* x = p.xyz + (size_t)b * 3 * p.N;
+        const float* c = p.ctr + (size_t)b * 3 * p.M;
+        rel[s][0] = __fsub_rn(x[j], c[m]);
+        rel[s][1] = __fsub_rn(x[p.N + j], c[p.M + m]);
+        rel[s][2] = __fsub_rn(x[2 * p.N + j], c[2 * p.M + m]);
       } else if constexpr (LOADER == LOAD_GATHER) {
         const int MK = p.M * p.K;
         const int b = pp / MK;
@@ -139,6 +153,17 @@ struct ALoader {
     if constexpr (LOADER == LOAD_PLAIN) {
       if (k0 >= p.Cin) return f4zero();
       return *reinterpret_cast<const float4*>(src0[s] + k0);
+    } else if constexpr (LOADER == LOAD_GATHER_MLP1) {
+      if (k0 >= p.Cin) return f4zero();
+      float4 r;
+      float* rp = reinterpret_cast<float*>(&r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float4 w = p.mlp1[k0 + e];
+        const float v = __fmaf_rn(w.z, rel[s][2], __fmaf_rn(w.y, rel[s][1], __fmaf_rn(w.x, rel[s][0], w.w)));
+        rp[e] = fmaxf(v, 0.f);
+      }
+      return r;
     } else if constexpr (LOADER == LOAD_GATHER) {
       if (k0 < p.Cf) return *reinterpret_cast<const float4*>(src0[s] + k0);
       if (k0 == p.Cf) return make_float4(rel[s][0], rel[s][1], rel[s][2], 0.f);
@@ -604,11 +629,13 @@ __global__ __launch_bounds__(64 * WAVES, NS == 1 ? WAVES / 2 : 1) void mlp_gemm_
 #define S4G_X3_TERM(PA, PB)                                                              \
   acc[0][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][PA], bf[PB], acc[0][cb], 0, 0, 0); \
   acc[1][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][PA], bf[PB], acc[1][cb], 0, 0, 0);
-        S4G_X3_TERM(0, 2)
-        S4G_X3_TERM(1, 1)
-        S4G_X3_TERM(2, 0)
-        S4G_X3_TERM(0, 1)
-        S4G_X3_TERM(1, 0)
+        if (!p.bf16_single) {
+          S4G_X3_TERM(0, 2)
+          S4G_X3_TERM(1, 1)
+          S4G_X3_TERM(2, 0)
+          S4G_X3_TERM(0, 1)
+          S4G_X3_TERM(1, 0)
+        }
         S4G_X3_TERM(0, 0)
 #undef S4G_X3_TERM
       }
@@ -669,7 +696,7 @@ static int launch_gemm(const GemmParams& p, int groups, hipStream_t st) {
 extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   using namespace s4g;
   if (!d || d->P < 0 || d->Cout <= 0 || d->groups <= 0 || !d->bias) return S4G_EINVAL;
-  const bool split = d->precision == S4G_GEMM_BF16X3;
+  const bool split = d->precision == S4G_GEMM_BF16X3 || d->precision == S4G_GEMM_BF16;
   if (split) {
     if (!d->W_bf16x3 || d->Kpad16 <= 0 || (d->Kpad16 & 15)) return S4G_EINVAL;
   } else if (d->precision == S4G_GEMM_FP32) {
@@ -684,6 +711,7 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   p.A = d->A; p.lda = d->lda; p.a_coff = d->a_coff; p.a_gcol = d->a_gcol;
   p.gidx = d->gidx; p.feat = d->feat; p.xyz = d->xyz; p.ctr = d->ctr;
   p.Cf = d->Cf; p.N = d->N; p.M = d->M; p.K = d->K;
+  p.mlp1 = (const float4*)d->mlp1_w;
   p.nidx = d->nidx; p.nw = d->nw; p.sparse = d->sparse; p.dense = d->dense;
   p.C2 = d->C2; p.C1 = d->C1; p.N2 = d->N2; p.N1 = d->N1;
   p.out = d->out; p.ldc = d->ldc; p.c_coff = d->c_coff; p.c_gcol = d->c_gcol;
@@ -693,6 +721,7 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   p.cf_sigmoid_from = d->cf_sigmoid_from; p.cf_N = d->cf_N;
   p.W3 = (const uint16_t*)d->W_bf16x3;
   p.Kpad16 = d->Kpad16;
+  p.bf16_single = d->precision == S4G_GEMM_BF16 ? 1 : 0;
   p.w3_plane = (size_t)d->groups * (size_t)d->Cout * (size_t)d->Kpad16;
   p.mtiles = (d->P + GM_BM - 1) / GM_BM;
   p.ntiles = (d->Cout + GM_BN - 1) / GM_BN;
@@ -704,6 +733,10 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   } else if (d->loader == S4G_GEMM_LOAD_GATHER) {
     if (!d->gidx || !d->xyz || !d->ctr || (d->Cf & 31) || (d->Cf > 0 && !d->feat) ||
         d->K <= 0 || d->M <= 0 || d->N <= 0 || d->groups != 1)
+      return S4G_EINVAL;
+  } else if (d->loader == S4G_GEMM_LOAD_GATHER_MLP1) {
+    if (!d->gidx || !d->xyz || !d->ctr || !d->mlp1_w || (d->Cin & 3) || d->K <= 0 || d->M <= 0 ||
+        d->N <= 0 || d->groups != 1 || ((uintptr_t)d->mlp1_w & 15))
       return S4G_EINVAL;
   } else if (d->loader == S4G_GEMM_LOAD_INTERP) {
     if (!d->nidx || !d->nw || !d->sparse || (d->C2 & 31) || (d->C1 & 3) ||
@@ -732,6 +765,8 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   S4G_GEMM_CASE(LOAD_GATHER, EPI_STORE)
   S4G_GEMM_CASE(LOAD_GATHER, EPI_MAX)
   S4G_GEMM_CASE(LOAD_INTERP, EPI_STORE)
+  S4G_GEMM_CASE(LOAD_GATHER_MLP1, EPI_STORE)
+  S4G_GEMM_CASE(LOAD_GATHER_MLP1, EPI_MAX)
 #undef S4G_GEMM_CASE
   return S4G_EUNSUPPORTED;
 }

@@ -34,7 +34,7 @@ _i32 = ctypes.c_int32
 _fp = ctypes.c_void_p
 GemmDesc = _cabi.GemmDesc
 
-LOAD_PLAIN, LOAD_GATHER, LOAD_INTERP = 0, 1, 2
+LOAD_PLAIN, LOAD_GATHER, LOAD_INTERP, LOAD_GATHER_MLP1 = 0, 1, 2, 3
 EPI_STORE, EPI_MAX, EPI_CF = 0, 1, 2
 
 
@@ -97,12 +97,14 @@ class FusedPointNet2:
 
     def __init__(self, net, precision=None):
         """precision: "bf16x3" (default; fp32-equivalent split on the bf16 matrix
-        cores) or "fp32" (fp32-input MFMA, an exact fma chain).  S4G_GEMM_MODE
+        cores), "fp32" (fp32-input MFMA, an exact fma chain) or "bf16" (plain bf16
+        inputs, fp32 accumulate -- reduced precision, outside the 1e-4 bar; the
+        bf16 roofline configuration of BASELINE.json configs[4]).  S4G_GEMM_MODE
         overrides the default."""
         if precision is None:
             precision = os.environ.get("S4G_GEMM_MODE", "bf16x3")
-        if precision not in ("bf16x3", "fp32"):
-            raise ValueError("precision must be 'bf16x3' or 'fp32'")
+        if precision not in ("bf16x3", "fp32", "bf16"):
+            raise ValueError("precision must be 'bf16x3', 'fp32' or 'bf16'")
         self.precision = precision
         p = next(net.parameters())
         if not p.is_cuda:
@@ -118,8 +120,14 @@ class FusedPointNet2:
             if sa.grouper.num_neighbours not in (16, 32, 64):
                 raise NotImplementedError("fast path needs num_neighbours in {16, 32, 64}")
             layers = []
+            mlp1 = None
             for li, blk in enumerate(sa.mlp):
                 w, b = fold_conv_bn(blk)
+                if li == 0 and sa.in_channels == 0 and len(sa.mlp) > 1 and w.shape[0] % 4 == 0:
+                    # xyz-only first layer (3 -> C1): evaluated inside the next layer's
+                    # loader (3 fmas per channel) instead of a launch that writes
+                    # (B*M*K, C1) to HBM and reads it back
+                    mlp1 = torch.cat([w[:, :3], b[:, None]], dim=1).contiguous()   # (C1, 4)
                 if li == 0:
                     # reference K order [xyz(3), feat(C)] (modules.py:50) -> ours [feat, xyz]
                     w = torch.cat([w[:, 3:], w[:, :3]], dim=1)
@@ -129,7 +137,7 @@ class FusedPointNet2:
                 layers.append(_Layer(_pad_k(w), b, cin))
             self.sa.append(dict(M=sa.num_centroids, radius=float(sa.grouper.radius),
                                 K=int(sa.grouper.num_neighbours), layers=layers,
-                                cf=sa.in_channels))
+                                cf=sa.in_channels, mlp1=mlp1))
         self.fp = []
         for fp in net.fp_modules:
             if fp.interpolator is None:
@@ -174,7 +182,7 @@ class FusedPointNet2:
         d.P, d.Cin, d.Kpad, d.Cout = P, layer.cin, layer.kpad, layer.cout
         d.W, d.bias = layer.W.data_ptr(), layer.bias.data_ptr()
         d.w_gstride, d.b_gstride = layer.cout * layer.kpad, layer.cout
-        d.precision = 1 if self.precision == "bf16x3" else 0
+        d.precision = {"fp32": 0, "bf16x3": 1, "bf16": 2}[self.precision]
         d.Kpad16, d.W_bf16x3 = layer.kpad16, layer.W3.data_ptr()
         for k, v in kw.items():
             if isinstance(v, torch.Tensor):
@@ -262,11 +270,17 @@ class FusedPointNet2:
             layers = sa["layers"]
             x = None
             for l, layer in enumerate(layers):
+                if l == 0 and sa["mlp1"] is not None:
+                    continue                      # folded into layer 1's loader
                 last = l == len(layers) - 1
                 rows = B * M if last else P
                 out = torch.empty((rows, layer.cout), dtype=torch.float32, device=dev)
                 kw = dict(out=out, ldc=layer.cout, K=K)
-                if l == 0:
+                if l == 1 and sa["mlp1"] is not None:
+                    kw.update(gidx=gidx, xyz=level_xyz[li], ctr=ctr, N=level_n[li], M=M,
+                              mlp1_w=sa["mlp1"])
+                    loader = LOAD_GATHER_MLP1
+                elif l == 0:
                     kw.update(gidx=gidx, feat=feat, xyz=level_xyz[li], ctr=ctr, Cf=sa["cf"],
                               N=level_n[li], M=M)
                     loader = LOAD_GATHER

@@ -245,6 +245,28 @@ def test_fused_model_full_golden(dev, precision):
         assert err < TOL, (k, err)
 
 
+def test_bf16_single_product_mode_is_close_but_reduced(dev):
+    """configs[4]: plain bf16 contraction.  Indices stay bit-exact (geometry is
+    untouched); outputs agree with the fp32 path to bf16-class tolerance only."""
+    from s4g_release_amd import synth
+    from s4g_release_amd.fused import FusedPointNet2
+    g = GU.load("pn2_small.npz")
+    from s4g_release_amd.model import PointNet2
+    net = PointNet2(**GU.small_config(g))
+    net.load_state_dict(GU.small_state_dict(g), strict=True)
+    net = net.to(dev).eval()
+    pts = torch.from_numpy(g["points"]).to(dev)
+    lo, inter = FusedPointNet2(net, precision="bf16")({"scene_points": pts}, return_intermediates=True)
+    for li in range(3):
+        assert np.array_equal(inter["ball%d" % li].cpu().numpy().astype(np.int64), g["ball%d" % li])
+    worst = 0.0
+    for k in ("score", "frame_R", "frame_t", "movable_logits"):
+        err = float(np.max(np.abs(lo[k].cpu().numpy() - g["out/" + k])))
+        scale = float(np.max(np.abs(g["out/" + k]))) + 1e-6
+        worst = max(worst, err / scale)
+    assert 1e-5 < worst < 0.1, worst     # clearly not fp32, clearly not garbage
+
+
 def test_fused_equals_modules_path_batch(dev):
     """Same model, both product paths, a batch of 3 dup-heavy scenes."""
     from s4g_release_amd import synth

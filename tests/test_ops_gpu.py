@@ -242,6 +242,40 @@ def test_three_interpolate_backward(F, oracle, dev):
     assert np.allclose(feat.grad.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
 
 
+def test_fmad_mode_all_geometry_ops(F, oracle, dev, bq_mode):
+    """S4G_FLAG_FMAD (nvcc-style contraction) against the oracle's fmad restatement."""
+    pts = synth.make_batch([6, 7], 9000, variant="dup-heavy")
+    M = 1500
+    try:
+        F.set_distance_mode("fmad")
+        idx = F.farthest_point_sample(_t(pts, dev), M).cpu().numpy()
+        ref_idx = oracle.fps(pts, M, fmad=1)
+        assert np.array_equal(idx, ref_idx)
+        ctr = oracle.gather_points(pts, ref_idx)
+        for mode in ("grid", "scan"):
+            bq_mode(mode)
+            bi, bc = F.ball_query(_t(pts, dev), _t(ctr, dev), 0.03, 32)
+            ri, rc = oracle.ball_query(pts, ctr, 0.03, 32, fmad=1)
+            assert np.array_equal(bi.cpu().numpy(), ri) and np.array_equal(bc.cpu().numpy(), rc)
+        ni, nd = F.search_nn_distance(_t(pts, dev), _t(ctr, dev), 3)
+        rni, rnd = oracle.three_nn(pts, ctr, fmad=1)
+        assert np.array_equal(ni.cpu().numpy(), rni) and np.array_equal(nd.cpu().numpy(), rnd)
+        feat = np.random.default_rng(0).standard_normal((2, 8, M)).astype(np.float32)
+        w = oracle.interp_weights(rnd)
+        out = F.feature_interpolate(_t(feat, dev), ni, _t(w, dev))
+        assert np.array_equal(out.cpu().numpy(), oracle.three_interpolate(feat, rni, w, fmad=1))
+    finally:
+        F.set_distance_mode("strict")
+
+
+def test_fps_tie_heavy_large(F, oracle, dev):
+    """25 600 points on a coarse lattice: thousands of exact distance ties per step."""
+    rng = np.random.default_rng(42)
+    pts = (rng.integers(0, 12, size=(2, 3, 25600)).astype(np.float32) * np.float32(0.05))
+    got = F.farthest_point_sample(_t(pts, dev), 700).cpu().numpy()
+    assert np.array_equal(got, oracle.fps(pts, 700))
+
+
 def test_runs_on_current_stream(F, oracle, dev):
     pts = synth.make_batch([1], 2048)
     s = torch.cuda.Stream(device=dev)

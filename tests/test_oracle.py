@@ -123,3 +123,54 @@ def test_synth_is_deterministic_and_permuted():
     assert not np.array_equal(a, synth.make_scene(6, 4096))
     d = synth.make_scene(0, 4096, variant="dup-heavy")
     assert len(np.unique(d.T, axis=0)) < 4096
+
+
+# ---------------------------------------------------------------- property tests
+from hypothesis import given, settings, strategies as st
+
+
+@settings(max_examples=40, deadline=None)
+@given(n=st.integers(3, 300), frac=st.floats(0.05, 1.0), levels=st.integers(1, 5),
+       seed=st.integers(0, 10 ** 6))
+def test_property_fps_tie_rule(oracle, n, frac, levels, seed):
+    """Closed-form tie rule == literal block emulation, on lattices with many ties
+    (levels = 1: all points identical)."""
+    m = max(1, int(n * frac))
+    rng = np.random.default_rng(seed)
+    pts = rng.integers(0, levels, size=(1, 3, n)).astype(np.float32) * np.float32(0.5)
+    a = oracle.fps(pts, m)
+    assert np.array_equal(a, oracle.fps_literal(pts, m))
+    assert a[0, 0] == 0 and a.min() >= 0 and a.max() < n
+
+
+@settings(max_examples=40, deadline=None)
+@given(n=st.integers(1, 200), m=st.integers(1, 40), k=st.integers(1, 20),
+       r=st.floats(0.01, 2.0), levels=st.integers(1, 6), seed=st.integers(0, 10 ** 6))
+def test_property_ball_query_invariants(oracle, n, m, k, r, levels, seed):
+    rng = np.random.default_rng(seed)
+    pts = rng.integers(0, levels, size=(1, 3, n)).astype(np.float32) * np.float32(0.3)
+    ctr = rng.integers(0, levels, size=(1, 3, m)).astype(np.float32) * np.float32(0.3)
+    idx, cnt = oracle.ball_query(pts, ctr, r, k)
+    ridx, rcnt = naive.ball_query(pts, ctr, r, k)
+    assert np.array_equal(idx, ridx) and np.array_equal(cnt, rcnt)
+    for j in range(m):
+        c = int(cnt[0, j])
+        row = idx[0, j]
+        assert 0 <= c <= k
+        assert (np.diff(row[:c]) > 0).all()            # strictly ascending index order
+        assert (row[c:] == (row[0] if c else 0)).all()  # padding = first hit (or zeros)
+
+
+@settings(max_examples=30, deadline=None)
+@given(n1=st.integers(1, 120), n2=st.integers(3, 60), levels=st.integers(1, 5),
+       seed=st.integers(0, 10 ** 6))
+def test_property_three_nn_order(oracle, n1, n2, levels, seed):
+    rng = np.random.default_rng(seed)
+    q = rng.integers(0, levels, size=(1, 3, n1)).astype(np.float32) * np.float32(0.25)
+    k = rng.integers(0, levels, size=(1, 3, n2)).astype(np.float32) * np.float32(0.25)
+    idx, d2 = oracle.three_nn(q, k)
+    ridx, rd2 = naive.three_nn(q, k)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+    assert (np.diff(d2, axis=2) >= 0).all()             # ascending distances
+    w = oracle.interp_weights(d2)
+    assert np.allclose(w.sum(-1), 1.0, atol=1e-6)
