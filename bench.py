@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--points", type=int, default=25600)
     ap.add_argument("--impl", default="auto", choices=["auto", "fused", "modules"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="batches kept in flight besides the one being collected")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="collect each batch before submitting the next")
     ap.add_argument("--variant", default="tabletop-v1")
@@ -123,13 +125,13 @@ def main():
                 for _ in range(n):
                     finish(runner(batch))
                 return
-            pending = None
+            pending = []
             for _ in range(n):
-                h = runner.submit(batch)
-                if pending is not None:
-                    finish(pending.result())
-                pending = h
-            finish(pending.result())
+                pending.append(runner.submit(batch))
+                if len(pending) > args.in_flight:
+                    finish(pending.pop(0).result())
+            while pending:
+                finish(pending.pop(0).result())
 
     run_steps(args.warmup)
 

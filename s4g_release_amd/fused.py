@@ -106,6 +106,7 @@ class FusedPointNet2:
         if precision not in ("bf16x3", "fp32", "bf16"):
             raise ValueError("precision must be 'bf16x3', 'fp32' or 'bf16'")
         self.precision = precision
+        self.dense_streams = int(os.environ.get("S4G_DENSE_STREAMS", "2"))
         p = next(net.parameters())
         if not p.is_cuda:
             raise RuntimeError("FusedPointNet2 needs the model on a HIP device (no CPU fallback)")
@@ -354,9 +355,14 @@ class FusedPointNet2:
             raise RuntimeError("scene_points must be (B, 3, N)")
         dev = xyz.device
         if self._streams is None or self._streams[0].device != dev:
+            # one high-priority geometry stream, dense streams used round-robin so
+            # that consecutive batches' contractions can fill each other's tails
             self._streams = (torch.cuda.Stream(device=dev, priority=-1),
-                             torch.cuda.Stream(device=dev))
-        gs, ds = self._streams
+                             [torch.cuda.Stream(device=dev) for _ in range(self.dense_streams)])
+            self._submitted = 0
+        gs = self._streams[0]
+        ds = self._streams[1][self._submitted % len(self._streams[1])]
+        self._submitted += 1
         with torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
             ev_in = cur.record_event()
