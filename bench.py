@@ -278,9 +278,11 @@ def main():
         "dtype": "bf16" if getattr(runner, "precision", "") == "bf16" else "f32", "data": "synthetic",
         "config": {"workload": "S4G PN2_CLS forward (3 SA + 3 FP + 4 heads), %d scenes/GPU/step, "
                                "%d-pt %s clouds, fp32 (%s), impl=%s%s" % (B, args.points, args.variant,
-                                                                      "contraction as exact 3xbf16 split, fp32 accumulate"
-                                                                      if getattr(runner, "precision", "") == "bf16x3"
-                                                                      else "fp32 MFMA / library GEMM", impl,
+                                                                      {"bf16x3": "contraction as exact 3xbf16 split, fp32 accumulate",
+                                                                       "bf16": "REDUCED PRECISION: plain bf16 contraction",
+                                                                       "fp32": "fp32 MFMA"}.get(
+                                                                          getattr(runner, "precision", ""), "library GEMM"),
+                                                                      impl,
                                                                     ", 1 batch in flight" if pipelined else ""),
                    "scenes_per_gpu": B, "num_points": args.points, "global_batch": world * B,
                    "parallelism": "scenes sharded over %d GPU(s), all-gather of 21 ch/point" % world},

@@ -106,7 +106,7 @@ class FusedPointNet2:
         if precision not in ("bf16x3", "fp32", "bf16"):
             raise ValueError("precision must be 'bf16x3', 'fp32' or 'bf16'")
         self.precision = precision
-        self.dense_streams = int(os.environ.get("S4G_DENSE_STREAMS", "2"))
+        self.dense_streams = int(os.environ.get("S4G_DENSE_STREAMS", "1"))
         p = next(net.parameters())
         if not p.is_cuda:
             raise RuntimeError("FusedPointNet2 needs the model on a HIP device (no CPU fallback)")
@@ -355,8 +355,9 @@ class FusedPointNet2:
             raise RuntimeError("scene_points must be (B, 3, N)")
         dev = xyz.device
         if self._streams is None or self._streams[0].device != dev:
-            # one high-priority geometry stream, dense streams used round-robin so
-            # that consecutive batches' contractions can fill each other's tails
+            # one high-priority geometry stream; S4G_DENSE_STREAMS=2 lets consecutive
+            # batches' contractions fill each other's kernel tails (+1.5 % measured),
+            # the default of 1 keeps per-kernel event timings clean
             self._streams = (torch.cuda.Stream(device=dev, priority=-1),
                              [torch.cuda.Stream(device=dev) for _ in range(self.dense_streams)])
             self._submitted = 0
