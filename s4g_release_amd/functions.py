@@ -415,6 +415,27 @@ class FeatureInterpolate(torch.autograd.Function):
 
 feature_interpolate = FeatureInterpolate.apply
 
+class GatherKNN(torch.autograd.Function):
+    """Drop-in for the reference's second native extension `dgcnn_ext`
+    (`network_models/functions/gather_knn.py:10-24`, kernels
+    `functions/csrc/gather_knn_kernel.cu:27-153`): feature (B,C,N), index (B,N,K)
+    -> (B,C,N,K).  It is group_points with M == N, forward and backward, so it
+    runs on the same two HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, feature, index):
+        ctx.save_for_backward(index)
+        ctx.num_points = feature.size(2)
+        return _group_points_forward(feature, index)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        index = ctx.saved_tensors[0]
+        return _group_points_backward(grad_output, index, ctx.num_points), None
+
+
+gather_knn = GatherKNN.apply
+
 # north-star spellings (erikwijmans lineage); same objects.
 furthest_point_sample = farthest_point_sample
 

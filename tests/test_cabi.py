@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
 def test_operator_api_names_match_reference():
     from s4g_release_amd import functions as F, pn2_ext
     for name in ("gather_points", "farthest_point_sample", "ball_query", "group_points",
-                 "search_nn_distance", "feature_interpolate",
+                 "search_nn_distance", "feature_interpolate", "gather_knn", "query_and_group",
                  "furthest_point_sample", "three_nn", "three_interpolate"):
         assert callable(getattr(F, name))
     for name in ("ball_query", "group_points_forward", "group_points_backward",

@@ -242,6 +242,24 @@ def test_three_interpolate_backward(F, oracle, dev):
     assert np.allclose(feat.grad.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
 
 
+def test_gather_knn_like_reference_self_test(F, dev):
+    """The reference's only test (functions/gather_knn.py:27-56): gather_knn against
+    torch.gather on an expanded view, forward and backward, B=2 C=4 N=5 k=3, seed 1
+    -- here with asserts instead of prints."""
+    torch.manual_seed(1)
+    B, N, C, k = 2, 5, 4, 3
+    feat = torch.rand(B, C, N).to(dev)
+    knn = torch.randint(0, N, [B, N, k]).long().to(dev)
+    a = feat.clone().requires_grad_(True)
+    b = feat.clone().requires_grad_(True)
+    ref = torch.gather(a.unsqueeze(2).expand(B, C, N, N), 3, knn.unsqueeze(1).expand(B, C, N, k))
+    got = F.gather_knn(b, knn)
+    assert torch.equal(ref, got)
+    ref.backward(torch.ones_like(ref))
+    got.backward(torch.ones_like(got))
+    assert torch.allclose(a.grad, b.grad)
+
+
 def test_fmad_mode_all_geometry_ops(F, oracle, dev, bq_mode):
     """S4G_FLAG_FMAD (nvcc-style contraction) against the oracle's fmad restatement."""
     pts = synth.make_batch([6, 7], 9000, variant="dup-heavy")
