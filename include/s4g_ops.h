@@ -236,6 +236,23 @@ int s4g_fps_gather_i32(const float *xyz_b3n, int64_t B, int64_t N, int64_t M,
                        int32_t *idx_bm, float *ctr_b3m, void *ws, size_t ws_bytes,
                        int flags, s4g_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Next row: pose decode right after the network.
+ * s4g_expected_score_f32: softmax over the C score classes of (B,C,N) logits,
+ *   score = sum_c values[c] * softmax[c]   (utils/file_logger_cls.py:34-36,66-68;
+ *   grasp_detector.py:145-149 with its own `values`).
+ * s4g_decode_poses_f32: for the selected point indices sel (B,K): row-major
+ *   R from frame_R (B,9,N), tau = sum_c t_bins[c]*softmax(frame_t)[c],
+ *   t = -tau*R[:,0] + p, Gram-Schmidt -> H (B,K,4,4) row-major
+ *   (utils/file_logger_cls.py:38-47,203-218; grasp_detector.py:124-135,176-180).
+ * ------------------------------------------------------------------------- */
+int s4g_expected_score_f32(const float *logits_bcn, int64_t B, int64_t C, int64_t N,
+                           const float *values_c, float *score_bn, s4g_stream_t stream);
+int s4g_decode_poses_f32(const float *xyz_b3n, const float *frame_R_b9n,
+                         const float *frame_t_btn, const int64_t *sel_bk, int64_t B,
+                         int64_t N, int64_t K, int64_t TC, const float *t_bins,
+                         float *H_bk44, s4g_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,54 @@
+"""Pose decode on the device -- the step right after `PointNet2.forward` in the
+reference's callers (`grasp_proposal_test.py:83` -> `utils/file_logger_cls.py`,
+`grasp_detector.py:137-185`); SURVEY.md section 8f row f1.
+
+`decode_top_poses` turns the four head tensors into the K best grasp frames per
+scene entirely on the GPU, so a serving loop ships K x 18 floats per scene
+instead of 21 x N.  Collision filtering (row f2) is not part of it.
+"""
+import torch
+
+from . import _cabi
+from . import functions as _F
+
+T_BINS = (0.08, 0.06, 0.04, 0.02)          # file_logger_cls.py:45, grasp_detector.py:177
+
+
+def score_values(num_classes, convention="demo"):
+    """`demo`: linspace(0,1,C+1)[:-1] (file_logger_cls.py:67); `detector`:
+    linspace(0,1,C+1)[1:] (grasp_detector.py:147)."""
+    v = torch.linspace(0, 1, num_classes + 1, dtype=torch.float64)
+    return (v[:-1] if convention == "demo" else v[1:]).float()
+
+
+def expected_score(score_logits, convention="demo"):
+    logits = _F._f32c(score_logits, "score")
+    B, C, N = logits.shape
+    vals = score_values(C, convention).to(logits.device)
+    out = torch.empty((B, N), dtype=torch.float32, device=logits.device)
+    with torch.cuda.device(logits.device):
+        rc = _cabi.lib().s4g_expected_score_f32(logits.data_ptr(), B, C, N, vals.data_ptr(),
+                                                out.data_ptr(), _F._stream())
+    _cabi.check(rc, "expected_score")
+    return out
+
+
+def decode_top_poses(predictions, scene_points, num_poses=50, convention="demo"):
+    """-> (H (B,K,4,4) fp32, score (B,K) fp32, index (B,K) int64), best first
+    (file_logger_cls.py:196-218: K = 50, argsort(-score)[:K], Gram-Schmidt)."""
+    xyz = _F._f32c(scene_points, "scene_points")
+    R = _F._f32c(predictions["frame_R"], "frame_R")
+    t = _F._f32c(predictions["frame_t"], "frame_t")
+    score = expected_score(predictions["score"], convention)
+    B, _, N = xyz.shape
+    K = min(int(num_poses), N)
+    top, sel = torch.topk(score, K, dim=1, largest=True, sorted=True)
+    sel = sel.contiguous()
+    bins = torch.tensor(T_BINS[:t.shape[1]], dtype=torch.float32, device=xyz.device)
+    H = torch.empty((B, K, 4, 4), dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        rc = _cabi.lib().s4g_decode_poses_f32(xyz.data_ptr(), R.data_ptr(), t.data_ptr(),
+                                              sel.data_ptr(), B, N, K, t.shape[1], bins.data_ptr(),
+                                              H.data_ptr(), _F._stream())
+    _cabi.check(rc, "decode_poses")
+    return H, top, sel

@@ -1,0 +1,42 @@
+"""GPU parity of the device-side pose decode (next row f1) against the CPU
+restatement of the reference's demo post-processing."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("convention", ["demo", "detector"])
+def test_decode_top_poses_matches_oracle(dev, convention):
+    from oracle import postprocess as OP
+    from s4g_release_amd import postprocess as PP, synth
+    rng = np.random.default_rng(5)
+    B, N, K = 3, 4000, 50
+    pts = synth.make_batch([1, 2, 3], N)
+    pred = {"score": rng.standard_normal((B, 3, N)).astype(np.float32) * 2,
+            "frame_R": rng.standard_normal((B, 9, N)).astype(np.float32),
+            "frame_t": rng.standard_normal((B, 4, N)).astype(np.float32),
+            "movable_logits": rng.random((B, 5, N)).astype(np.float32)}
+    H, s, idx = PP.decode_top_poses({k: torch.from_numpy(v).to(dev) for k, v in pred.items()},
+                                    torch.from_numpy(pts).to(dev), K, convention)
+    rH, rs, ridx = OP.decode_top_poses(pred, pts, K, convention)
+    assert tuple(H.shape) == (B, K, 4, 4)
+    assert np.allclose(s.cpu().numpy(), rs, atol=2e-6)
+    # same selection (scores are distinct for random logits), best first
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.allclose(H.cpu().numpy(), rH, atol=2e-5)
+    Hn = H.cpu().numpy().astype(np.float64)
+    RtR = np.einsum("bkij,bkil->bkjl", Hn[..., :3, :3], Hn[..., :3, :3])
+    assert np.allclose(RtR, np.eye(3), atol=1e-5)                        # orthonormal frames
+    assert np.allclose(np.linalg.det(Hn[..., :3, :3]), 1.0, atol=1e-5)   # right-handed
+
+
+def test_expected_score_full_size(dev):
+    from s4g_release_amd import postprocess as PP
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(2, 3, 25600, generator=g).to(dev)
+    got = PP.expected_score(logits, "detector")
+    ref = (torch.softmax(logits.double(), dim=1) *
+           torch.tensor([1 / 3, 2 / 3, 1.0], dtype=torch.float64, device=dev)[None, :, None]).sum(1)
+    assert (got.double() - ref).abs().max().item() < 1e-6
