@@ -80,6 +80,14 @@ def test_sharded_forward_all_gather_gloo(world):
         assert shapes["score"] == (6, 3, 50) and shapes["movable_logits"] == (6, 5, 50)
 
 
+def test_all_gather_poses_single_process_roundtrip():
+    H = torch.randn(3, 7, 4, 4)
+    score = torch.rand(3, 7)
+    index = torch.randint(0, 25600, (3, 7))
+    h2, s2, i2 = sdist.all_gather_poses(H, score, index)
+    assert torch.equal(h2, H) and torch.equal(s2, score) and torch.equal(i2, index)
+
+
 def test_uneven_batch_is_rejected():
     with pytest.raises(ValueError):
         class _G:   # fake a 4-rank world without initialising a process group
