@@ -253,6 +253,18 @@ int s4g_decode_poses_f32(const float *xyz_b3n, const float *frame_R_b9n,
                          int64_t N, int64_t K, int64_t TC, const float *t_bins,
                          float *H_bk44, s4g_stream_t stream);
 
+/* Next row f2: batched gripper-vs-cloud collision counts, replaces the per-pose
+ * loop over CloudCollisionChecker.view_non_collision
+ * (cloud_processor/view_collision_checker.py:37-65, grasp_detector.py:216-234).
+ * g2l = global->gripper 4x4 row-major per pose; gripper6 (HOST pointer) =
+ * {FINGER_LENGTH, BOTTOM_LENGTH, HALF_HAND_THICKNESS, HALF_BOTTOM_WIDTH,
+ *  HALF_BOTTOM_SPACE, BACK_COLLISION_MARGIN} (configs/gripper_config.py:10-21,
+ * processing_config.py:39); counts (B,K,2) int32 = {behind the palm, inside
+ * the finger volumes}. */
+int s4g_collision_counts_f32(const float *xyz_b3n, const float *g2l_bk44, int64_t B,
+                             int64_t N, int64_t K, const float *gripper6,
+                             int32_t *counts_bk2, s4g_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

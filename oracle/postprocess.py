@@ -37,3 +37,31 @@ def decode_top_poses(pred, scene_points, K=50, convention="demo"):
             H[i, :3, 3] = frame_t[ind]
         Hs.append(H); Ss.append(scene_pred[top]); Is.append(top)
     return np.stack(Hs), np.stack(Ss), np.stack(Is)
+
+
+def view_non_collision(poses, scene_points, half_bottom_width=0.057, bottom_length=0.16,
+                       finger_width=0.023, half_hand_thickness=0.012, finger_length=0.09,
+                       back_margin=0.0, back_threshold=10 * np.sqrt(8), finger_threshold=10):
+    """Restatement of CloudCollisionChecker.view_non_collision
+    (cloud_processor/view_collision_checker.py:37-65) for (B,K,4,4) poses; returns
+    (ok (B,K) bool, counts (B,K,2))."""
+    B, K = poses.shape[:2]
+    ok = np.zeros((B, K), dtype=bool)
+    counts = np.zeros((B, K, 2), dtype=np.int64)
+    hbs = half_bottom_width - finger_width
+    for b in range(B):
+        homo = np.concatenate([scene_points[b], np.ones((1, scene_points.shape[2]), np.float32)], 0)
+        for k in range(K):
+            g2l = np.linalg.inv(poses[b, k].astype(np.float64)).astype(np.float32)
+            local = torch.matmul(torch.from_numpy(g2l), torch.from_numpy(homo)).numpy()      # :38
+            close = (local[0] < finger_length) & (local[0] > -bottom_length)                  # :39-40
+            lc = local[:, close][0:3]                                                         # :42
+            zc = (lc[2] < half_hand_thickness) & (lc[2] > -half_hand_thickness)               # :44-45
+            back = (lc[1] < half_bottom_width) & (lc[1] > -half_bottom_width) & \
+                   (lc[0] < -back_margin) & zc                                                # :47-49
+            left = (lc[1] < half_bottom_width) & (lc[1] > hbs)                                # :54-55
+            right = (lc[1] > -half_bottom_width) & (lc[1] < -hbs)                             # :56-57
+            fing = zc & (left | right)                                                        # :59-60
+            counts[b, k] = (back.sum(), fing.sum())
+            ok[b, k] = not (back.sum() > back_threshold) and not (fing.sum() > finger_threshold)
+    return ok, counts

@@ -108,3 +108,72 @@ extern "C" int s4g_decode_poses_f32(const float* xyz_b3n, const float* frame_R_b
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Batched gripper-vs-cloud collision counts: restates
+// CloudCollisionChecker.view_non_collision
+// (cloud_processor/view_collision_checker.py:37-65), which the detector calls
+// once per pose in a Python loop with a host sync each (grasp_detector.py:216-234).
+// One workgroup per pose streams the cloud once (HBM/L2-bound, 12 B per point)
+// and counts the points behind the palm and inside the two finger volumes.
+// ---------------------------------------------------------------------------
+namespace s4g {
+
+struct GripperBox {
+  float finger_length, bottom_length, half_hand_thickness, half_bottom_width, half_bottom_space,
+      back_margin;
+};
+
+__global__ __launch_bounds__(256) void collision_counts_kernel(
+    const float* __restrict__ xyz, const float* __restrict__ g2l, int N, int K, GripperBox g,
+    int* __restrict__ counts) {
+  __shared__ int sback[4], sfing[4];
+  const int b = blockIdx.y, k = blockIdx.x, t = threadIdx.x;
+  const float* G = g2l + ((size_t)b * K + k) * 16;   // row-major 4x4 global -> gripper frame
+  const float g00 = G[0], g01 = G[1], g02 = G[2], g03 = G[3];
+  const float g10 = G[4], g11 = G[5], g12 = G[6], g13 = G[7];
+  const float g20 = G[8], g21 = G[9], g22 = G[10], g23 = G[11];
+  const float* px = xyz + (size_t)b * 3 * N;
+  int nback = 0, nfing = 0;
+  for (int i = t; i < N; i += 256) {
+    const float x = px[i], y = px[N + i], z = px[2 * (size_t)N + i];
+    const float lx = g00 * x + g01 * y + g02 * z + g03;
+    const float ly = g10 * x + g11 * y + g12 * z + g13;
+    const float lz = g20 * x + g21 * y + g22 * z + g23;
+    const bool close = (lx < g.finger_length) && (lx > -g.bottom_length);            // :39-40
+    const bool zin = (lz < g.half_hand_thickness) && (lz > -g.half_hand_thickness);  // :44-45
+    const bool back = close && zin && (ly < g.half_bottom_width) && (ly > -g.half_bottom_width) &&
+                      (lx < -g.back_margin);                                          // :47-49
+    const bool fl = (ly < g.half_bottom_width) && (ly > g.half_bottom_space);        // :54-55
+    const bool fr = (ly > -g.half_bottom_width) && (ly < -g.half_bottom_space);      // :56-57
+    const bool fing = close && zin && (fl || fr);                                     // :59-60
+    nback += __popcll(__ballot(back)) ;
+    nfing += __popcll(__ballot(fing));
+  }
+  // every lane of a wave holds the wave's totals (ballot counts are wave-uniform)
+  if ((t & 63) == 0) {
+    sback[t >> 6] = nback;
+    sfing[t >> 6] = nfing;
+  }
+  __syncthreads();
+  if (t == 0) {
+    int* c = counts + ((size_t)b * K + k) * 2;
+    c[0] = sback[0] + sback[1] + sback[2] + sback[3];
+    c[1] = sfing[0] + sfing[1] + sfing[2] + sfing[3];
+  }
+}
+
+}  // namespace s4g
+
+extern "C" int s4g_collision_counts_f32(const float* xyz_b3n, const float* g2l_bk44, int64_t B,
+                                        int64_t N, int64_t K, const float* gripper6,
+                                        int32_t* counts_bk2, s4g_stream_t stream) {
+  if (B < 0 || N <= 0 || K < 0 || B > 65535 || N >= (1ll << 31)) return S4G_EINVAL;
+  if (B == 0 || K == 0) return S4G_OK;
+  if (!xyz_b3n || !g2l_bk44 || !gripper6 || !counts_bk2) return S4G_EINVAL;
+  s4g::GripperBox g = {gripper6[0], gripper6[1], gripper6[2], gripper6[3], gripper6[4], gripper6[5]};
+  hipLaunchKernelGGL(s4g::collision_counts_kernel, dim3((unsigned)K, (unsigned)B), dim3(256), 0,
+                     (hipStream_t)stream, xyz_b3n, g2l_bk44, (int)N, (int)K, g, counts_bk2);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}

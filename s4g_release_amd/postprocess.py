@@ -6,6 +6,10 @@ reference's callers (`grasp_proposal_test.py:83` -> `utils/file_logger_cls.py`,
 scene entirely on the GPU, so a serving loop ships K x 18 floats per scene
 instead of 21 x N.  Collision filtering (row f2) is not part of it.
 """
+import ctypes
+import math
+from dataclasses import dataclass
+
 import torch
 
 from . import _cabi
@@ -52,3 +56,44 @@ def decode_top_poses(predictions, scene_points, num_poses=50, convention="demo")
                                               H.data_ptr(), _F._stream())
     _cabi.check(rc, "decode_poses")
     return H, top, sel
+
+
+@dataclass
+class GripperConfig:
+    """configs/gripper_config.py:10-21 and processing_config.py:25,37-40."""
+    half_bottom_width: float = 0.057
+    bottom_length: float = 0.16
+    finger_width: float = 0.023
+    half_hand_thickness: float = 0.012
+    finger_length: float = 0.09
+    back_collision_margin: float = 0.0
+    back_collision_threshold: float = 10 * math.sqrt(8)
+    finger_collision_threshold: float = 10
+
+    @property
+    def half_bottom_space(self):
+        return self.half_bottom_width - self.finger_width
+
+
+def view_non_collision(poses, scene_points, gripper=None):
+    """Batched `CloudCollisionChecker.view_non_collision`
+    (cloud_processor/view_collision_checker.py:37-65) for all poses of all scenes
+    in one launch.  poses (B,K,4,4) gripper->global frames; returns
+    (ok (B,K) bool, counts (B,K,2) int32).  The inverse is taken in float64 and
+    rounded to fp32 like the reference's caller (file_logger_cls.py:223-224)."""
+    gripper = gripper or GripperConfig()
+    xyz = _F._f32c(scene_points, "scene_points")
+    B, _, N = xyz.shape
+    K = poses.shape[1]
+    g2l = torch.linalg.inv(poses.double()).float().contiguous()
+    counts = torch.empty((B, K, 2), dtype=torch.int32, device=xyz.device)
+    params = (ctypes.c_float * 6)(gripper.finger_length, gripper.bottom_length,
+                                  gripper.half_hand_thickness, gripper.half_bottom_width,
+                                  gripper.half_bottom_space, gripper.back_collision_margin)
+    with torch.cuda.device(xyz.device):
+        rc = _cabi.lib().s4g_collision_counts_f32(xyz.data_ptr(), g2l.data_ptr(), B, N, K, params,
+                                                  counts.data_ptr(), _F._stream())
+    _cabi.check(rc, "collision_counts")
+    ok = (counts[..., 0] <= gripper.back_collision_threshold) & \
+         (counts[..., 1] <= gripper.finger_collision_threshold)
+    return ok, counts

@@ -40,3 +40,25 @@ def test_expected_score_full_size(dev):
     ref = (torch.softmax(logits.double(), dim=1) *
            torch.tensor([1 / 3, 2 / 3, 1.0], dtype=torch.float64, device=dev)[None, :, None]).sum(1)
     assert (got.double() - ref).abs().max().item() < 1e-6
+
+
+def test_batched_collision_check_matches_oracle(dev):
+    """Row f2: counts of points behind the palm / inside the finger volumes for all
+    poses in one launch vs the per-pose restatement of the reference."""
+    from oracle import postprocess as OP
+    from s4g_release_amd import postprocess as PP, synth
+    rng = np.random.default_rng(9)
+    B, N, K = 2, 25600, 40
+    pts = synth.make_batch([4, 5], N)
+    pred = {"score": rng.standard_normal((B, 3, N)).astype(np.float32),
+            "frame_R": rng.standard_normal((B, 9, N)).astype(np.float32),
+            "frame_t": rng.standard_normal((B, 4, N)).astype(np.float32)}
+    H, _, _ = PP.decode_top_poses({k: torch.from_numpy(v).to(dev) for k, v in pred.items()},
+                                  torch.from_numpy(pts).to(dev), K)
+    ok, counts = PP.view_non_collision(H, torch.from_numpy(pts).to(dev))
+    rok, rcounts = OP.view_non_collision(H.cpu().numpy(), pts)
+    # a point within one fp32 ulp of a box face may fall on either side
+    assert np.abs(counts.cpu().numpy().astype(np.int64) - rcounts).max() <= 1
+    agree = (ok.cpu().numpy() == rok).mean()
+    assert agree >= 0.95, agree
+    assert counts.cpu().numpy().sum() > 0          # the gripper does touch the table-top cloud
