@@ -451,9 +451,9 @@ static int ball_query_dispatch(const float* xyz, const float* ctr, int64_t B,
   const bool fmad = (flags & S4G_FLAG_FMAD) != 0;
   const dim3 block(64 * BQ_WAVES_PER_BLOCK);
   const dim3 grid((unsigned)((M + BQ_WAVES_PER_BLOCK - 1) / BQ_WAVES_PER_BLOCK), (unsigned)B);
-  int cpw = 1;  // centroids per wave (S4G_BQ_CPW=1|2|4|8 tuning knob; 1 measured best)
-  if (const char* e = getenv("S4G_BQ_CPW")) cpw = atoi(e);
-  if (cpw != 1 && cpw != 2 && cpw != 4 && cpw != 8) cpw = 1;
+  // centroids per wave: 1 measured best on MI355X (0.115 ms vs 0.141 / 0.136 / 0.146 ms
+  // for 2 / 4 / 8 at B = 16, SA1 size): more waves in flight beat amortised set-up.
+  constexpr int cpw = 1;
   const int cpb = BQ_WAVES_PER_BLOCK * cpw;
   const dim3 qgrid((unsigned)((M + cpb - 1) / cpb), (unsigned)B);
   const bool use_grid = bq_use_grid(N, K) && ws && ws_bytes >= grid_ws_bytes(B, N) &&
@@ -482,13 +482,7 @@ static int ball_query_dispatch(const float* xyz, const float* ctr, int64_t B,
 #define S4G_BQ_LAUNCH4(F, G, W, C)                                                        \
   hipLaunchKernelGGL((bq_grid_query_kernel<F, IdxT, G, W, C>), qgrid, block, lds, st, xyz, \
                      ctr, (int)N, (int)M, r2, inv_h, (int)K, g, idx, cnt, grouped, wpl)
-#define S4G_BQ_LAUNCH3(F, G, W)                  \
-  do {                                           \
-    if (cpw == 1) S4G_BQ_LAUNCH4(F, G, W, 1);    \
-    else if (cpw == 2) S4G_BQ_LAUNCH4(F, G, W, 2);\
-    else if (cpw == 4) S4G_BQ_LAUNCH4(F, G, W, 4);\
-    else S4G_BQ_LAUNCH4(F, G, W, 8);             \
-  } while (0)
+#define S4G_BQ_LAUNCH3(F, G, W) S4G_BQ_LAUNCH4(F, G, W, cpw)
 #define S4G_BQ_LAUNCH(F, G)                      \
   do {                                           \
     if (wpl == 13) S4G_BQ_LAUNCH3(F, G, 13);     \
