@@ -506,7 +506,7 @@ __device__ __forceinline__ void split3_frag(const float4 lo, const float4 hi, bf
 }
 
 template <int LOADER, int EPI, int NS, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, NS == 1 ? WAVES / 2 : 1) void mlp_gemm_bf16x3_kernel(const GemmParams p) {
+__global__ __launch_bounds__(64 * WAVES, (NS == 1 && WAVES == 4 && LOADER != LOAD_INTERP) ? 3 : (NS == 1 ? WAVES / 2 : 1)) void mlp_gemm_bf16x3_kernel(const GemmParams p) {
   constexpr int THREADS = 64 * WAVES;
   constexpr int WC = WAVES / 2;          // column strips (wave grid is 2 x WC)
   constexpr int NCB = 4 / WC;            // 32-wide column blocks per wave
