@@ -12,9 +12,13 @@ The timed region is bracketed by barrier + synchronize on both sides and the
 slowest rank's time is used.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      the kernel(s) the north star names: ball_query + group_points at
-                SA1 size (HBM-bound), live HIP-event durations from the timed region
-  kernels       every native launch: mean ms, algorithmic bytes, GB/s
+  roofline      the dominant kernel of a step: the MFMA shared-MLP contraction (all its
+                launches), HIP-event durations from the timed region, flops the matrix
+                cores execute against the dense peak, PMC traffic from profiles/
+  roofline_ball_query_group_points
+                the HBM-bound operator pair the north star names, at SA1 size, through
+                the operator API on the same batch (+ the fused single-pass entry point)
+  kernels       every native launch: mean ms, algorithmic bytes / flops, GB/s / TFLOP/s
   cpu_baseline  the CPU oracle forward (oracle/pn2_forward.py) on ONE scene,
                 rank 0 at N == 1 only -- a reported baseline, not the target
 """
@@ -211,6 +215,12 @@ def main():
             roofline["traffic_source"] = tr["source"]
     except (OSError, ValueError):
         pass
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            tr = json.load(f).get("mlp_gemm_bf16x3_kernel[step,B=%d,N=%d]" % (B, N))
+        dense_traffic = (tr["traffic_bytes"], tr["source"]) if tr else None
+    except (OSError, ValueError):
+        dense_traffic = None
     fq = probe.get("query_group[N=%d,M=%d,K=%d]" % (N, M, K))
     if fq:   # the same pair as ONE pass (s4g_query_group_f32), same algorithmic bytes
         roofline["fused_pair_ms"] = round(fq[1], 5)
@@ -251,6 +261,12 @@ def main():
                           "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                           "frac": round(dense_tf / FP32_MFMA_PEAK_TF, 4)}
 
+    roofline_dense["traffic"] = None
+    if dense_traffic and getattr(runner, "precision", "") == "bf16x3":
+        roofline_dense["traffic"] = dense_traffic[0]
+        roofline_dense["traffic_source"] = dense_traffic[1]
+        roofline_dense["traffic_unit"] = "bytes per step (all contraction launches)"
+
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
         from oracle import pn2_forward
@@ -286,7 +302,9 @@ def main():
                                                                     ", 1 batch in flight" if pipelined else ""),
                    "scenes_per_gpu": B, "num_points": args.points, "global_batch": world * B,
                    "parallelism": "scenes sharded over %d GPU(s), all-gather of 21 ch/point" % world},
-        "roofline": roofline, "roofline_dense": roofline_dense, "kernels": kernels,
+        # `roofline`: the dominant kernel of the step (the MFMA contraction, >90 % of GPU time);
+        # `roofline_ball_query_group_points`: the HBM-bound operator pair the north star names.
+        "roofline": roofline_dense, "roofline_ball_query_group_points": roofline, "kernels": kernels,
         "cpu_baseline": cpu_baseline,
     }
     print(json.dumps(line))

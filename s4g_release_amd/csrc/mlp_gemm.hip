@@ -651,14 +651,11 @@ static int launch_gemm_bf16x3_cfg(const GemmParams& p, int groups, hipStream_t s
   size_t lds = sizeof(float) * GM_BM * (BK + 4) + sizeof(uint16_t) * 3 * GM_BN * (BK + 8);
   const size_t epi = sizeof(float) * 4 * 32 * 68;   // staged epilogue stores (either layout)
   if (lds < epi) lds = epi;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&mlp_gemm_bf16x3_kernel<LOADER, EPI, NS, WAVES>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    configured = true;
-  }
+  // one-time, thread-safe (C++11 magic static): allow > 64 KB of dynamic LDS
+  static const hipError_t attr = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&mlp_gemm_bf16x3_kernel<LOADER, EPI, NS, WAVES>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr != hipSuccess) return (int)attr;
   const dim3 grid((unsigned)(p.mtiles * p.ntiles), (unsigned)groups);
   hipLaunchKernelGGL((mlp_gemm_bf16x3_kernel<LOADER, EPI, NS, WAVES>), grid, dim3(64 * WAVES), lds,
                      st, p);
@@ -677,14 +674,10 @@ static int launch_gemm_bf16x3(const GemmParams& p, int groups, hipStream_t st) {
 template <int LOADER, int EPI>
 static int launch_gemm(const GemmParams& p, int groups, hipStream_t st) {
   const size_t lds = sizeof(float) * 2 * (GM_BM + GM_BN) * GM_LDS;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&mlp_gemm_kernel<LOADER, EPI>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    configured = true;
-  }
+  static const hipError_t attr = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&mlp_gemm_kernel<LOADER, EPI>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr != hipSuccess) return (int)attr;
   const dim3 grid((unsigned)(p.mtiles * p.ntiles), (unsigned)groups);
   hipLaunchKernelGGL((mlp_gemm_kernel<LOADER, EPI>), grid, dim3(GM_THREADS), lds, st, p);
   S4G_LAUNCH_CHECK();
