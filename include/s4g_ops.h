@@ -222,6 +222,17 @@ int s4g_three_nn_weights_i32(const float *q_b3n1, const float *k_b3n2, int64_t B
                              int64_t N1, int64_t N2, float eps, int32_t *idx_bn3,
                              float *w_bn3, void *ws, size_t ws_bytes, int flags,
                              s4g_stream_t stream);
+/* Grid-accelerated variant of s4g_three_nn_weights_i32 for the fast path: keys are
+ * binned into cells of edge `cell` (use the set-abstraction radius of the level
+ * the keys came from), queries search 27 cells, unanswered queries fall back to
+ * the index-order scan in the same call -- identical results for every input.
+ * Workspace: s4g_three_nn_grid_workspace_bytes(B, N1, N2); N2 <= 65536. */
+size_t s4g_three_nn_grid_workspace_bytes(int64_t B, int64_t N1, int64_t N2);
+int s4g_three_nn_weights_grid_i32(const float *q_b3n1, const float *k_b3n2, int64_t B,
+                                  int64_t N1, int64_t N2, float eps, float cell,
+                                  int32_t *idx_bn3, float *w_bn3, void *ws,
+                                  size_t ws_bytes, int flags, s4g_stream_t stream);
+
 /* QueryGrouper's operator pair in one pass (modules.py:39-42):
  * ball_query + group_points(xyz, index).  Same outputs as calling
  * s4g_ball_query_f32 then s4g_group_points_f32 with C = 3: index (B,M,K) int64,

@@ -40,7 +40,7 @@
 //        QueryGrouper uses (modules.py:39-42) costs one pass over the output.
 #include <stdlib.h>
 
-#include "s4g_common.h"
+#include "grid.h"
 
 namespace s4g {
 
@@ -100,55 +100,7 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void ball_query_scan_kerne
 }
 
 // ---------------------------------------------------------------- GRID path
-constexpr int GR_DIM = 32;            // cells per axis (toroidal)
-constexpr int GR_RANGES = 8;          // z-slabs = build workgroups per scene
-constexpr int GR_RANGE_SLOTS = 4096;  // slots per slab
-constexpr int GR_START_STRIDE = GR_RANGE_SLOTS + 4;  // +1 end entry, padded to 16 B
-constexpr int GR_BUILD_THREADS = 1024;
-constexpr int GR_BUILD_U = 8;         // independent point loads in flight per lane
-constexpr int GR_COORD_LIMIT = 4096;  // |cell coordinate| bound of the exactness argument
-constexpr int GR_MAX_POINTS = 65536;  // bitmap of N bits per wave must fit LDS
-
-struct GridWs {
-  float4* sorted;  // [B][GR_RANGES * N] records (x, y, z, index bits)
-  int* starts;     // [B][GR_RANGES][GR_START_STRIDE], absolute record offsets
-  int* flags;      // [B] 1 = scene out of the exactness range -> SCAN path
-};
-
-static size_t grid_ws_bytes(int64_t B, int64_t N) {
-  return (size_t)B * ((size_t)GR_RANGES * N * sizeof(float4) +
-                      (size_t)GR_RANGES * GR_START_STRIDE * sizeof(int) + 64);
-}
-
-static GridWs grid_ws_carve(void* ws, int64_t B, int64_t N) {
-  GridWs g;
-  char* p = (char*)ws;
-  g.sorted = (float4*)p;
-  p += (size_t)B * GR_RANGES * N * sizeof(float4);
-  g.starts = (int*)p;
-  p += (size_t)B * GR_RANGES * GR_START_STRIDE * sizeof(int);
-  g.flags = (int*)p;
-  return g;
-}
-
-__device__ __forceinline__ int grid_coord(float v, float o, float inv_h) {
-  return (int)floorf(__fmul_rn(__fsub_rn(v, o), inv_h));
-}
-// false for NaN / inf / anything outside the exactness range (checked in float:
-// the int conversion saturates and abs(INT_MIN) would slip through).
-__device__ __forceinline__ bool grid_coord_ok(float v, float o, float inv_h) {
-  return fabsf(__fmul_rn(__fsub_rn(v, o), inv_h)) < (float)(GR_COORD_LIMIT - 1);
-}
-// slot = (range, local): range = y mod 8 (interleaved stripes balance thin,
-// table-top shaped clouds over the 8 build workgroups), local = z5 | y-high2 | x5.
-// Any function of (y, z) keeps the 32 x-cells of a row contiguous.
-__device__ __forceinline__ int grid_range(int yy, int zz) { (void)zz; return yy & 7; }
-__device__ __forceinline__ int grid_local_row(int yy, int zz) { return (zz << 7) | ((yy >> 3) << 5); }
-__device__ __forceinline__ int grid_slot(int cx, int cy, int cz) {
-  const int yy = cy & 31, zz = cz & 31;
-  return (grid_range(yy, zz) << 12) | grid_local_row(yy, zz) | (cx & 31);
-}
-
+// (grid layout, slot mapping and workspace carving: grid.h)
 __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
     const float* __restrict__ xyz, int N, float inv_h, GridWs ws) {
   __shared__ uint32_t hist[GR_RANGE_SLOTS];
@@ -415,6 +367,14 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void bq_grid_query_kernel(
   }
 }
 
+int launch_grid_build(const float* xyz, int64_t B, int64_t N, float inv_h, GridWs ws,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(bq_grid_build_kernel, dim3(GR_RANGES, (unsigned)B), dim3(GR_BUILD_THREADS),
+                     0, st, xyz, (int)N, inv_h, ws);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
+
 enum { BQ_AUTO = 0, BQ_SCAN = 1, BQ_GRID = 2 };
 
 static int bq_mode() {  // S4G_BQ_MODE=scan|grid|auto (tuning / test knob, read per call)
@@ -472,9 +432,7 @@ static int ball_query_dispatch(const float* xyz, const float* ctr, int64_t B,
   const GridWs g = grid_ws_carve(ws, B, N);
   const float h = radius * (1.0f + 1.0f / 256.0f);
   const float inv_h = 1.0f / h;
-  hipLaunchKernelGGL(bq_grid_build_kernel, dim3(GR_RANGES, (unsigned)B), dim3(GR_BUILD_THREADS),
-                     0, st, xyz, (int)N, inv_h, g);
-  S4G_LAUNCH_CHECK();
+  if (int rc = launch_grid_build(xyz, B, N, inv_h, g, st)) return rc;
   const int words = (int)((N + 31) / 32);
   int wpl = (words + 63) / 64;
   if ((wpl & 1) == 0) ++wpl;  // odd stride: conflict-free per-lane word runs

@@ -1,0 +1,62 @@
+// Toroidal 32^3 cell grid shared by the ball query and the 3-NN search
+// (definitions; the build kernel lives in ball_query.hip).
+#pragma once
+#include "s4g_common.h"
+
+namespace s4g {
+
+constexpr int GR_DIM = 32;            // cells per axis (toroidal)
+constexpr int GR_RANGES = 8;          // z-slabs = build workgroups per scene
+constexpr int GR_RANGE_SLOTS = 4096;  // slots per slab
+constexpr int GR_START_STRIDE = GR_RANGE_SLOTS + 4;  // +1 end entry, padded to 16 B
+constexpr int GR_BUILD_THREADS = 1024;
+constexpr int GR_BUILD_U = 8;         // independent point loads in flight per lane
+constexpr int GR_COORD_LIMIT = 4096;  // |cell coordinate| bound of the exactness argument
+constexpr int GR_MAX_POINTS = 65536;  // bitmap of N bits per wave must fit LDS
+
+struct GridWs {
+  float4* sorted;  // [B][GR_RANGES * N] records (x, y, z, index bits)
+  int* starts;     // [B][GR_RANGES][GR_START_STRIDE], absolute record offsets
+  int* flags;      // [B] 1 = scene out of the exactness range -> SCAN path
+};
+
+inline size_t grid_ws_bytes(int64_t B, int64_t N) {
+  return (size_t)B * ((size_t)GR_RANGES * N * sizeof(float4) +
+                      (size_t)GR_RANGES * GR_START_STRIDE * sizeof(int) + 64);
+}
+
+inline GridWs grid_ws_carve(void* ws, int64_t B, int64_t N) {
+  GridWs g;
+  char* p = (char*)ws;
+  g.sorted = (float4*)p;
+  p += (size_t)B * GR_RANGES * N * sizeof(float4);
+  g.starts = (int*)p;
+  p += (size_t)B * GR_RANGES * GR_START_STRIDE * sizeof(int);
+  g.flags = (int*)p;
+  return g;
+}
+
+__device__ __forceinline__ int grid_coord(float v, float o, float inv_h) {
+  return (int)floorf(__fmul_rn(__fsub_rn(v, o), inv_h));
+}
+// false for NaN / inf / anything outside the exactness range (checked in float:
+// the int conversion saturates and abs(INT_MIN) would slip through).
+__device__ __forceinline__ bool grid_coord_ok(float v, float o, float inv_h) {
+  return fabsf(__fmul_rn(__fsub_rn(v, o), inv_h)) < (float)(GR_COORD_LIMIT - 1);
+}
+// slot = (range, local): range = y mod 8 (interleaved stripes balance thin,
+// table-top shaped clouds over the 8 build workgroups), local = z5 | y-high2 | x5.
+// Any function of (y, z) keeps the 32 x-cells of a row contiguous.
+__device__ __forceinline__ int grid_range(int yy, int zz) { (void)zz; return yy & 7; }
+__device__ __forceinline__ int grid_local_row(int yy, int zz) { return (zz << 7) | ((yy >> 3) << 5); }
+__device__ __forceinline__ int grid_slot(int cx, int cy, int cz) {
+  const int yy = cy & 31, zz = cz & 31;
+  return (grid_range(yy, zz) << 12) | grid_local_row(yy, zz) | (cx & 31);
+}
+
+
+// Builds the grid of `xyz` (B,3,N) with cell edge 1/inv_h into `ws` (one launch).
+int launch_grid_build(const float* xyz, int64_t B, int64_t N, float inv_h, GridWs ws,
+                      hipStream_t st);
+
+}  // namespace s4g

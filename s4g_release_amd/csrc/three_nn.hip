@@ -12,7 +12,7 @@
 // through the scalar cache (s_load) and feed the VALU as SGPR operands -- no
 // LDS staging and no per-lane key traffic at all.  The insertion network only
 // runs when some lane of the wave needs it (wave-uniform branch).
-#include "s4g_common.h"
+#include "grid.h"
 
 namespace s4g {
 
@@ -68,6 +68,165 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(
       d2out[o + 1] = b1;
       d2out[o + 2] = b2;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// GRID path (fast path of the FP layers): the keys are binned into the same
+// toroidal cell grid the ball query uses (grid.h) and every query looks only at
+// the 27 cells around it -- ~30-100 candidates instead of all N2 keys.
+// The reference result is "the 3 smallest by (d, key index)" (strict '<' while
+// scanning keys in index order), so candidates may be visited in
+// any order as long as ties are broken on the index.  A query is DONE when it
+// has three candidates and its third distance is below (cell * (1 - 1e-3))^2:
+// every key outside the 27-cell block is at least one cell edge away, hence
+// strictly farther.  Anything else (isolated points, out-of-range scenes) goes
+// to a list that a second kernel answers with the literal index-order scan, one
+// wave per query -- so the result is exact for every input.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool nn_less(float d, int j, float bd, int bj) {
+  return d < bd || (d == bd && j < bj);
+}
+
+template <bool WEIGHTS, typename IdxT>
+__device__ __forceinline__ void nn_write(IdxT* __restrict__ idx, float* __restrict__ out, size_t o,
+                                         int i0, int i1, int i2, float b0, float b1, float b2,
+                                         float eps) {
+  idx[o + 0] = (IdxT)i0;
+  idx[o + 1] = (IdxT)i1;
+  idx[o + 2] = (IdxT)i2;
+  if constexpr (WEIGHTS) {
+    const float ia = __fdiv_rn(1.0f, b0 < eps ? eps : b0);
+    const float ib = __fdiv_rn(1.0f, b1 < eps ? eps : b1);
+    const float ic = __fdiv_rn(1.0f, b2 < eps ? eps : b2);
+    const float s = __fadd_rn(__fadd_rn(ia, ib), ic);
+    out[o + 0] = __fdiv_rn(ia, s);
+    out[o + 1] = __fdiv_rn(ib, s);
+    out[o + 2] = __fdiv_rn(ic, s);
+  } else {
+    out[o + 0] = b0;
+    out[o + 1] = b1;
+    out[o + 2] = b2;
+  }
+}
+
+template <bool FMAD, bool WEIGHTS, typename IdxT>
+__global__ __launch_bounds__(NN_THREADS) void three_nn_grid_kernel(
+    const float* __restrict__ q, const float* __restrict__ key, int N1, int N2, float inv_h,
+    float d2_done, GridWs ws, float eps, IdxT* __restrict__ idx, float* __restrict__ out,
+    int* __restrict__ fail_list, int* __restrict__ fail_count) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * NN_THREADS + threadIdx.x;
+  if (i >= N1) return;
+  const float* __restrict__ qx = q + (size_t)b * 3 * N1;
+  const float* __restrict__ kx = key + (size_t)b * 3 * N2;
+  const float x1 = qx[i], y1 = qx[N1 + i], z1 = qx[2 * N1 + i];
+  const float ox = kx[0], oy = kx[N2], oz = kx[2 * N2];
+  const bool exact = ws.flags[b] == 0 && grid_coord_ok(x1, ox, inv_h) &&
+                     grid_coord_ok(y1, oy, inv_h) && grid_coord_ok(z1, oz, inv_h);
+  float b0 = __builtin_inff(), b1 = __builtin_inff(), b2 = __builtin_inff();
+  int i0 = 0x7FFFFFFF, i1 = 0x7FFFFFFF, i2 = 0x7FFFFFFF;
+  if (exact) {
+    const int icx = grid_coord(x1, ox, inv_h), icy = grid_coord(y1, oy, inv_h),
+              icz = grid_coord(z1, oz, inv_h);
+    const float4* __restrict__ rec = ws.sorted + (size_t)b * GR_RANGES * N2;
+    const int* __restrict__ starts_b = ws.starts + (size_t)b * GR_RANGES * GR_START_STRIDE;
+    const int x0 = (icx - 1) & 31;
+    for (int r = 0; r < 9; ++r) {
+      const int zz = (icz + r / 3 - 1) & 31, yy = (icy + r % 3 - 1) & 31;
+      const int* __restrict__ st = starts_b + grid_range(yy, zz) * GR_START_STRIDE +
+                                   grid_local_row(yy, zz);
+      int beg[2], end[2];
+      if (x0 <= GR_DIM - 3) {
+        beg[0] = st[x0];
+        end[0] = st[x0 + 3];
+        beg[1] = end[1] = 0;
+      } else {
+        beg[0] = st[x0];
+        end[0] = st[GR_DIM];
+        beg[1] = st[0];
+        end[1] = st[(x0 + 3) & 31];
+      }
+#pragma unroll
+      for (int piece = 0; piece < 2; ++piece)
+        for (int j = beg[piece]; j < end[piece]; ++j) {
+          const float4 p = rec[j];
+          const int kj = __float_as_int(p.w);
+          const float d = dist2<FMAD>(p.x, p.y, p.z, x1, y1, z1);
+          if (nn_less(d, kj, b2, i2)) {
+            if (nn_less(d, kj, b1, i1)) {
+              b2 = b1;
+              i2 = i1;
+              if (nn_less(d, kj, b0, i0)) {
+                b1 = b0;
+                i1 = i0;
+                b0 = d;
+                i0 = kj;
+              } else {
+                b1 = d;
+                i1 = kj;
+              }
+            } else {
+              b2 = d;
+              i2 = kj;
+            }
+          }
+        }
+    }
+  }
+  const bool done = exact && i2 != 0x7FFFFFFF && b2 < d2_done;
+  if (done) {
+    nn_write<WEIGHTS, IdxT>(idx, out, ((size_t)b * N1 + i) * 3, i0, i1, i2, b0, b1, b2, eps);
+  } else {
+    fail_list[atomicAdd(fail_count, 1)] = b * N1 + i;
+  }
+}
+
+// One wave per unanswered query: lanes stride the keys, each keeps its own
+// (d, index)-ordered triple, three wave-argmin rounds merge them.
+template <bool FMAD, bool WEIGHTS, typename IdxT>
+__global__ __launch_bounds__(NN_THREADS) void three_nn_fallback_kernel(
+    const float* __restrict__ q, const float* __restrict__ key, int N1, int N2, float eps,
+    IdxT* __restrict__ idx, float* __restrict__ out, const int* __restrict__ fail_list,
+    const int* __restrict__ fail_count) {
+  const int lane = threadIdx.x & 63;
+  const int wave0 = blockIdx.x * (NN_THREADS / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (NN_THREADS / 64);
+  const int count = *fail_count;
+  for (int f = wave0; f < count; f += nwaves) {
+    const int qi = fail_list[f];
+    const int b = qi / N1, i = qi - b * N1;
+    const float* __restrict__ qx = q + (size_t)b * 3 * N1;
+    const float* __restrict__ kx = key + (size_t)b * 3 * N2;
+    const float x1 = qx[i], y1 = qx[N1 + i], z1 = qx[2 * N1 + i];
+    float b0 = __builtin_inff(), b1 = __builtin_inff(), b2 = __builtin_inff();
+    int i0 = 0x7FFFFFFF, i1 = 0x7FFFFFFF, i2 = 0x7FFFFFFF;
+    for (int j = lane; j < N2; j += 64) {
+      const float d = dist2<FMAD>(kx[j], kx[N2 + j], kx[2 * N2 + j], x1, y1, z1);
+      if (nn_less(d, j, b2, i2)) {
+        if (nn_less(d, j, b1, i1)) {
+          b2 = b1; i2 = i1;
+          if (nn_less(d, j, b0, i0)) { b1 = b0; i1 = i0; b0 = d; i0 = j; }
+          else { b1 = d; i1 = j; }
+        } else { b2 = d; i2 = j; }
+      }
+    }
+    float rd[3];
+    int rj[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      // wave-wide minimum of the lanes' heads by (d, index); d >= 0 so its bits order like u32
+      const uint32_t dm = wave_min_u32(__float_as_uint(b0));
+      const uint32_t jm = wave_min_u32(__float_as_uint(b0) == dm ? (uint32_t)i0 : 0xFFFFFFFFu);
+      rd[k] = __uint_as_float(dm);
+      rj[k] = (int)jm;
+      if (__float_as_uint(b0) == dm && (uint32_t)i0 == jm) {  // pop this lane's head
+        b0 = b1; i0 = i1; b1 = b2; i1 = i2; b2 = __builtin_inff(); i2 = 0x7FFFFFFF;
+      }
+    }
+    if (lane == 0)
+      nn_write<WEIGHTS, IdxT>(idx, out, ((size_t)b * N1 + i) * 3, rj[0], rj[1], rj[2], rd[0], rd[1],
+                              rd[2], eps);
   }
 }
 
@@ -139,6 +298,55 @@ extern "C" int s4g_three_nn_weights_i32(const float* q_b3n1, const float* k_b3n2
     hipLaunchKernelGGL((s4g::three_nn_kernel<false, true, int32_t>), grid,
                        dim3(s4g::NN_THREADS), 0, st, q_b3n1, k_b3n2, (int)N1,
                        (int)N2, eps, idx_bn3, w_bn3);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
+
+extern "C" size_t s4g_three_nn_grid_workspace_bytes(int64_t B, int64_t N1, int64_t N2) {
+  return s4g::grid_ws_bytes(B, N2) + sizeof(int) * ((size_t)B * N1 + 16);
+}
+
+extern "C" int s4g_three_nn_weights_grid_i32(const float* q_b3n1, const float* k_b3n2,
+                                             int64_t B, int64_t N1, int64_t N2, float eps,
+                                             float cell, int32_t* idx_bn3, float* w_bn3,
+                                             void* ws, size_t ws_bytes, int flags,
+                                             s4g_stream_t stream) {
+  using namespace s4g;
+  if (B < 0 || N1 < 0 || N2 < 3 || B > 65535 || N2 > GR_MAX_POINTS || N1 >= (1ll << 31) ||
+      !(cell > 0.f) || !(cell < 1e18f))
+    return S4G_EINVAL;
+  if (B == 0 || N1 == 0) return S4G_OK;
+  if (!q_b3n1 || !k_b3n2 || !idx_bn3 || !w_bn3 || !ws) return S4G_EINVAL;
+  if (ws_bytes < s4g_three_nn_grid_workspace_bytes(B, N1, N2)) return S4G_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const GridWs g = grid_ws_carve(ws, B, N2);
+  int* fail_count = reinterpret_cast<int*>((char*)ws + grid_ws_bytes(B, N2));
+  int* fail_list = fail_count + 16;
+  hipError_t e = hipMemsetAsync(fail_count, 0, sizeof(int), st);
+  if (e != hipSuccess) return (int)e;
+  const float inv_h = 1.0f / cell;
+  if (int rc = launch_grid_build(k_b3n2, B, N2, inv_h, g, st)) return rc;
+  const float edge = cell * (1.0f - 1e-3f);
+  const float d2_done = edge * edge;
+  const dim3 grid((unsigned)((N1 + NN_THREADS - 1) / NN_THREADS), (unsigned)B);
+  const bool fmad = (flags & S4G_FLAG_FMAD) != 0;
+  if (fmad)
+    hipLaunchKernelGGL((three_nn_grid_kernel<true, true, int32_t>), grid, dim3(NN_THREADS), 0, st,
+                       q_b3n1, k_b3n2, (int)N1, (int)N2, inv_h, d2_done, g, eps, idx_bn3, w_bn3,
+                       fail_list, fail_count);
+  else
+    hipLaunchKernelGGL((three_nn_grid_kernel<false, true, int32_t>), grid, dim3(NN_THREADS), 0, st,
+                       q_b3n1, k_b3n2, (int)N1, (int)N2, inv_h, d2_done, g, eps, idx_bn3, w_bn3,
+                       fail_list, fail_count);
+  S4G_LAUNCH_CHECK();
+  if (fmad)
+    hipLaunchKernelGGL((three_nn_fallback_kernel<true, true, int32_t>), dim3(512), dim3(NN_THREADS),
+                       0, st, q_b3n1, k_b3n2, (int)N1, (int)N2, eps, idx_bn3, w_bn3, fail_list,
+                       fail_count);
+  else
+    hipLaunchKernelGGL((three_nn_fallback_kernel<false, true, int32_t>), dim3(512),
+                       dim3(NN_THREADS), 0, st, q_b3n1, k_b3n2, (int)N1, (int)N2, eps, idx_bn3,
+                       w_bn3, fail_list, fail_count);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }

@@ -289,6 +289,29 @@ def _interpolate_backward(grad_output, index, weight, num_inst):
     return gin
 
 
+def three_nn_weights_grid(query_xyz, key_xyz, cell, eps=1e-10):
+    """Fast-path 3-NN: (index (B,N1,3) int32, interpolation weights (B,N1,3) fp32) through
+    the cell-grid kernel (`s4g_three_nn_weights_grid_i32`); bit-identical to
+    `search_nn_distance` + `interp_weights` for every input (unanswered queries fall back
+    to the index-order scan inside the call).  `cell` = grid edge, e.g. the SA radius."""
+    query_xyz = _f32c(query_xyz, "query_xyz")
+    key_xyz = _f32c(key_xyz, "key_xyz")
+    B, _, N1 = query_xyz.shape
+    N2 = key_xyz.size(2)
+    if not N2 >= 3:
+        raise RuntimeError("num_key is not greater than or equal to num_neighbours")
+    idx = torch.empty((B, N1, 3), dtype=torch.int32, device=query_xyz.device)
+    w = torch.empty((B, N1, 3), dtype=torch.float32, device=query_xyz.device)
+    with torch.cuda.device(query_xyz.device):
+        nbytes = _cabi.lib().s4g_three_nn_grid_workspace_bytes(B, N1, N2)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=query_xyz.device)
+        rc = _cabi.lib().s4g_three_nn_weights_grid_i32(_ptr(query_xyz), _ptr(key_xyz), B, N1, N2,
+                                                       float(eps), float(cell), _ptr(idx), _ptr(w),
+                                                       _ptr(ws), nbytes, _DIST_FLAGS, _stream())
+    _cabi.check(rc, "three_nn_weights_grid")
+    return idx, w
+
+
 def interp_weights(distance, eps=1e-10):
     """Inverse-distance weights of FeatureInterpolator.forward (modules.py:118-120)
     in one launch instead of three elementwise ones."""

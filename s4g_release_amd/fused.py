@@ -221,11 +221,22 @@ class FusedPointNet2:
         _cabi.check(rc, "ball_query_i32")
         return idx, cnt
 
-    def _three_nn(self, q, k, eps):
+    def _three_nn(self, q, k, eps, cell=0.0):
         B, _, N1 = q.shape
         N2 = k.shape[2]
         idx = torch.empty((B, N1, 3), dtype=torch.int32, device=q.device)
         w = torch.empty((B, N1, 3), dtype=torch.float32, device=q.device)
+        if cell > 0.0 and 2048 <= N2 <= 65536 and os.environ.get("S4G_NN_MODE", "grid") != "scan":
+            # keys are the centroids of an SA level: its ball radius is the natural cell edge
+            nbytes = _cabi.lib().s4g_three_nn_grid_workspace_bytes(B, N1, N2)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+            with _F._timed("three_nn[N1=%d,N2=%d]" % (N1, N2), B * (12 * N2 + 12 * N1 + 24 * N1 + 12 * N1)):
+                rc = _cabi.lib().s4g_three_nn_weights_grid_i32(q.data_ptr(), k.data_ptr(), B, N1, N2,
+                                                               eps, cell, idx.data_ptr(),
+                                                               w.data_ptr(), ws.data_ptr(), nbytes,
+                                                               _F._DIST_FLAGS, _F._stream())
+            _cabi.check(rc, "three_nn_weights_grid_i32")
+            return idx, w
         with _F._timed("three_nn[N1=%d,N2=%d]" % (N1, N2), B * (12 * N2 + 12 * N1 + 24 * N1 + 12 * N1)):
             rc = _cabi.lib().s4g_three_nn_weights_i32(q.data_ptr(), k.data_ptr(), B, N1, N2, eps,
                                                       idx.data_ptr(), w.data_ptr(), None, 0,
@@ -253,7 +264,9 @@ class FusedPointNet2:
         sparse_xyz = geo["level_xyz"][-1]
         for fi, fp in enumerate(self.fp):
             dense_xyz = geo["level_xyz"][-2 - fi]
-            geo["fp"].append(self._three_nn(dense_xyz, sparse_xyz, fp["eps"]))
+            # the keys of FP layer fi are the centroids of SA layer (n_sa - 1 - fi)
+            cell = self.sa[len(self.sa) - 1 - fi]["radius"] if fi < len(self.sa) else 0.0
+            geo["fp"].append(self._three_nn(dense_xyz, sparse_xyz, fp["eps"], cell))
             sparse_xyz = dense_xyz
         return geo
 

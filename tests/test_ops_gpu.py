@@ -199,6 +199,35 @@ def test_three_nn_matches_oracle(F, oracle, dev, N1, N2):
     assert torch.equal(i2, idx) and torch.equal(dd, d2)
 
 
+@pytest.mark.parametrize("variant,N1,N2,cell", [
+    ("tabletop-v1", 25600, 5120, 0.02),     # FP3 of the shipped config
+    ("tabletop-v1", 5120, 2048, 0.08),
+    ("dup-heavy", 25600, 5120, 0.02),       # exact distance ties between distinct keys
+    ("uniform-box", 25600, 5120, 0.02),     # sparse: most queries need the fallback scan
+    ("tabletop-v1", 25600, 5120, 0.004),    # cell far too small: everything falls back
+    ("tabletop-v1", 25600, 5120, 0.5),      # cell as big as the scene: all keys are candidates
+])
+def test_three_nn_grid_matches_oracle(F, oracle, dev, variant, N1, N2, cell):
+    pts = synth.make_batch([1, 8], N1, variant=variant)
+    keys = oracle.gather_points(pts, oracle.fps(pts, N2))
+    pts[1, :, 5] = (9.0, 9.0, 9.0)           # an isolated query far from every key
+    idx, w = F.three_nn_weights_grid(_t(pts, dev), _t(keys, dev), cell)
+    ridx, rd2 = oracle.three_nn(pts, keys)
+    assert idx.dtype == torch.int32
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), ridx)
+    assert np.array_equal(w.cpu().numpy(), oracle.interp_weights(rd2))
+
+
+def test_three_nn_grid_out_of_range_scene(F, oracle, dev):
+    pts = synth.make_batch([2, 3], 6000)
+    keys = oracle.gather_points(pts, oracle.fps(pts, 2500))
+    keys[0, 0, 100] += 400.0                  # > 4096 cells from the origin: whole scene falls back
+    idx, w = F.three_nn_weights_grid(_t(pts, dev), _t(keys, dev), 0.05)
+    ridx, rd2 = oracle.three_nn(pts, keys)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), ridx)
+    assert np.array_equal(w.cpu().numpy(), oracle.interp_weights(rd2))
+
+
 def test_three_nn_ties_and_errors(F, oracle, dev):
     rng = np.random.default_rng(3)
     q, k = _quantized(rng, 2, 300), _quantized(rng, 2, 40)
