@@ -58,6 +58,9 @@ def main():
         for name, q, k in (("3nn 25600<-5120", pts, c1), ("3nn 5120<-1024", c1, c2)):
             ms = timeit(lambda: F.search_nn_distance(q, k, 3))
             print("%-28s B=%d  %9.3f ms" % (name, B, ms))
+        ms = timeit(lambda: F.three_nn_weights_grid(pts, c1, 0.02))
+        nb = B * (12 * 5120 + 12 * 25600 + 24 * 25600 + 12 * 25600)
+        print("%-28s B=%d  %9.3f ms   %.1f GB/s alg" % ("3nn grid 25600<-5120", B, ms, nb / ms / 1e6))
     if "interp" in ops:
         feat = torch.randn(B, 512, 5120, device=dev)
         i3, d3 = F.search_nn_distance(pts, c1, 3)
