@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void ball_query_scan_kerne
 // ---------------------------------------------------------------- GRID path
 // (grid layout, slot mapping and workspace carving: grid.h)
 __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
-    const float* __restrict__ xyz, int N, float inv_h, GridWs ws) {
+    const float* __restrict__ xyz, int N, float inv_h, GridWs ws, int write_aos) {
   __shared__ uint32_t hist[GR_RANGE_SLOTS];
   __shared__ uint32_t wsum[GR_BUILD_THREADS / 64];
   const int b = blockIdx.y;
@@ -184,6 +184,7 @@ __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
     for (int u = 0; u < GR_BUILD_U; ++u) {
       const int j = j0 + u * GR_BUILD_THREADS;
       if (j < N) {
+        if (g == 0 && write_aos) ws.xyz4[(size_t)b * N + j] = make_float4(x[u], y[u], z[u], 0.f);
         const int slot = grid_slot(grid_coord(x[u], ox, inv_h), grid_coord(y[u], oy, inv_h),
                                    grid_coord(z[u], oz, inv_h));
         if ((slot >> 12) == g) {
@@ -357,20 +358,22 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void bq_grid_query_kernel(
       // group_points(xyz, index) for this centroid: out[b][c][m][k] = xyz[b][c][idx]
       const size_t MK = (size_t)M * K;
       float* __restrict__ gx = grouped + (size_t)b * 3 * MK + (size_t)m * K;
+      const float4* __restrict__ p4 = ws.xyz4 + (size_t)b * N;
       for (int k = lane; k < K; k += 64) {
         const int v = in_lds ? row[k] : (int)out_row[k];
-        gx[k] = px[v];
-        gx[MK + k] = py[v];
-        gx[2 * MK + k] = pz[v];
+        const float4 p = p4[v];   // one 16-byte gather instead of three 4-byte ones
+        gx[k] = p.x;
+        gx[MK + k] = p.y;
+        gx[2 * MK + k] = p.z;
       }
     }
   }
 }
 
 int launch_grid_build(const float* xyz, int64_t B, int64_t N, float inv_h, GridWs ws,
-                      hipStream_t st) {
+                      hipStream_t st, bool write_aos) {
   hipLaunchKernelGGL(bq_grid_build_kernel, dim3(GR_RANGES, (unsigned)B), dim3(GR_BUILD_THREADS),
-                     0, st, xyz, (int)N, inv_h, ws);
+                     0, st, xyz, (int)N, inv_h, ws, write_aos ? 1 : 0);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }
@@ -432,7 +435,7 @@ static int ball_query_dispatch(const float* xyz, const float* ctr, int64_t B,
   const GridWs g = grid_ws_carve(ws, B, N);
   const float h = radius * (1.0f + 1.0f / 256.0f);
   const float inv_h = 1.0f / h;
-  if (int rc = launch_grid_build(xyz, B, N, inv_h, g, st)) return rc;
+  if (int rc = launch_grid_build(xyz, B, N, inv_h, g, st, grouped != nullptr)) return rc;
   const int words = (int)((N + 31) / 32);
   int wpl = (words + 63) / 64;
   if ((wpl & 1) == 0) ++wpl;  // odd stride: conflict-free per-lane word runs

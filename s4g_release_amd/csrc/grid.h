@@ -18,11 +18,13 @@ struct GridWs {
   float4* sorted;  // [B][GR_RANGES * N] records (x, y, z, index bits)
   int* starts;     // [B][GR_RANGES][GR_START_STRIDE], absolute record offsets
   int* flags;      // [B] 1 = scene out of the exactness range -> SCAN path
+  float4* xyz4;    // [B][N] index-ordered (x, y, z, 0) copy: one 16-byte gather per neighbour
 };
 
 inline size_t grid_ws_bytes(int64_t B, int64_t N) {
   return (size_t)B * ((size_t)GR_RANGES * N * sizeof(float4) +
-                      (size_t)GR_RANGES * GR_START_STRIDE * sizeof(int) + 64);
+                      (size_t)GR_RANGES * GR_START_STRIDE * sizeof(int) + 64 +
+                      (size_t)N * sizeof(float4));
 }
 
 inline GridWs grid_ws_carve(void* ws, int64_t B, int64_t N) {
@@ -33,6 +35,8 @@ inline GridWs grid_ws_carve(void* ws, int64_t B, int64_t N) {
   g.starts = (int*)p;
   p += (size_t)B * GR_RANGES * GR_START_STRIDE * sizeof(int);
   g.flags = (int*)p;
+  p += (size_t)B * 64;
+  g.xyz4 = (float4*)p;
   return g;
 }
 
@@ -55,8 +59,9 @@ __device__ __forceinline__ int grid_slot(int cx, int cy, int cz) {
 }
 
 
-// Builds the grid of `xyz` (B,3,N) with cell edge 1/inv_h into `ws` (one launch).
+// Builds the grid of `xyz` (B,3,N) with cell edge 1/inv_h into `ws` (one launch);
+// write_aos also fills ws.xyz4 (only the fused query+group epilogue reads it).
 int launch_grid_build(const float* xyz, int64_t B, int64_t N, float inv_h, GridWs ws,
-                      hipStream_t st);
+                      hipStream_t st, bool write_aos = false);
 
 }  // namespace s4g
