@@ -139,7 +139,8 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(
 #pragma unroll
     for (int p = 0; p < PPT; ++p) {
       const float d = dist2<FMAD>(cx, cy, cz, x[p], y[p], z[p]);
-      const float m = (d < md[p]) ? d : md[p];
+      float m;  // one v_min_f32 (== (d < md) ? d : md for the non-NaN contract; fminf adds a canonicalising v_max)
+      asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(d), "v"(md[p]));
       md[p] = m;
       if (m > best) {
         best = m;
