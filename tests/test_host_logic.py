@@ -1,0 +1,70 @@
+"""CPU tests of the host-side logic of the fast path (no kernels involved):
+BatchNorm folding, the exact 3-way bf16 split, K permutation / padding of the
+packed weights, and the GEMM descriptor's ABI layout."""
+import ctypes
+
+import numpy as np
+import torch
+
+from s4g_release_amd import _cabi
+from s4g_release_amd.fused import _pad_k, fold_conv_bn, split_bf16x3
+from s4g_release_amd.model import PointNet2, randomize_bn_
+from s4g_release_amd.nn_utils import Conv1d, Conv2d
+
+
+def test_fold_conv_bn_equals_conv_then_bn_eval():
+    torch.manual_seed(0)
+    for blk, shape in ((Conv1d(7, 5, 1), (2, 7, 11)), (Conv2d(4, 6, 1), (2, 4, 3, 5))):
+        blk.bn.weight.data.uniform_(0.5, 1.5)
+        blk.bn.bias.data.normal_()
+        blk.bn.running_mean.normal_()
+        blk.bn.running_var.uniform_(0.5, 2.0)
+        blk.eval()
+        x = torch.randn(*shape)
+        ref = blk(x.clone())
+        w, b = fold_conv_bn(blk)
+        y = torch.einsum("oc,bc...->bo...", w, x) + b.view(1, -1, *([1] * (x.dim() - 2)))
+        assert torch.allclose(torch.relu(y), ref, atol=1e-5)
+
+
+def test_split_bf16x3_is_exact():
+    g = torch.Generator().manual_seed(1)
+    w = torch.cat([torch.randn(4000, generator=g), torch.randn(4000, generator=g) * 1e-6,
+                   torch.randn(4000, generator=g) * 1e6, torch.tensor([0.0, 1.0, -1.0, 3.1415927])])
+    planes = split_bf16x3(w)
+    assert planes.dtype == torch.bfloat16 and planes.shape == (3, w.numel())
+    back = planes[0].double() + planes[1].double() + planes[2].double()
+    assert torch.equal(back, w.double())            # 8 + 8 + 8 significand bits: nothing lost
+    assert (planes[1].float().abs() <= planes[0].float().abs() * 2.0 ** -7 + 1e-45).all()
+
+
+def test_pad_k_and_sa_weight_permutation():
+    w = torch.arange(2 * 11, dtype=torch.float32).view(2, 11)
+    p = _pad_k(w)
+    assert p.shape == (2, 16) and torch.equal(p[:, :11], w) and (p[:, 11:] == 0).all()
+    # SA first layers: reference K order [xyz(3), feat(C)] -> ours [feat(C), xyz(3)]
+    perm = torch.cat([w[:, 3:], w[:, :3]], dim=1)
+    assert torch.equal(perm[:, -3:], w[:, :3]) and torch.equal(perm[:, :8], w[:, 3:])
+
+
+def test_gemm_desc_matches_the_c_struct_layout():
+    d = _cabi.GemmDesc
+    # natural alignment as the C compiler lays out s4g_gemm_desc_t (include/s4g_ops.h)
+    assert d.W.offset == 32 and d.bias.offset == 40 and d.A.offset == 56
+    assert d.gidx.offset % 8 == 0 and d.cf_ptr.offset % 8 == 0
+    assert d.W_bf16x3.offset % 8 == 0 and d.mlp1_w.offset == d.W_bf16x3.offset + 8
+    assert ctypes.sizeof(d) % 8 == 0
+
+
+def test_randomize_bn_is_deterministic_and_nontrivial():
+    cfg = dict(score_classes=3, num_centroids=(8, 4, 2), radius=(0.1, 0.2, 0.4),
+               num_neighbours=(16, 16, 16), sa_channels=((8, 8), (8, 8), (8, 8)),
+               fp_channels=((8, 8), (8, 8), (8, 8)), num_fp_neighbours=(3, 3, 3),
+               seg_channels=(8, 8), num_removal_directions=5, dropout_prob=0.5)
+    torch.manual_seed(3)
+    a = randomize_bn_(PointNet2(**cfg), 4).state_dict()
+    torch.manual_seed(3)
+    b = randomize_bn_(PointNet2(**cfg), 4).state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    k = "sa_modules.0.mlp.0.bn.running_var"
+    assert not torch.allclose(a[k], torch.ones_like(a[k]))
