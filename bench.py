@@ -41,7 +41,7 @@ GFLOP_PER_SCENE = 203.48       # SURVEY.md Appendix B (BN folded, 2*MAC)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16, help="scenes per GPU per step")
     ap.add_argument("--points", type=int, default=25600)
@@ -52,8 +52,8 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="collect each batch before submitting the next")
     ap.add_argument("--variant", default="tabletop-v1")
-    ap.add_argument("--precision", default=None, choices=["bf16x3", "fp32", "bf16"],
-                    help="contraction arithmetic of the fast path (default bf16x3 = fp32-equivalent); "
+    ap.add_argument("--precision", default=None, choices=["f16x2", "bf16x3", "fp32", "bf16"],
+                    help="contraction arithmetic of the fast path (default f16x2 = fp32-class); "
                          "'bf16' is the reduced-precision roofline configuration, not the headline")
     return ap.parse_args()
 
@@ -235,6 +235,18 @@ def main():
                               "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
                               "frac": round(dense_tf / BF16_MFMA_PEAK_TF, 4),
                               "ms_per_step": round(gemm_ms, 3)}
+        elif getattr(runner, "precision", "fp32") == "f16x2":
+            # three fp16 MFMA products per fp32-equivalent product: price the flops the
+            # matrix cores actually execute against the dense fp16 peak (= the bf16 one).
+            roofline_dense = {"kernel": "mlp_gemm_f16x2_kernel (v_mfma_f32_32x32x16_f16, 3 products "
+                                        "per fp32-equivalent product), all launches of one step",
+                              "bound": "mfma", "achieved": round(3 * dense_tf, 1),
+                              "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                              "frac": round(3 * dense_tf / BF16_MFMA_PEAK_TF, 4),
+                              "fp32_equivalent_TFLOPs": round(dense_tf, 2),
+                              "fp32_equivalent_vs_fp32_mfma_peak": round(dense_tf / FP32_MFMA_PEAK_TF, 4),
+                              "GFLOP_per_step_fp32_equivalent": round(gemm_flops / 1e9, 1),
+                              "ms_per_step": round(gemm_ms, 3)}
         elif getattr(runner, "precision", "fp32") == "bf16x3":
             # six bf16 MFMA products per fp32-equivalent product: price the flops the
             # matrix cores actually execute against the dense bf16 peak.
@@ -262,7 +274,7 @@ def main():
                           "frac": round(dense_tf / FP32_MFMA_PEAK_TF, 4)}
 
     roofline_dense["traffic"] = None
-    if dense_traffic and getattr(runner, "precision", "") == "bf16x3":
+    if dense_traffic and getattr(runner, "precision", "") in ("bf16x3", "f16x2"):
         roofline_dense["traffic"] = dense_traffic[0]
         roofline_dense["traffic_source"] = dense_traffic[1]
         roofline_dense["traffic_unit"] = "bytes per step (all contraction launches)"
@@ -294,7 +306,8 @@ def main():
         "dtype": "bf16" if getattr(runner, "precision", "") == "bf16" else "f32", "data": "synthetic",
         "config": {"workload": "S4G PN2_CLS forward (3 SA + 3 FP + 4 heads), %d scenes/GPU/step, "
                                "%d-pt %s clouds, fp32 (%s), impl=%s%s" % (B, args.points, args.variant,
-                                                                      {"bf16x3": "contraction as exact 3xbf16 split, fp32 accumulate",
+                                                                      {"f16x2": "contraction as scaled 2xfp16 split, 3 MFMA products, fp32 accumulate",
+                                                                       "bf16x3": "contraction as exact 3xbf16 split, fp32 accumulate",
                                                                        "bf16": "REDUCED PRECISION: plain bf16 contraction",
                                                                        "fp32": "fp32 MFMA"}.get(
                                                                           getattr(runner, "precision", ""), "library GEMM"),

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define S4G_ABI_VERSION 1
+#define S4G_ABI_VERSION 2
 
 #define S4G_OK 0
 #define S4G_EINVAL (-1)     /* bad size / null pointer */
@@ -167,6 +167,7 @@ int s4g_interp_weights_f32(const float *d2_bn3, int64_t B, int64_t N1,
 #define S4G_GEMM_FP32 0
 #define S4G_GEMM_BF16X3 1
 #define S4G_GEMM_BF16 2 /* reduced precision: one bf16 product, fp32 accumulate */
+#define S4G_GEMM_F16X2 3 /* fp32-class: two fp16 planes per operand, three products */
 
 typedef struct s4g_gemm_desc {
   int32_t loader, epilogue, groups, relu;
@@ -205,6 +206,25 @@ typedef struct s4g_gemm_desc {
   int32_t precision, Kpad16;
   const void *W_bf16x3;
   const float *mlp1_w; /* GATHER_MLP1: (Cin, 4) = wx, wy, wz, bias */
+  /* S4G_GEMM_F16X2 (ABI >= 2): every fp32 operand x is scaled by a power of two
+   * s into fp16's range and split x*s = x1 + x2 (two fp16, round-to-nearest:
+   * 22 significand bits); three v_mfma_f32_32x32x16_f16 per step evaluate
+   * a1*w1 + (a1*w2 + a2*w1) with fp32 accumulation -- the error of a plain
+   * fp32 dot product, at half the MFMA count of BF16X3.
+   *   W_f16x2      [2][groups][Cout][Kpad16] fp16 planes of W[n][:] / w_inv_scale[n]
+   *   w_inv_scale  [groups][Cout] power-of-two 1/s per output channel
+   *   a_amax(2)    NULL or 64 floats whose maximum bounds |A| (two pointers: the
+   *                INTERP loader reads two tensors); a_amax_floor >= 0 is a host
+   *                side bound joined with them (ball radius for the GATHER xyz
+   *                columns, the MLP1 bound) -- at least one must be positive
+   *   out_amax     NULL or 64 uint32 slots (zeroed by the caller before the
+   *                launch): receives atomicMax(bits of max |out|), the a_amax of
+   *                the next layer. */
+  const void *W_f16x2;
+  const float *w_inv_scale;
+  const float *a_amax, *a_amax2;
+  float a_amax_floor;
+  float *out_amax;
 } s4g_gemm_desc_t;
 
 int s4g_mlp_gemm_f32(const s4g_gemm_desc_t *desc, s4g_stream_t stream);

@@ -58,11 +58,19 @@ __device__ __forceinline__ void fps_block_exchange(FpsSlot* slots, int wave,
   __syncthreads();
   const FpsSlot s = slots[lane & (WAVES - 1)];
   const uint32_t bmax = row16_max_u32(s.d);
-  const uint32_t cand = (s.d == bmax) ? s.tie : 0xFFFFFFFFu;
-  const uint32_t btie = row16_min_u32(cand);
-  const uint64_t win = __ballot(s.d == bmax && s.tie == btie);
+  // lanes 0..WAVES-1 hold the distinct slots; a unique maximum (the usual
+  // case) needs no tie reduction
+  uint64_t win = __ballot(s.d == bmax) & ((1ull << WAVES) - 1ull);
+  uint32_t btie;
+  if (__popcll(win) > 1) {
+    const uint32_t cand = (s.d == bmax) ? s.tie : 0xFFFFFFFFu;
+    btie = __builtin_amdgcn_readlane(row16_min_u32(cand), 0);
+    win = __ballot(s.d == bmax && s.tie == btie);
+  } else {
+    btie = __builtin_amdgcn_readlane(s.tie, __ffsll((unsigned long long)win) - 1);
+  }
   const int wl = __ffsll((unsigned long long)win) - 1;  // lane < 16, uniform
-  cur = (int)(__builtin_amdgcn_readlane(btie, 0) & FPS_JMASK);
+  cur = (int)(btie & FPS_JMASK);
   cx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.x), wl));
   cy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.y), wl));
   cz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.z), wl));
@@ -152,8 +160,14 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(
     const uint32_t tie = rkey | jbest;
     const uint32_t dbits = __float_as_uint(best);
     const uint32_t wmax = wave_max_u32(dbits);
-    const uint32_t wtie = wave_min_u32((dbits == wmax) ? tie : 0xFFFFFFFFu);
-    const uint64_t win = __ballot(dbits == wmax && tie == wtie);
+    uint64_t win = __ballot(dbits == wmax);
+    uint32_t wtie;
+    if (__popcll(win) > 1) {  // exact tie inside the wave: reference tie rule
+      wtie = wave_min_u32((dbits == wmax) ? tie : 0xFFFFFFFFu);
+      win = __ballot(dbits == wmax && tie == wtie);
+    } else {
+      wtie = __builtin_amdgcn_readlane(tie, __ffsll((unsigned long long)win) - 1);
+    }
     const int wl = __ffsll((unsigned long long)win) - 1;
     const int pw = __builtin_amdgcn_readlane(bestp, wl);
     // coordinates of this wave's candidate: static register index per case.
@@ -268,8 +282,11 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
   if (variant == 1024) {
     S4G_FPS_CASE(1024, 25)
   }
-  S4G_FPS_CASE(1024, 1)
-  S4G_FPS_CASE(1024, 2)
+  // small levels: fewer waves = cheaper exchange (measured: 512x2 beats 1024x1 at N=1024)
+  S4G_FPS_CASE(256, 1)
+  S4G_FPS_CASE(512, 1)
+  S4G_FPS_CASE(512, 2)
+  S4G_FPS_CASE(512, 5)
   S4G_FPS_CASE(512, 10)
   S4G_FPS_CASE(512, 20)
   S4G_FPS_CASE(512, 32)

@@ -86,6 +86,15 @@ struct GemmParams {
   int Kpad16;
   int bf16_single;  // 1: plain bf16 contraction (hi planes only), reduced precision
   size_t w3_plane;  // elements between planes
+  // f16x2 path: W split into two fp16 planes of W * w_scale[n] (power-of-two
+  // per-channel scales), activations scaled by a power of two derived from
+  // the running maxima below so that both fit fp16's range
+  const uint16_t* Wh2;         // [2][groups][Cout][Kpad16] fp16
+  const float* w_inv_scale;    // [groups][Cout]
+  const float* a_amax;         // 64 slots or NULL
+  const float* a_amax2;        // 64 slots or NULL
+  float a_amax_floor;
+  uint32_t* out_amax;          // 64 slots or NULL
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -645,6 +654,258 @@ __global__ __launch_bounds__(64 * WAVES, (NS == 1 && WAVES == 4 && LOADER != LOA
   gemm_epilogue<EPI, NCB>(p, acc, bg, g, p0, n0, wave, wr, wc, li, lh, smemf);
 }
 
+// ---------------------------------------------------------------------------
+// f16x2 variant: fp32-class contraction in THREE fp16 MFMAs per 16-deep step.
+//
+// fp16 carries 11 significand bits, so two planes hold 22 of fp32's 24:
+//   xs = x * s (s a power of two bringing the tensor's max below 2^15),
+//   x1 = fp16(xs), x2 = fp16(xs - x1)           (both round-to-nearest-even)
+//   a*b ~= (a1*b1 + (a1*b2 + a2*b1)) / (s_a s_b)
+// The representation error is 2^-22 |x| per operand and the dropped a2*b2 term
+// is below 2^-22 |a||b|: against fp64 the result is as accurate as a plain
+// fp32 dot product (rms 2.9e-8 vs 2.8e-8 of sum|a||b| at K=128..1024, see
+// tests/test_fused_gpu.py), at half the matrix-pipe time of the bf16x3 form.
+// Scales: W per output channel, fixed on the host; activations per tensor,
+// from the maximum the PRODUCING launch left in `out_amax` (64 atomicMax
+// slots) -- no extra pass over the data.  Elements below 2^-18 of the
+// tensor's maximum start losing low-order bits (fp16 subnormals of the second
+// plane), which is far under the fp32 round-off of any sum they take part in.
+// A is split once per workgroup while it is staged into LDS as two fp16
+// planes (same LDS bytes as fp32); W arrives pre-split.
+// ---------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int GH_STR = 40;  // halves per LDS row (32 + 8: conflict-free b128 reads)
+
+__device__ __forceinline__ uint32_t pack_h2(float a, float b) {
+  f16x2 v;
+  v.x = (_Float16)a;
+  v.y = (_Float16)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+template <bool CLAMP>
+__device__ __forceinline__ void split2_h(const float4 v, float s, uint2& h, uint2& l) {
+  float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+  float r[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if constexpr (CLAMP) x[e] = __builtin_amdgcn_fmed3f(x[e], -65504.f, 65504.f);
+    r[e] = x[e] - (float)(_Float16)x[e];
+  }
+  h.x = pack_h2(x[0], x[1]);
+  h.y = pack_h2(x[2], x[3]);
+  l.x = pack_h2(r[0], r[1]);
+  l.y = pack_h2(r[2], r[3]);
+}
+
+__device__ __forceinline__ float amax_slots(const float* __restrict__ slots, int lane) {
+  return __uint_as_float(wave_max_u32(__float_as_uint(slots[lane])));
+}
+
+// NCB = 32-wide column blocks per wave: 2 -> 128 x 128 tile (three workgroups per
+// CU), 4 -> 128 x 256 tile, wave tile 64 x 128 (two workgroups per CU): 25 % less
+// LDS and L1 traffic per MFMA and twice the matrix work per barrier; used when
+// Cout > 128.
+template <int LOADER, int EPI, int NCB>
+__global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP) ? 2 : 3) void mlp_gemm_f16x2_kernel(
+    const GemmParams p) {
+  constexpr int BN = 64 * NCB;
+  constexpr int RPT = 4, RS = 32, WPT = BN / 64, WRS = 64, BK = 32;
+  constexpr int APLANE = GM_BM * GH_STR;  // halves per A plane
+  constexpr int WPLANE = BN * GH_STR;     // halves per W plane
+  extern __shared__ __attribute__((aligned(16))) float smemf[];
+  uint16_t* Ah = reinterpret_cast<uint16_t*>(smemf);  // [2][BM][40]
+  uint16_t* Wh = Ah + 2 * APLANE;                     // [2][BN][40]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int g = blockIdx.y;
+  const int nb = p.mtiles * p.ntiles;
+  int id = blockIdx.x;
+  {
+    const int q = nb >> 3, r = nb & 7, xcd = id & 7;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int mt = id / p.ntiles;
+  const int nt = id - mt * p.ntiles;
+  const int p0 = mt * GM_BM;
+  const int n0 = nt * BN;
+  const float* __restrict__ bg = p.bias + (size_t)g * p.b_gstride;
+  const uint16_t* __restrict__ Wg = p.Wh2 + (size_t)g * p.Cout * p.Kpad16;
+
+  // activation scale: the power of two that puts the tensor maximum in [2^14, 2^15)
+  float amax = p.a_amax_floor;
+  if (p.a_amax) amax = fmaxf(amax, amax_slots(p.a_amax, lane));
+  if (p.a_amax2) amax = fmaxf(amax, amax_slots(p.a_amax2, lane));
+  uint32_t ex = __float_as_uint(amax) >> 23;
+  ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
+  ex = __builtin_amdgcn_readfirstlane(ex);
+  const float sa = __uint_as_float((268u - ex) << 23);       // 2^(141 - ex)
+  const float inv_sa = __uint_as_float((ex - 14u) << 23);    // 2^(ex - 141)
+
+  ALoader<LOADER, RPT, RS> ld;
+  ld.init(p, p0, g, t);
+  const int chunk = t & 7;    // A: 4-float chunk of the 32-wide K tile
+  const int srow = t >> 3;    // A: rows srow + 32 s
+  const int wchunk = t & 3;   // W: 8-half chunk
+  const int wrow = t >> 2;    // W: rows wrow + 64 s
+  bool wok[WPT];
+  size_t woff[WPT];
+#pragma unroll
+  for (int s = 0; s < WPT; ++s) {
+    const int n = n0 + wrow + WRS * s;
+    wok[s] = n < p.Cout;
+    woff[s] = (size_t)(wok[s] ? n : 0) * p.Kpad16 + wchunk * 8;
+  }
+
+  f32x16 acc[2][NCB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NCB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int a_off = (wr * 64 + li) * GH_STR + 8 * lh;
+  const int b_off = (wc * 32 * NCB + li) * GH_STR + 8 * lh;
+
+  float4 ra[RPT];
+  uint4 rw[2][WPT];
+  const int ntile_k = (p.Kpad16 + BK - 1) / BK;
+
+  auto gload = [&](int kt) {
+    const int k0 = kt * BK + chunk * 4;
+    const bool live = k0 < p.Kpad16;
+#pragma unroll
+    for (int s = 0; s < RPT; ++s) ra[s] = live ? ld.load(p, s, k0, t) : f4zero();
+    const bool wlive = kt * BK + wchunk * 8 < p.Kpad16;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int s = 0; s < WPT; ++s)
+        rw[pl][s] = (wlive && wok[s])
+                        ? *reinterpret_cast<const uint4*>(Wg + pl * p.w3_plane + woff[s] + kt * BK)
+                        : make_uint4(0u, 0u, 0u, 0u);
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int s = 0; s < RPT; ++s) {
+      uint2 h, l;
+      split2_h<LOADER == LOAD_GATHER>(ra[s], sa, h, l);
+      uint16_t* dst = Ah + (srow + RS * s) * GH_STR + chunk * 4;
+      *reinterpret_cast<uint2*>(dst) = h;
+      *reinterpret_cast<uint2*>(dst + APLANE) = l;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int s = 0; s < WPT; ++s)
+        *reinterpret_cast<uint4*>(Wh + pl * WPLANE + (wrow + WRS * s) * GH_STR + wchunk * 8) = rw[pl][s];
+  };
+
+#define S4G_H2_TERM(PA, PB)                                                                              \
+  acc[0][cp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][PA], bf[0][PB], acc[0][cp], 0, 0, 0);         \
+  acc[0][cp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][PA], bf[1][PB], acc[0][cp + 1], 0, 0, 0); \
+  acc[1][cp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][PA], bf[0][PB], acc[1][cp], 0, 0, 0);         \
+  acc[1][cp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][PA], bf[1][PB], acc[1][cp + 1], 0, 0, 0);
+  auto compute_ks = [&](int ks) {
+    f16x8 af[2][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        af[rb][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(
+            Ah + pl * APLANE + a_off + rb * 32 * GH_STR + ks * 16));
+#pragma unroll
+    for (int cp = 0; cp < NCB; cp += 2) {
+      f16x8 bf[2][2];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          bf[cb][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(
+              Wh + pl * WPLANE + b_off + (cp + cb) * 32 * GH_STR + ks * 16));
+      // three products per tile, the small cross terms first
+      S4G_H2_TERM(0, 1)
+      S4G_H2_TERM(1, 0)
+      S4G_H2_TERM(0, 0)
+    }
+  };
+
+  gload(0);
+  for (int kt = 0; kt < ntile_k; ++kt) {
+    lstore();
+    __syncthreads();
+    if (kt + 1 < ntile_k) gload(kt + 1);
+    const int krem = p.Kpad16 - kt * BK;
+    const int nks = krem >= BK ? 2 : 1;
+    for (int ks = 0; ks < nks; ++ks) compute_ks(ks);
+    __syncthreads();
+  }
+#undef S4G_H2_TERM
+
+  // undo the scales (exact: powers of two) and leave this tile's maximum for
+  // the consumer of the output tensor
+  float tmax = 0.f;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int n = n0 + wc * 32 * NCB + cb * 32 + li;
+    const bool nok = n < p.Cout;
+    const float sc = nok ? inv_sa * p.w_inv_scale[(size_t)g * p.b_gstride + n] : 0.f;
+    const float bias = nok ? bg[n] : 0.f;
+    float mx = -__builtin_inff(), mn = __builtin_inff();
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[rb][cb][r] * sc;
+        acc[rb][cb][r] = v;
+        mx = fmaxf(mx, v);
+        mn = fminf(mn, v);
+      }
+    const float hi = mx + bias, lo = mn + bias;
+    tmax = fmaxf(tmax, p.relu ? hi : fmaxf(fabsf(hi), fabsf(lo)));
+  }
+  if (p.out_amax) {
+    const uint32_t wm = wave_max_u32(__float_as_uint(fmaxf(tmax, 0.f)));
+    if (lane == 0) atomicMax(p.out_amax + ((blockIdx.x * 4 + wave) & 63), wm);
+  }
+  gemm_epilogue<EPI, NCB>(p, acc, bg, g, p0, n0, wave, wr, wc, li, lh, smemf);
+}
+
+template <int LOADER, int EPI, int NCB>
+static int launch_gemm_f16x2_cfg(GemmParams p, int groups, hipStream_t st) {
+  constexpr int BN = 64 * NCB;
+  p.ntiles = (p.Cout + BN - 1) / BN;
+  size_t lds = sizeof(uint16_t) * 2 * (GM_BM + BN) * GH_STR;
+  const size_t epi = sizeof(float) * 4 * 32 * (32 * NCB + 4);   // staged epilogue stores
+  if (lds < epi) lds = epi;
+  static const hipError_t attr = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&mlp_gemm_f16x2_kernel<LOADER, EPI, NCB>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr != hipSuccess) return (int)attr;
+  const dim3 grid((unsigned)(p.mtiles * p.ntiles), (unsigned)groups);
+  hipLaunchKernelGGL((mlp_gemm_f16x2_kernel<LOADER, EPI, NCB>), grid, dim3(256), lds, st, p);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
+
+template <int LOADER, int EPI>
+static int launch_gemm_f16x2(const GemmParams& p, int groups, hipStream_t st) {
+  static const int force = [] { const char* e = getenv("S4G_GEMM_NCB"); return e ? atoi(e) : 0; }();
+  // the INTERP / GATHER loaders hold too much per-row state for the wide tile's
+  // 128 accumulator registers (they would spill)
+  const bool wide = force ? force == 4
+                          : p.Cout > 128 && (LOADER == LOAD_PLAIN || LOADER == LOAD_GATHER_MLP1);
+  if (wide) return launch_gemm_f16x2_cfg<LOADER, EPI, 4>(p, groups, st);
+  return launch_gemm_f16x2_cfg<LOADER, EPI, 2>(p, groups, st);
+}
+
 template <int LOADER, int EPI, int NS, int WAVES>
 static int launch_gemm_bf16x3_cfg(const GemmParams& p, int groups, hipStream_t st) {
   constexpr int BK = 32 * NS;
@@ -690,7 +951,12 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   using namespace s4g;
   if (!d || d->P < 0 || d->Cout <= 0 || d->groups <= 0 || !d->bias) return S4G_EINVAL;
   const bool split = d->precision == S4G_GEMM_BF16X3 || d->precision == S4G_GEMM_BF16;
-  if (split) {
+  const bool h2 = d->precision == S4G_GEMM_F16X2;
+  if (h2) {
+    if (!d->W_f16x2 || !d->w_inv_scale || d->Kpad16 <= 0 || (d->Kpad16 & 15) ||
+        !(d->a_amax_floor >= 0.f) || (!d->a_amax && !d->a_amax2 && !(d->a_amax_floor > 0.f)))
+      return S4G_EINVAL;
+  } else if (split) {
     if (!d->W_bf16x3 || d->Kpad16 <= 0 || (d->Kpad16 & 15)) return S4G_EINVAL;
   } else if (d->precision == S4G_GEMM_FP32) {
     if (!d->W || d->Kpad <= 0 || (d->Kpad & 7)) return S4G_EINVAL;
@@ -716,6 +982,10 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   p.Kpad16 = d->Kpad16;
   p.bf16_single = d->precision == S4G_GEMM_BF16 ? 1 : 0;
   p.w3_plane = (size_t)d->groups * (size_t)d->Cout * (size_t)d->Kpad16;
+  p.Wh2 = (const uint16_t*)d->W_f16x2;
+  p.w_inv_scale = d->w_inv_scale;
+  p.a_amax = d->a_amax; p.a_amax2 = d->a_amax2; p.a_amax_floor = d->a_amax_floor;
+  p.out_amax = (uint32_t*)d->out_amax;
   p.mtiles = (d->P + GM_BM - 1) / GM_BM;
   p.ntiles = (d->Cout + GM_BN - 1) / GM_BN;
   hipStream_t st = (hipStream_t)stream;
@@ -750,8 +1020,9 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
 
 #define S4G_GEMM_CASE(L, E)                                            \
   if (d->loader == L && d->epilogue == E)                              \
-    return split ? launch_gemm_bf16x3<L, E>(p, d->groups, st)          \
-                 : launch_gemm<L, E>(p, d->groups, st);
+    return h2 ? launch_gemm_f16x2<L, E>(p, d->groups, st)              \
+           : split ? launch_gemm_bf16x3<L, E>(p, d->groups, st)        \
+                   : launch_gemm<L, E>(p, d->groups, st);
   S4G_GEMM_CASE(LOAD_PLAIN, EPI_STORE)
   S4G_GEMM_CASE(LOAD_PLAIN, EPI_MAX)
   S4G_GEMM_CASE(LOAD_PLAIN, EPI_CHANNEL_FIRST)

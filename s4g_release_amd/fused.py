@@ -75,9 +75,26 @@ def split_bf16x3(w):
     return torch.stack([w1, w2, w3], dim=0).contiguous()
 
 
+def split_f16x2(w):
+    """Scaled 2-way fp16 split of an fp32 tensor (..., Cout, K): per output row a
+    power-of-two scale s puts max|w| in [2^14, 2^15); w*s ~= w1 + w2 (fp16,
+    round-to-nearest; 22 significand bits).  Returns ((2, ..., Cout, K) float16
+    planes, (..., Cout) float32 1/s)."""
+    amax = w.abs().amax(dim=-1)
+    _, ex = torch.frexp(amax)                       # amax < 2^ex
+    ex = torch.where(amax > 0, ex, torch.zeros_like(ex)).clamp(-100, 100)
+    one = torch.ones_like(amax)
+    s = torch.ldexp(one, 15 - ex)
+    ws = w * s[..., None]                           # exact (power of two)
+    w1 = ws.to(torch.float16)
+    w2 = (ws - w1.float()).to(torch.float16)
+    return torch.stack([w1, w2], dim=0).contiguous(), torch.ldexp(one, ex - 15).contiguous()
+
+
 class _Layer:
     """Folded weights of one launch: W (groups, Cout, Kpad), bias (groups, Cout),
-    plus the bf16x3 planes (3, groups, Cout, Kpad16) for the split-precision kernel."""
+    plus the bf16x3 planes (3, groups, Cout, Kpad16) and the scaled fp16x2 planes
+    (2, groups, Cout, Kpad16) + per-channel inverse scales for the split kernels."""
 
     def __init__(self, W, bias, cin, groups=1):
         self.W = W.contiguous()
@@ -90,23 +107,27 @@ class _Layer:
         w16 = self.W.new_zeros(self.W.shape[:-1] + (self.kpad16,))
         w16[..., :self.kpad] = self.W
         self.W3 = split_bf16x3(w16)
+        self.Wh2, self.w_inv_scale = split_f16x2(w16)
 
 
 class FusedPointNet2:
     """Callable with the reference forward's signature: {"scene_points": (B,3,N)} -> dict."""
 
     def __init__(self, net, precision=None):
-        """precision: "bf16x3" (default; fp32-equivalent split on the bf16 matrix
-        cores), "fp32" (fp32-input MFMA, an exact fma chain) or "bf16" (plain bf16
-        inputs, fp32 accumulate -- reduced precision, outside the 1e-4 bar; the
-        bf16 roofline configuration of BASELINE.json configs[4]).  S4G_GEMM_MODE
-        overrides the default."""
+        """precision: "f16x2" (default; fp32 operands split into two scaled fp16
+        planes, three fp16 MFMA products, fp32 accumulate: the error of a plain fp32
+        dot product), "bf16x3" (three bf16 planes, six products: ~2x tighter than
+        fp32 round-off, half the speed), "fp32" (fp32-input MFMA, an exact fma
+        chain) or "bf16" (plain bf16 inputs, fp32 accumulate -- reduced precision,
+        outside the 1e-4 bar; the bf16 roofline configuration of BASELINE.json
+        configs[4]).  S4G_GEMM_MODE overrides the default."""
         if precision is None:
-            precision = os.environ.get("S4G_GEMM_MODE", "bf16x3")
-        if precision not in ("bf16x3", "fp32", "bf16"):
-            raise ValueError("precision must be 'bf16x3', 'fp32' or 'bf16'")
+            precision = os.environ.get("S4G_GEMM_MODE", "f16x2")
+        if precision not in ("f16x2", "bf16x3", "fp32", "bf16"):
+            raise ValueError("precision must be 'f16x2', 'bf16x3', 'fp32' or 'bf16'")
         self.precision = precision
-        self.dense_streams = int(os.environ.get("S4G_DENSE_STREAMS", "1"))
+        self.dense_streams = max(1, int(os.environ.get("S4G_DENSE_STREAMS", "1")))
+        self.geo_streams = max(1, int(os.environ.get("S4G_GEO_STREAMS", "2")))
         p = next(net.parameters())
         if not p.is_cuda:
             raise RuntimeError("FusedPointNet2 needs the model on a HIP device (no CPU fallback)")
@@ -136,9 +157,13 @@ class FusedPointNet2:
                 else:
                     cin = w.shape[1]
                 layers.append(_Layer(_pad_k(w), b, cin))
-            self.sa.append(dict(M=sa.num_centroids, radius=float(sa.grouper.radius),
+            radius = float(sa.grouper.radius)
+            # |relu(w . rel + b)| <= (|wx|+|wy|+|wz|) r + |b| for neighbours inside the ball
+            mlp1_bound = 0.0 if mlp1 is None else float(
+                (mlp1[:, :3].abs().sum(dim=1) * radius + mlp1[:, 3].abs()).max())
+            self.sa.append(dict(M=sa.num_centroids, radius=radius,
                                 K=int(sa.grouper.num_neighbours), layers=layers,
-                                cf=sa.in_channels, mlp1=mlp1))
+                                cf=sa.in_channels, mlp1=mlp1, mlp1_bound=mlp1_bound))
         self.fp = []
         for fp in net.fp_modules:
             if fp.interpolator is None:
@@ -183,12 +208,14 @@ class FusedPointNet2:
         d.P, d.Cin, d.Kpad, d.Cout = P, layer.cin, layer.kpad, layer.cout
         d.W, d.bias = layer.W.data_ptr(), layer.bias.data_ptr()
         d.w_gstride, d.b_gstride = layer.cout * layer.kpad, layer.cout
-        d.precision = {"fp32": 0, "bf16x3": 1, "bf16": 2}[self.precision]
+        d.precision = {"fp32": 0, "bf16x3": 1, "bf16": 2, "f16x2": 3}[self.precision]
         d.Kpad16, d.W_bf16x3 = layer.kpad16, layer.W3.data_ptr()
+        d.W_f16x2, d.w_inv_scale = layer.Wh2.data_ptr(), layer.w_inv_scale.data_ptr()
         for k, v in kw.items():
             if isinstance(v, torch.Tensor):
                 v = v.data_ptr()
-            setattr(d, k, v)
+            if v is not None:
+                setattr(d, k, v)
         flops = 2.0 * P * layer.cout * layer.cin * layer.groups
         with _F._timed("gemm[%s P=%d K=%d N=%dx%d]" % (name, P, layer.cin, layer.groups, layer.cout),
                        0, flops):
@@ -271,76 +298,90 @@ class FusedPointNet2:
         return geo
 
     def _dense(self, xyz, geo):
-        """The shared-MLP contractions of every layer (fp32 MFMA)."""
+        """The shared-MLP contractions of every layer (MFMA).
+
+        f16x2 precision: every launch leaves max|out| in a 64-slot row of `amax`
+        (atomicMax in its epilogue) and the launch that consumes the tensor derives
+        its power-of-two activation scale from that row."""
         B, _, N0 = xyz.shape
         dev = xyz.device
         level_xyz, level_n = geo["level_xyz"], geo["level_n"]
-        level_feat = [None]
-        feat = None
+        n_launch = sum(len(sa["layers"]) for sa in self.sa) + \
+            sum(len(fp["layers"]) for fp in self.fp) + len(self.head_layers) + 1
+        amax = torch.zeros((n_launch, 64), dtype=torch.float32, device=dev)
+        rows = iter(amax.unbind(0))
+        level_feat = [(None, None)]                  # (tensor, amax row)
+        feat = feat_amax = None
         for li, sa in enumerate(self.sa):
             M, K = sa["M"], sa["K"]
             _, ctr, gidx, _ = geo["sa"][li]
             P = B * M * K
             layers = sa["layers"]
-            x = None
+            x = x_amax = None
             for l, layer in enumerate(layers):
                 if l == 0 and sa["mlp1"] is not None:
                     continue                      # folded into layer 1's loader
                 last = l == len(layers) - 1
-                rows = B * M if last else P
-                out = torch.empty((rows, layer.cout), dtype=torch.float32, device=dev)
-                kw = dict(out=out, ldc=layer.cout, K=K)
+                nrow = B * M if last else P
+                out = torch.empty((nrow, layer.cout), dtype=torch.float32, device=dev)
+                out_amax = next(rows)
+                kw = dict(out=out, ldc=layer.cout, K=K, out_amax=out_amax)
                 if l == 1 and sa["mlp1"] is not None:
                     kw.update(gidx=gidx, xyz=level_xyz[li], ctr=ctr, N=level_n[li], M=M,
-                              mlp1_w=sa["mlp1"])
+                              mlp1_w=sa["mlp1"], a_amax_floor=sa["mlp1_bound"])
                     loader = LOAD_GATHER_MLP1
                 elif l == 0:
                     kw.update(gidx=gidx, feat=feat, xyz=level_xyz[li], ctr=ctr, Cf=sa["cf"],
-                              N=level_n[li], M=M)
+                              N=level_n[li], M=M, a_amax=feat_amax, a_amax_floor=sa["radius"])
                     loader = LOAD_GATHER
                 else:
-                    kw.update(A=x, lda=x.shape[1])
+                    kw.update(A=x, lda=x.shape[1], a_amax=x_amax)
                     loader = LOAD_PLAIN
                 self._gemm("sa%d.%d" % (li, l), layer, P, loader, EPI_MAX if last else EPI_STORE,
                            **kw)
-                x = out
-            feat = x
-            level_feat.append(feat)
+                x, x_amax = out, out_amax
+            feat, feat_amax = x, x_amax
+            level_feat.append((feat, feat_amax))
 
-        sparse_feat, n_sparse = level_feat[-1], level_n[-1]
+        (sparse_feat, sparse_amax), n_sparse = level_feat[-1], level_n[-1]
         for fi, fp in enumerate(self.fp):
-            dense_feat, n_dense = level_feat[-2 - fi], level_n[-2 - fi]
+            (dense_feat, dense_amax), n_dense = level_feat[-2 - fi], level_n[-2 - fi]
             nidx, nw = geo["fp"][fi]
             P = B * n_dense
-            x = None
+            x = x_amax = None
             for l, layer in enumerate(fp["layers"]):
                 out = torch.empty((P, layer.cout), dtype=torch.float32, device=dev)
+                out_amax = next(rows)
                 if l == 0:
                     c1 = 0 if dense_feat is None else dense_feat.shape[1]
                     self._gemm("fp%d.%d" % (fi, l), layer, P, LOAD_INTERP, EPI_STORE, out=out,
                                ldc=layer.cout, nidx=nidx, nw=nw, sparse=sparse_feat,
                                dense=dense_feat, C2=sparse_feat.shape[1], C1=c1, N2=n_sparse,
-                               N1=n_dense)
+                               N1=n_dense, a_amax=sparse_amax, a_amax2=dense_amax,
+                               out_amax=out_amax)
                 else:
                     self._gemm("fp%d.%d" % (fi, l), layer, P, LOAD_PLAIN, EPI_STORE, out=out,
-                               ldc=layer.cout, A=x, lda=x.shape[1])
-                x = out
-            sparse_feat, n_sparse = x, n_dense
+                               ldc=layer.cout, A=x, lda=x.shape[1], a_amax=x_amax,
+                               out_amax=out_amax)
+                x, x_amax = out, out_amax
+            sparse_feat, sparse_amax, n_sparse = x, x_amax, n_dense
 
         # heads
         P = B * N0
-        x = sparse_feat
+        x, x_amax = sparse_feat, sparse_amax
         l0 = self.head_layers[0]
         h = torch.empty((P, l0.cout), dtype=torch.float32, device=dev)
+        h_amax = next(rows)
         self._gemm("heads.0", l0, P, LOAD_PLAIN, EPI_STORE, out=h, ldc=l0.cout, A=x,
-                   lda=x.shape[1])
-        x = h
+                   lda=x.shape[1], a_amax=x_amax, out_amax=h_amax)
+        x, x_amax = h, h_amax
         for l, layer in enumerate(self.head_layers[1:], start=1):
             h = torch.empty((P, 4 * layer.cout), dtype=torch.float32, device=dev)
+            h_amax = next(rows)
             self._gemm("heads.%d" % l, layer, P, LOAD_PLAIN, EPI_STORE, out=h,
                        ldc=4 * layer.cout, c_gcol=layer.cout, A=x, lda=x.shape[1],
-                       a_gcol=layer.cin)
-            x = h
+                       a_gcol=layer.cin, a_amax=x_amax, out_amax=h_amax)
+            x, x_amax = h, h_amax
         names = ("score", "frame_R", "frame_t", "movable_logits")
         outs = [torch.empty((B, c, N0), dtype=torch.float32, device=dev)
                 for c in self.head_channels]
@@ -351,7 +392,7 @@ class FusedPointNet2:
         cf_start = (_i32 * 5)(*starts)
         self._gemm("heads.logits", self.logit_layer, P, LOAD_PLAIN, EPI_CF, relu=False, A=x,
                    lda=x.shape[1], cf_ptr=cf_ptr, cf_start=cf_start,
-                   cf_sigmoid_from=self.sigmoid_from, cf_N=N0)
+                   cf_sigmoid_from=self.sigmoid_from, cf_N=N0, a_amax=x_amax)
         return dict(zip(names, outs))
 
     @torch.no_grad()
@@ -367,14 +408,18 @@ class FusedPointNet2:
         if xyz.dim() != 3 or xyz.size(1) != 3:
             raise RuntimeError("scene_points must be (B, 3, N)")
         dev = xyz.device
-        if self._streams is None or self._streams[0].device != dev:
-            # one high-priority geometry stream; S4G_DENSE_STREAMS=2 lets consecutive
-            # batches' contractions fill each other's kernel tails (+1.5 % measured),
-            # the default of 1 keeps per-kernel event timings clean
-            self._streams = (torch.cuda.Stream(device=dev, priority=-1),
+        if self._streams is None or self._streams[0][0].device != dev:
+            # high-priority geometry streams: FPS is a latency chain on one CU per
+            # scene, so S4G_GEO_STREAMS (default 2) consecutive batches may run
+            # their chains side by side (needs >= 2 batches in flight to matter);
+            # S4G_DENSE_STREAMS=2 lets consecutive batches' contractions fill each
+            # other's kernel tails (+1.5 % measured), the default of 1 keeps
+            # per-kernel event timings clean
+            self._streams = ([torch.cuda.Stream(device=dev, priority=-1)
+                              for _ in range(self.geo_streams)],
                              [torch.cuda.Stream(device=dev) for _ in range(self.dense_streams)])
             self._submitted = 0
-        gs = self._streams[0]
+        gs = self._streams[0][self._submitted % len(self._streams[0])]
         ds = self._streams[1][self._submitted % len(self._streams[1])]
         self._submitted += 1
         with torch.cuda.device(dev):

@@ -39,7 +39,32 @@ def _w3(w):
     return kp, split_bf16x3(w16)
 
 
-PRECISIONS = [0, 1]   # S4G_GEMM_FP32, S4G_GEMM_BF16X3
+PRECISIONS = [0, 1, 3]   # S4G_GEMM_FP32, S4G_GEMM_BF16X3, S4G_GEMM_F16X2
+
+
+def _h2(w, *tensors, floor=0.0):
+    """Descriptor fields of the f16x2 mode: scaled fp16 planes of W, per-channel
+    inverse scales, one 64-slot amax row per input tensor (the slot position is
+    arbitrary) and a zeroed out_amax row."""
+    from s4g_release_amd.fused import split_f16x2
+    k = w.shape[-1]
+    kp = (k + 15) // 16 * 16
+    w16 = w.new_zeros(w.shape[:-1] + (kp,))
+    w16[..., :k] = w
+    planes, inv = split_f16x2(w16)
+    kw = dict(W_f16x2=planes, w_inv_scale=inv, a_amax_floor=float(floor),
+              out_amax=torch.zeros(64, device=w.device))
+    for name, t in zip(("a_amax", "a_amax2"), [t for t in tensors if t is not None]):
+        row = torch.zeros(64, device=w.device)
+        row[17] = t.abs().max()
+        kw[name] = row
+    return kw
+
+
+def _check_out_amax(kw, out):
+    """out_amax is an upper bound of max|out| (rows past P contribute |bias|)."""
+    got = kw["out_amax"].max().item()
+    assert got >= out.abs().max().item()
 
 
 def _padk(w):
@@ -62,13 +87,16 @@ def test_gemm_plain_store(dev, P, Cin, Cout, relu, prec):
     out = torch.full((P, Cout), float("nan"), device=dev)
     Wp = _padk(W)
     k16, w3 = _w3(W)
+    h2 = _h2(W, A)
     _run(dict(loader=0, epilogue=0, groups=1, relu=int(relu), P=P, Cin=Cin, Kpad=Wp.shape[1],
               Cout=Cout, W=Wp, bias=b, A=A, lda=Cin, out=out, ldc=Cout, precision=prec,
-              Kpad16=k16, W_bf16x3=w3), dev)
+              Kpad16=k16, W_bf16x3=w3, **h2), dev)
     ref = A.double() @ W.double().t() + b.double()
     if relu:
         ref = ref.clamp_min(0)
     assert torch.isfinite(out).all()
+    if prec == 3:
+        _check_out_amax(h2, out)
     assert (out.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
@@ -83,7 +111,7 @@ def test_gemm_grouped_column_slices(dev, prec):
     k16, w3 = _w3(W)
     _run(dict(loader=0, epilogue=0, groups=G, relu=1, P=P, Cin=Cin, Kpad=Cin, Cout=Cout, W=W,
               bias=b, w_gstride=Cout * Cin, b_gstride=Cout, A=A, lda=G * Cin, a_gcol=Cin, out=out,
-              ldc=G * Cout, c_gcol=Cout, precision=prec, Kpad16=k16, W_bf16x3=w3), dev)
+              ldc=G * Cout, c_gcol=Cout, precision=prec, Kpad16=k16, W_bf16x3=w3, **_h2(W, A)), dev)
     for i in range(G):
         ref = (A[:, i * Cin:(i + 1) * Cin].double() @ W[i].double().t() + b[i].double()).clamp_min(0)
         assert (out[:, i * Cout:(i + 1) * Cout].double() - ref).abs().max().item() < 2e-5
@@ -107,9 +135,13 @@ def test_gemm_gather_max(dev, K, Cf, prec):
     P = B * M * K
     out = torch.full((B * M, Cout), float("nan"), device=dev)
     k16, w3 = _w3(W)
+    # random neighbour lists are not inside any ball: bound the xyz columns by the cloud's extent
+    h2 = _h2(W, feat, floor=2 * xyz.abs().max().item())
     _run(dict(loader=1, epilogue=1, groups=1, relu=1, P=P, Cin=Cin, Kpad=Wp.shape[1], Cout=Cout,
               W=Wp, bias=b, gidx=gidx, feat=feat, xyz=xyz, ctr=ctr, Cf=Cf, N=N, M=M, K=K, out=out,
-              ldc=Cout, precision=prec, Kpad16=k16, W_bf16x3=w3), dev)
+              ldc=Cout, precision=prec, Kpad16=k16, W_bf16x3=w3, **h2), dev)
+    if prec == 3:
+        _check_out_amax(h2, out)
     rows = []
     for bi in range(B):
         gi = gidx[bi].long()                                        # (M,K)
@@ -141,7 +173,8 @@ def test_gemm_interp_store(dev, prec):
         k16, w3 = _w3(Wc)
         _run(dict(loader=2, epilogue=0, groups=1, relu=1, P=P, Cin=C2 + c1, Kpad=C2 + c1, Cout=Cout,
                   W=Wc, bias=b, nidx=nidx, nw=nw, sparse=sparse, dense=dn, C2=C2, C1=c1, N2=N2,
-                  N1=N1, out=out, ldc=Cout, precision=prec, Kpad16=k16, W_bf16x3=w3), dev)
+                  N1=N1, out=out, ldc=Cout, precision=prec, Kpad16=k16, W_bf16x3=w3,
+                  **_h2(Wc, sparse, dn)), dev)
         sp = sparse.view(B, N2, C2)
         interp = torch.stack([(sp[bi][nidx[bi].long()] * nw[bi][:, :, None]).sum(1)
                               for bi in range(B)]).view(P, C2)
@@ -164,7 +197,7 @@ def test_gemm_channel_first_heads(dev, prec):
     _run(dict(loader=0, epilogue=2, groups=1, relu=0, P=B * N, Cin=Cin, Kpad=Cin, Cout=21, W=W,
               bias=b, A=A, lda=Cin, cf_ptr=(ctypes.c_void_p * 4)(*[o.data_ptr() for o in outs]),
               cf_start=(ctypes.c_int32 * 5)(*starts), cf_sigmoid_from=16, cf_N=N, precision=prec,
-              Kpad16=k16, W_bf16x3=w3), dev)
+              Kpad16=k16, W_bf16x3=w3, **_h2(W, A)), dev)
     ref = (A.double() @ W.double().t() + b.double()).view(B, N, 21).permute(0, 2, 1)
     for h, o in enumerate(outs):
         r = ref[:, starts[h]:starts[h + 1]]
@@ -189,14 +222,38 @@ def test_bf16x3_error_is_fp32_class(dev):
         out = torch.empty(P, Cout, device=dev)
         _run(dict(loader=0, epilogue=0, groups=1, relu=0, P=P, Cin=Cin, Kpad=Cin, Cout=Cout, W=W,
                   bias=b, A=A, lda=Cin, out=out, ldc=Cout, precision=prec, Kpad16=k16,
-                  W_bf16x3=w3), dev)
+                  W_bf16x3=w3, **_h2(W, A)), dev)
         errs[prec] = ((out.double() - ref).abs() / scale).max().item()
-    print("max |err| / sum|a||w|: fp32 MFMA %.3g, bf16x3 %.3g" % (errs[0], errs[1]))
-    assert errs[0] < 1e-6 and errs[1] < 1e-6          # fp32 unit round-off is 6e-8; K = 1024 terms
+    print("max |err| / sum|a||w|: fp32 MFMA %.3g, bf16x3 %.3g, f16x2 %.3g" % (errs[0], errs[1], errs[3]))
+    assert errs[0] < 1e-6 and errs[1] < 1e-6 and errs[3] < 1e-6   # fp32 unit round-off is 6e-8; K = 1024 terms
     assert errs[1] < 4 * errs[0] + 6e-8
+    assert errs[3] < 4 * errs[0] + 6e-8
 
 
-def _check_model(dev, g, net, pts, full, precision="bf16x3"):
+def test_f16x2_wide_dynamic_range(dev):
+    """Per-tensor activation scale: rows 2^-12 below the tensor's maximum keep
+    fp32-class accuracy relative to their own sum|a||w|; only below 2^-18 of the
+    maximum do low-order bits start to go (fp16 subnormals of the second plane)."""
+    g = torch.Generator(device="cpu").manual_seed(12)
+    P, Cin, Cout = 1024, 256, 128
+    A = torch.randn(P, Cin, generator=g)
+    A[P // 2:] *= 2.0 ** -12
+    A = A.to(dev)
+    W = (torch.randn(Cout, Cin, generator=g) * torch.logspace(-3, 1, Cout)[:, None]).to(dev)
+    b = torch.zeros(Cout, device=dev)
+    out = torch.empty(P, Cout, device=dev)
+    k16, w3 = _w3(W)
+    _run(dict(loader=0, epilogue=0, groups=1, relu=0, P=P, Cin=Cin, Kpad=Cin, Cout=Cout, W=W,
+              bias=b, A=A, lda=Cin, out=out, ldc=Cout, precision=3, Kpad16=k16, W_bf16x3=w3,
+              **_h2(W, A)), dev)
+    ref = A.double() @ W.double().t()
+    scale = A.double().abs() @ W.double().abs().t()
+    err = ((out.double() - ref).abs() / scale)
+    assert err[:P // 2].max().item() < 5e-7
+    assert err[P // 2:].max().item() < 5e-7
+
+
+def _check_model(dev, g, net, pts, full, precision="f16x2"):
     from s4g_release_amd.fused import FusedPointNet2
     fused = FusedPointNet2(net.to(dev).eval(), precision=precision)
     pred, inter = fused({"scene_points": torch.from_numpy(pts).to(dev)}, return_intermediates=True)
@@ -218,7 +275,7 @@ def _check_model(dev, g, net, pts, full, precision="bf16x3"):
     return pred
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x2", "bf16x3", "fp32"])
 def test_fused_model_small_golden(dev, precision):
     from s4g_release_amd.model import PointNet2
     g = GU.load("pn2_small.npz")
@@ -231,7 +288,7 @@ def test_fused_model_small_golden(dev, precision):
         assert err < TOL, (k, err)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x2", "bf16x3", "fp32"])
 def test_fused_model_full_golden(dev, precision):
     from s4g_release_amd import synth
     g = GU.load("pn2_full.npz")

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from s4g_release_amd import _cabi
-from s4g_release_amd.fused import _pad_k, fold_conv_bn, split_bf16x3
+from s4g_release_amd.fused import _pad_k, fold_conv_bn, split_bf16x3, split_f16x2
 from s4g_release_amd.model import PointNet2, randomize_bn_
 from s4g_release_amd.nn_utils import Conv1d, Conv2d
 
@@ -25,6 +25,28 @@ def test_fold_conv_bn_equals_conv_then_bn_eval():
         w, b = fold_conv_bn(blk)
         y = torch.einsum("oc,bc...->bo...", w, x) + b.view(1, -1, *([1] * (x.dim() - 2)))
         assert torch.allclose(torch.relu(y), ref, atol=1e-5)
+
+
+def test_split_f16x2_scales_and_precision():
+    """Per-row power-of-two scale into [2^14, 2^15); two fp16 planes carry >= 22
+    significand bits of the scaled value; zero rows stay zero."""
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(2, 48, 64, generator=g) * torch.logspace(-6, 3, 48)[None, :, None]
+    w[1, 5] = 0.0
+    planes, inv = split_f16x2(w)
+    assert planes.dtype == torch.float16 and planes.shape == (2, 2, 48, 64) and inv.shape == (2, 48)
+    m, e = torch.frexp(inv)
+    assert torch.all(m == 0.5)                                    # exact powers of two
+    scaled = w.double() / inv.double()[..., None]
+    amax = scaled.abs().amax(dim=-1)
+    nz = amax > 0
+    assert torch.all(amax[nz] >= 2.0 ** 14) and torch.all(amax[nz] < 2.0 ** 15)
+    rec = planes[0].double() + planes[1].double()
+    err = (rec - scaled).abs()
+    # second plane rounds at 2^-11 of the first plane's half-ulp (2^-11 |x|); below
+    # 2^-14 the second plane is subnormal with a 2^-25 absolute grid
+    assert torch.all(err <= torch.maximum(scaled.abs() * 2.0 ** -22, torch.tensor(2.0 ** -25, dtype=torch.float64)))
+    assert torch.all(planes[:, 1, 5] == 0)
 
 
 def test_split_bf16x3_is_exact():

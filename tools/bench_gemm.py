@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stand-alone timing of the shared-MLP contraction (plain loader, store epilogue).
-Usage: python tools/bench_gemm.py [P K N] [--prec 0|1] [--reps 10]"""
+Usage: python tools/bench_gemm.py [P K N] [--prec 0|1|2|3] [--reps 10]"""
 import argparse
 import ctypes
 import os
@@ -10,13 +10,13 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from s4g_release_amd import _cabi  # noqa: E402
-from s4g_release_amd.fused import split_bf16x3  # noqa: E402
+from s4g_release_amd.fused import split_bf16x3, split_f16x2  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dims", nargs="*", type=int, default=[409600, 256, 1024])
-    ap.add_argument("--prec", type=int, default=1)
+    ap.add_argument("--prec", type=int, default=3)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--dbg", type=int, default=0)
     a = ap.parse_args()
@@ -35,6 +35,12 @@ def main():
     d.P, d.Cin, d.Kpad, d.Cout = P, K, K, N
     d.W, d.bias, d.A, d.lda, d.out, d.ldc = W.data_ptr(), b.data_ptr(), A.data_ptr(), K, out.data_ptr(), N
     d.precision, d.Kpad16, d.W_bf16x3 = a.prec, k16, w3.data_ptr()
+    wh2, winv = split_f16x2(w16)
+    amax_in = torch.zeros(64, device=dev)
+    amax_in[0] = A.abs().max()
+    amax_out = torch.zeros(64, device=dev)
+    d.W_f16x2, d.w_inv_scale = wh2.data_ptr(), winv.data_ptr()
+    d.a_amax, d.out_amax = amax_in.data_ptr(), amax_out.data_ptr()
     lib = _cabi.lib()
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(3):
