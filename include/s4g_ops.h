@@ -225,6 +225,13 @@ typedef struct s4g_gemm_desc {
   const float *a_amax, *a_amax2;
   float a_amax_floor;
   float *out_amax;
+  /* optional: the same two fp16 planes in MFMA-fragment order,
+   * [groups][Cout/32][Kpad16/16][2 planes][64 lanes][8 halves] with lane = 32*(k/8 % 2) + n % 32
+   * (needs Cout % 32 == 0).  When given, launches with Kpad16 % 64 == 0,
+   * Cout % 128 == 0 and a short contraction (the A panel of 64 or 128 positions
+   * fits LDS) use the resident-A kernel, which streams W fragments straight into
+   * the matrix-core operand registers. */
+  const void *W_f16x2_frag;
 } s4g_gemm_desc_t;
 
 int s4g_mlp_gemm_f32(const s4g_gemm_desc_t *desc, s4g_stream_t stream);

@@ -38,7 +38,7 @@ class GemmDesc(ctypes.Structure):
         ("cf_ptr", _vp * 4), ("cf_start", _i32 * 5), ("cf_sigmoid_from", _i32), ("cf_N", _i32),
         ("precision", _i32), ("Kpad16", _i32), ("W_bf16x3", _vp), ("mlp1_w", _vp),
         ("W_f16x2", _vp), ("w_inv_scale", _vp), ("a_amax", _vp), ("a_amax2", _vp),
-        ("a_amax_floor", _f32), ("out_amax", _vp),
+        ("a_amax_floor", _f32), ("out_amax", _vp), ("W_f16x2_frag", _vp),
     ]
 
 

@@ -95,6 +95,7 @@ struct GemmParams {
   const float* a_amax2;        // 64 slots or NULL
   float a_amax_floor;
   uint32_t* out_amax;          // 64 slots or NULL
+  const uint16_t* Wfrag;       // f16x2 planes in MFMA-fragment order (resident-A kernel) or NULL
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -676,7 +677,11 @@ __global__ __launch_bounds__(64 * WAVES, (NS == 1 && WAVES == 4 && LOADER != LOA
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int GH_STR = 40;  // halves per LDS row (32 + 8: conflict-free b128 reads)
+// LDS rows are 32 halves (64 B, no padding); the 16-byte chunk c of row r sits at
+// position c ^ ((r >> 2) & 3).  A 16-lane b128 read phase (16 consecutive rows,
+// one chunk) and a 16-lane b128 / 32-lane b64 write phase (4 consecutive rows, all
+// chunks) then touch all 64 banks exactly once.
+constexpr int GH_STR = 32;
 
 __device__ __forceinline__ uint32_t pack_h2(float a, float b) {
   f16x2 v;
@@ -771,8 +776,10 @@ __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP) ? 2 : 3) v
 
   const int wr = wave >> 1, wc = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
-  const int a_off = (wr * 64 + li) * GH_STR + 8 * lh;
-  const int b_off = (wc * 32 * NCB + li) * GH_STR + 8 * lh;
+  const int fswz = (li >> 2) & 3;   // row + 32 k keeps bits 2..3: one swizzle per lane
+  const int a_row = (wr * 64 + li) * GH_STR;
+  const int b_row = (wc * 32 * NCB + li) * GH_STR;
+  const int f_off[2] = {((0 + lh) ^ fswz) * 8, ((2 + lh) ^ fswz) * 8};   // chunk 2 ks + lh
 
   float4 ra[RPT];
   uint4 rw[2][WPT];
@@ -797,7 +804,7 @@ __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP) ? 2 : 3) v
     for (int s = 0; s < RPT; ++s) {
       uint2 h, l;
       split2_h<LOADER == LOAD_GATHER>(ra[s], sa, h, l);
-      uint16_t* dst = Ah + (srow + RS * s) * GH_STR + chunk * 4;
+      uint16_t* dst = Ah + (srow + RS * s) * GH_STR + (((chunk >> 1) ^ ((srow >> 2) & 3)) * 8) + (chunk & 1) * 4;
       *reinterpret_cast<uint2*>(dst) = h;
       *reinterpret_cast<uint2*>(dst + APLANE) = l;
     }
@@ -805,7 +812,8 @@ __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP) ? 2 : 3) v
     for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
       for (int s = 0; s < WPT; ++s)
-        *reinterpret_cast<uint4*>(Wh + pl * WPLANE + (wrow + WRS * s) * GH_STR + wchunk * 8) = rw[pl][s];
+        *reinterpret_cast<uint4*>(Wh + pl * WPLANE + (wrow + WRS * s) * GH_STR +
+                                  ((wchunk ^ ((wrow >> 2) & 3)) * 8)) = rw[pl][s];
   };
 
 #define S4G_H2_TERM(PA, PB)                                                                              \
@@ -820,7 +828,7 @@ __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP) ? 2 : 3) v
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl)
         af[rb][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(
-            Ah + pl * APLANE + a_off + rb * 32 * GH_STR + ks * 16));
+            Ah + pl * APLANE + a_row + rb * 32 * GH_STR + f_off[ks]));
 #pragma unroll
     for (int cp = 0; cp < NCB; cp += 2) {
       f16x8 bf[2][2];
@@ -829,7 +837,7 @@ __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP) ? 2 : 3) v
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
           bf[cb][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(
-              Wh + pl * WPLANE + b_off + (cp + cb) * 32 * GH_STR + ks * 16));
+              Wh + pl * WPLANE + b_row + (cp + cb) * 32 * GH_STR + f_off[ks]));
       // three products per tile, the small cross terms first
       S4G_H2_TERM(0, 1)
       S4G_H2_TERM(1, 0)
@@ -895,9 +903,307 @@ static int launch_gemm_f16x2_cfg(GemmParams p, int groups, hipStream_t st) {
   return S4G_OK;
 }
 
+// ---------------------------------------------------------------------------
+// f16x2, resident-A variant for short contractions (K <= 256).
+//
+// A workgroup owns BM = 64 * RW positions and ALL output channels.  Its A panel
+// (BM x K) is loaded, scaled and split ONCE into two fp16 planes that stay in LDS;
+// the four waves then walk the channel strips on their own -- no barrier after the
+// prologue.  W never touches LDS: the host stores its planes in MFMA-fragment
+// order ([n/32][k/16][plane][lane][8 halves]), so a wave reads each fragment as one
+// coalesced 1 KB load straight into the operand registers, prefetched RING steps
+// (16 k each) ahead.  Per 16-deep step a wave issues 4 LDS reads + 4 global loads
+// for 12 MFMAs, and the A panel is neither re-fetched nor re-split per channel
+// tile (the tiled kernel does both Cout/128 times).
+//   RW x CW = 4 waves: CW = 4 (BM = 64) for Cout % 256 == 0, CW = 2 (BM = 128)
+//   for Cout % 128 == 0.  LDS = BM * (K + 8) * 4 bytes <= 80 KB: two workgroups
+//   per CU.
+// STORE epilogue: the MFMA operands are swapped (D = W A^T), so a lane holds four
+// CONSECUTIVE channels of one position per register quad -> float4 stores with
+// no LDS staging.  MAX keeps D = A W^T (the row max is an in-register max).
+// ---------------------------------------------------------------------------
+constexpr int GR_RING = 4;   // W fragment prefetch depth in 16-deep steps
+
+template <int LOADER, int EPI, int RW, int KT>
+__global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const GemmParams p) {
+  constexpr int CW = 4 / RW;
+  constexpr int BM = 64 * RW;
+  constexpr int RPT = BM / 32, RS = 32;
+  constexpr bool SWAP = EPI == EPI_STORE;
+  extern __shared__ __attribute__((aligned(16))) float smemf[];
+  uint16_t* Ah = reinterpret_cast<uint16_t*>(smemf);   // [2][BM][K + 8]
+  constexpr int K = KT;                   // compile time: every LDS / fragment offset is an immediate
+  constexpr int astr = K + 8;             // halves per row: (K/8 + 1) odd -> conflict-free reads
+  constexpr int aplane = BM * astr;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int g = blockIdx.y;
+  const int p0 = blockIdx.x * BM;
+  const float* __restrict__ bg = p.bias + (size_t)g * p.b_gstride;
+  const float* __restrict__ wsc = p.w_inv_scale + (size_t)g * p.b_gstride;
+
+  float amax = p.a_amax_floor;
+  if (p.a_amax) amax = fmaxf(amax, amax_slots(p.a_amax, lane));
+  if (p.a_amax2) amax = fmaxf(amax, amax_slots(p.a_amax2, lane));
+  uint32_t ex = __float_as_uint(amax) >> 23;
+  ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
+  ex = __builtin_amdgcn_readfirstlane(ex);
+  const float sa = __uint_as_float((268u - ex) << 23);
+  const float inv_sa = __uint_as_float((ex - 14u) << 23);
+
+  const int wr = wave / CW, wc = wave % CW;
+  const int li = lane & 31, lh = lane >> 5;
+  constexpr int KS = K >> 4;                     // 16-deep steps per channel strip
+  const int nstrip = p.Cout / (64 * CW);         // strips this wave walks
+  const int total = nstrip * KS;
+  // fragment address of flattened step s (strip s / KS, k-step s % KS):
+  // [n32 = (strip * CW + wc) * 2 + cb][ks][plane][lane][8 halves]
+  // wave-uniform base (SGPRs) + one constant 32-bit lane offset: saddr-form global loads
+  const int wc_u = __builtin_amdgcn_readfirstlane(wc);
+  const char* __restrict__ wf_u = reinterpret_cast<const char*>(p.Wfrag + (size_t)g * p.Cout * K * 2);
+  const uint32_t wf_lane = (uint32_t)lane * 16u;
+  constexpr size_t cb_stride = (size_t)KS * 2048;           // bytes between n32 and n32 + 1
+  constexpr size_t strip_stride = (size_t)CW * 2 * cb_stride;   // bytes between strips
+  auto wfrag_ptr = [&](int strip, int ks, int cb, int pl) {
+    const char* u = wf_u + ((size_t)strip * strip_stride + (size_t)(wc_u * 2 + cb) * cb_stride +
+                            (size_t)(ks * 2 + pl) * 1024);
+    return reinterpret_cast<const uint4*>(u + wf_lane);
+  };
+  uint4 ring[GR_RING][2][2];
+  // KS % RING == 0 and KS >= RING: the first RING steps are in strip 0
+#pragma unroll
+  for (int d = 0; d < GR_RING; ++d)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) ring[d][cb][pl] = *wfrag_ptr(0, d, cb, pl);
+
+  // prologue: the A panel -> two fp16 planes in LDS
+  {
+    ALoader<LOADER, RPT, RS> ld;
+    ld.init(p, p0, g, t);
+    const int chunk = t & 7, srow = t >> 3;
+    // K % 64 == 0: two 32-wide K tiles (2 RPT loads) in flight per round
+    for (int kt = 0; kt < K / 32; kt += 2) {
+      float4 ra[2][RPT];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int s = 0; s < RPT; ++s) ra[u][s] = ld.load(p, s, (kt + u) * 32 + chunk * 4, t);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int s = 0; s < RPT; ++s) {
+          uint2 h, l;
+          split2_h<LOADER == LOAD_GATHER>(ra[u][s], sa, h, l);
+          uint16_t* dst = Ah + (srow + RS * s) * astr + (kt + u) * 32 + chunk * 4;
+          *reinterpret_cast<uint2*>(dst) = h;
+          *reinterpret_cast<uint2*>(dst + aplane) = l;
+        }
+    }
+  }
+  __syncthreads();
+
+  const uint16_t* a_lane = Ah + (wr * 64 + li) * astr + 8 * lh;
+  f32x16 acc[2][2];   // SWAP: [channel block][position block]; else [position block][channel block]
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  zero_acc();
+
+  f16x8 afn[2][2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+      afn[rb][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(
+          a_lane + pl * aplane + rb * 32 * astr));
+  int strip = 0, ks0 = 0;             // position of ring slot 0 in (strip, k-step)
+  float e_sc = 0.f, e_bias = 0.f;     // epilogue scale / bias of channel n0 + lane (loaded a strip ahead)
+  for (int s0 = 0; s0 < total; s0 += GR_RING) {
+    if (ks0 == 0) {
+      const int n = (strip * CW + wc) * 64 + lane;
+      e_sc = inv_sa * wsc[n];
+      e_bias = bg[n];
+    }
+    // the slots refilled this round hold the steps RING ahead
+    int nstrip_ = strip, nks0 = ks0 + GR_RING;
+    if (nks0 == KS) {
+      nks0 = 0;
+      ++nstrip_;
+    }
+    if (nstrip_ == nstrip) {   // tail: re-read the last round (never used)
+      nstrip_ = strip;
+      nks0 = ks0;
+    }
+#pragma unroll
+    for (int d = 0; d < GR_RING; ++d) {
+      // A fragments of the NEXT step are read from LDS before this step's MFMAs
+      // are issued (the panel is the same for every strip: k wraps around)
+      const int ksn = (ks0 + d + 1 == KS) ? 0 : ks0 + d + 1;
+      f16x8 af[2][2], bf[2][2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          af[rb][pl] = afn[rb][pl];
+          afn[rb][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(
+              a_lane + pl * aplane + rb * 32 * astr + ksn * 16));
+        }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) bf[cb][pl] = __builtin_bit_cast(f16x8, ring[d][cb][pl]);
+      // refill this ring slot with the step RING ahead
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) ring[d][cb][pl] = *wfrag_ptr(nstrip_, nks0 + d, cb, pl);
+#define S4G_R_TERM(PA, PB)                                                                              \
+  if constexpr (SWAP) {                                                                                 \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0][PB], af[0][PA], acc[0][0], 0, 0, 0);       \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0][PB], af[1][PA], acc[0][1], 0, 0, 0);       \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[1][PB], af[0][PA], acc[1][0], 0, 0, 0);       \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[1][PB], af[1][PA], acc[1][1], 0, 0, 0);       \
+  } else {                                                                                              \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][PA], bf[0][PB], acc[0][0], 0, 0, 0);       \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][PA], bf[1][PB], acc[0][1], 0, 0, 0);       \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][PA], bf[0][PB], acc[1][0], 0, 0, 0);       \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][PA], bf[1][PB], acc[1][1], 0, 0, 0);       \
+  }
+      S4G_R_TERM(0, 1)
+      S4G_R_TERM(1, 0)
+      S4G_R_TERM(0, 0)
+#undef S4G_R_TERM
+    }
+    // KS % RING == 0: a strip can only end at the end of a ring round
+    const int strip_done = strip;
+    const bool done = ks0 + GR_RING == KS;
+    ks0 += GR_RING;
+    if (done) {
+      ks0 = 0;
+      ++strip;
+    }
+    if (!done) continue;
+      const int n0 = (strip_done * CW + wc) * 64;
+    float tmax = 0.f;
+    if constexpr (SWAP) {
+      // lane: position li of position block pb; registers 4 j .. 4 j + 3 = channels
+      // n0 + 32 nb + 8 j + 4 lh + (0..3)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + nb * 32 + 8 * j + 4 * lh;
+          float scv[4], bv[4];   // channel n + e lives in lane nb*32 + 8j + 4lh + e of e_sc / e_bias
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c0 = nb * 32 + 8 * j + e;
+            const float s0v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e_sc), c0));
+            const float s1v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e_sc), c0 + 4));
+            const float b0v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e_bias), c0));
+            const float b1v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e_bias), c0 + 4));
+            scv[e] = lh ? s1v : s0v;
+            bv[e] = lh ? b1v : b0v;
+          }
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x = acc[nb][pb][4 * j + e] * scv[e] + bv[e];
+              if (p.relu) x = fmaxf(x, 0.f);
+              v[e] = x;
+              tmax = fmaxf(tmax, fabsf(x));
+            }
+            const int row = p0 + wr * 64 + pb * 32 + li;
+            if (row < p.P)
+              *reinterpret_cast<float4*>(p.out + (size_t)row * p.ldc + p.c_coff + g * p.c_gcol + n) =
+                  make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      if (p.out_amax) {
+        const uint32_t wm = wave_max_u32(__float_as_uint(tmax));
+        if (lane == 0) atomicMax(p.out_amax + ((blockIdx.x * 4 + wave + strip_done) & 63), wm);
+      }
+    } else {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        // channel n0 + cb*32 + li: lane cb*32 + li of e_sc / e_bias
+        const float sc = __shfl(e_sc, cb * 32 + li);
+        const float bias = __shfl(e_bias, cb * 32 + li);
+        float mx = -__builtin_inff(), mn = __builtin_inff();
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[rb][cb][r] * sc;
+            acc[rb][cb][r] = v;
+            mx = fmaxf(mx, v);
+            mn = fminf(mn, v);
+          }
+        const float hi = mx + bias, lo = mn + bias;
+        tmax = fmaxf(tmax, p.relu ? hi : fmaxf(fabsf(hi), fabsf(lo)));
+      }
+      if (p.out_amax) {
+        const uint32_t wm = wave_max_u32(__float_as_uint(fmaxf(tmax, 0.f)));
+        if (lane == 0) atomicMax(p.out_amax + ((blockIdx.x * 4 + wave + strip_done) & 63), wm);
+      }
+      gemm_epilogue<EPI, 2>(p, acc, bg, g, p0, n0, wave, wr, 0, li, lh, smemf);
+    }
+    zero_acc();
+    }
+}
+
+template <int LOADER, int EPI, int RW, int KT>
+static int launch_gemm_f16x2_resident(const GemmParams& p, int groups, hipStream_t st) {
+  constexpr int BM = 64 * RW;
+  constexpr size_t lds = sizeof(uint16_t) * 2 * BM * (size_t)(KT + 8);
+  static_assert(lds <= 80 * 1024, "two workgroups per CU");
+  static const hipError_t attr = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&mlp_gemm_f16x2_resident_kernel<LOADER, EPI, RW, KT>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr != hipSuccess) return (int)attr;
+  const dim3 grid((unsigned)((p.P + BM - 1) / BM), (unsigned)groups);
+  hipLaunchKernelGGL((mlp_gemm_f16x2_resident_kernel<LOADER, EPI, RW, KT>), grid, dim3(256), lds, st, p);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
+
 template <int LOADER, int EPI>
 static int launch_gemm_f16x2(const GemmParams& p, int groups, hipStream_t st) {
   static const int force = [] { const char* e = getenv("S4G_GEMM_NCB"); return e ? atoi(e) : 0; }();
+  // S4G_GEMM_RESIDENT=0 never / 1 whenever the shape qualifies / unset: only where it
+  // measured faster than the tiled kernel (Cout >= 1024: +6 %; short strips lose to
+  // the per-workgroup prologue)
+  const char* rmode = getenv("S4G_GEMM_RESIDENT");
+  const bool no_resident = rmode && rmode[0] == '0';
+  const bool any_resident = rmode && rmode[0] == '1';
+  if constexpr (EPI != EPI_CHANNEL_FIRST && LOADER != LOAD_INTERP) {
+    // resident-A kernel: short contractions whose A panel fits LDS twice per CU
+    const bool vec_ok = ((p.ldc | p.c_coff | p.c_gcol) & 3) == 0 &&
+                        ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
+    if (!no_resident && !force && p.Wfrag && (EPI != EPI_STORE || vec_ok) &&
+        (EPI != EPI_MAX || p.K == 64) && (any_resident || p.Cout >= 1024)) {
+      if (p.Kpad16 == 256 && p.Cout % 256 == 0)
+        return launch_gemm_f16x2_resident<LOADER, EPI, 1, 256>(p, groups, st);
+      if (p.Kpad16 == 128 && p.Cout % 256 == 0)
+        return launch_gemm_f16x2_resident<LOADER, EPI, 1, 128>(p, groups, st);
+      if (p.Kpad16 == 128 && p.Cout % 128 == 0)
+        return launch_gemm_f16x2_resident<LOADER, EPI, 2, 128>(p, groups, st);
+      if (p.Kpad16 == 64 && p.Cout % 256 == 0)
+        return launch_gemm_f16x2_resident<LOADER, EPI, 1, 64>(p, groups, st);
+      if (p.Kpad16 == 64 && p.Cout % 128 == 0)
+        return launch_gemm_f16x2_resident<LOADER, EPI, 2, 64>(p, groups, st);
+    }
+  }
   // the INTERP / GATHER loaders hold too much per-row state for the wide tile's
   // 128 accumulator registers (they would spill)
   const bool wide = force ? force == 4
@@ -986,6 +1292,7 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   p.w_inv_scale = d->w_inv_scale;
   p.a_amax = d->a_amax; p.a_amax2 = d->a_amax2; p.a_amax_floor = d->a_amax_floor;
   p.out_amax = (uint32_t*)d->out_amax;
+  p.Wfrag = (const uint16_t*)d->W_f16x2_frag;
   p.mtiles = (d->P + GM_BM - 1) / GM_BM;
   p.ntiles = (d->Cout + GM_BN - 1) / GM_BN;
   hipStream_t st = (hipStream_t)stream;

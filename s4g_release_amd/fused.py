@@ -91,6 +91,17 @@ def split_f16x2(w):
     return torch.stack([w1, w2], dim=0).contiguous(), torch.ldexp(one, ex - 15).contiguous()
 
 
+def fragment_order(planes):
+    """(2, G, Cout, K16) fp16 planes -> (G, Cout/32, K16/16, 2, 64, 8): each 32-channel x
+    16-deep MFMA operand fragment as one contiguous 1 KB block per plane, lane =
+    32 * (k // 8 % 2) + n % 32 (the 32x32x16 A/B operand layout)."""
+    if planes.dim() == 3:
+        planes = planes.unsqueeze(1)
+    two, G, cout, k16 = planes.shape
+    x = planes.view(2, G, cout // 32, 32, k16 // 16, 2, 8)      # pl g n32 li ks lh i
+    return x.permute(1, 2, 4, 0, 5, 3, 6).contiguous()           # g n32 ks pl lh li i
+
+
 class _Layer:
     """Folded weights of one launch: W (groups, Cout, Kpad), bias (groups, Cout),
     plus the bf16x3 planes (3, groups, Cout, Kpad16) and the scaled fp16x2 planes
@@ -108,6 +119,7 @@ class _Layer:
         w16[..., :self.kpad] = self.W
         self.W3 = split_bf16x3(w16)
         self.Wh2, self.w_inv_scale = split_f16x2(w16)
+        self.Wfrag = fragment_order(self.Wh2) if self.cout % 32 == 0 else None
 
 
 class FusedPointNet2:
@@ -211,6 +223,8 @@ class FusedPointNet2:
         d.precision = {"fp32": 0, "bf16x3": 1, "bf16": 2, "f16x2": 3}[self.precision]
         d.Kpad16, d.W_bf16x3 = layer.kpad16, layer.W3.data_ptr()
         d.W_f16x2, d.w_inv_scale = layer.Wh2.data_ptr(), layer.w_inv_scale.data_ptr()
+        if layer.Wfrag is not None:
+            d.W_f16x2_frag = layer.Wfrag.data_ptr()
         for k, v in kw.items():
             if isinstance(v, torch.Tensor):
                 v = v.data_ptr()

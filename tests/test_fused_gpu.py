@@ -15,6 +15,17 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+@pytest.fixture(params=["tiled", "resident"])
+def gemm_variant(request, monkeypatch):
+    """Unit tests run twice: default dispatch, and with the resident-A kernel
+    forced for every shape it supports (S4G_GEMM_RESIDENT is read per launch)."""
+    if request.param == "resident":
+        monkeypatch.setenv("S4G_GEMM_RESIDENT", "1")
+    else:
+        monkeypatch.setenv("S4G_GEMM_RESIDENT", "0")
+    return request.param
+
+
 def _run(desc_kwargs, dev):
     from s4g_release_amd import _cabi
     d = _cabi.GemmDesc()
@@ -46,7 +57,7 @@ def _h2(w, *tensors, floor=0.0):
     """Descriptor fields of the f16x2 mode: scaled fp16 planes of W, per-channel
     inverse scales, one 64-slot amax row per input tensor (the slot position is
     arbitrary) and a zeroed out_amax row."""
-    from s4g_release_amd.fused import split_f16x2
+    from s4g_release_amd.fused import fragment_order, split_f16x2
     k = w.shape[-1]
     kp = (k + 15) // 16 * 16
     w16 = w.new_zeros(w.shape[:-1] + (kp,))
@@ -54,6 +65,9 @@ def _h2(w, *tensors, floor=0.0):
     planes, inv = split_f16x2(w16)
     kw = dict(W_f16x2=planes, w_inv_scale=inv, a_amax_floor=float(floor),
               out_amax=torch.zeros(64, device=w.device))
+    if w.shape[-2] % 32 == 0:     # enables the resident-A kernel where the shape qualifies
+        p4 = planes if planes.dim() == 4 else planes.unsqueeze(1)
+        kw["W_f16x2_frag"] = fragment_order(p4)
     for name, t in zip(("a_amax", "a_amax2"), [t for t in tensors if t is not None]):
         row = torch.zeros(64, device=w.device)
         row[17] = t.abs().max()
@@ -77,9 +91,12 @@ def _padk(w):
 
 @pytest.mark.parametrize("P,Cin,Cout,relu", [(128, 32, 128, True), (1000, 128, 256, True),
                                              (77, 260, 21, False), (4096, 1536, 1024, True),
-                                             (300, 8, 130, True)])
+                                             (300, 8, 130, True),
+                                             # resident-A kernel shapes (K % 64 == 0, Cout % 128 == 0)
+                                             (777, 256, 512, True), (300, 128, 128, False),
+                                             (4100, 64, 256, True), (64, 256, 2048, True)])
 @pytest.mark.parametrize("prec", PRECISIONS)
-def test_gemm_plain_store(dev, P, Cin, Cout, relu, prec):
+def test_gemm_plain_store(dev, P, Cin, Cout, relu, prec, gemm_variant):
     g = torch.Generator(device="cpu").manual_seed(P + Cin)
     A = torch.randn(P, Cin, generator=g).to(dev)
     W = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).to(dev)
@@ -100,10 +117,11 @@ def test_gemm_plain_store(dev, P, Cin, Cout, relu, prec):
     assert (out.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("Cin,Cout", [(64, 48), (64, 128), (128, 256)])
 @pytest.mark.parametrize("prec", PRECISIONS)
-def test_gemm_grouped_column_slices(dev, prec):
+def test_gemm_grouped_column_slices(dev, prec, Cin, Cout, gemm_variant):
     g = torch.Generator(device="cpu").manual_seed(3)
-    P, G, Cin, Cout = 700, 4, 64, 48
+    P, G = 700, 4
     A = torch.randn(P, G * Cin, generator=g).to(dev)
     W = (torch.randn(G, Cout, Cin, generator=g) / 8).to(dev)
     b = torch.randn(G, Cout, generator=g).to(dev)
@@ -154,6 +172,61 @@ def test_gemm_gather_max(dev, K, Cf, prec):
     A = torch.stack(rows).double()                                  # (B,M,K,Cin)
     ref = (A @ W.double().t() + b.double()).clamp_min(0).max(dim=2)[0].view(B * M, Cout)
     assert (out.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("Cin,Cout,K", [(128, 256, 64), (256, 512, 64), (64, 128, 64), (96, 160, 32)])
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_gemm_plain_max(dev, Cin, Cout, K, prec, gemm_variant):
+    """Last SA layer: max over the K neighbour rows of each centroid, then bias + ReLU."""
+    g = torch.Generator(device="cpu").manual_seed(Cin + Cout)
+    groups_n = 37
+    P = groups_n * K
+    A = torch.randn(P, Cin, generator=g).to(dev)
+    W = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    out = torch.full((groups_n, Cout), float("nan"), device=dev)
+    Wp = _padk(W)
+    k16, w3 = _w3(W)
+    h2 = _h2(W, A)
+    _run(dict(loader=0, epilogue=1, groups=1, relu=1, P=P, Cin=Cin, Kpad=Wp.shape[1], Cout=Cout,
+              W=Wp, bias=b, A=A, lda=Cin, K=K, out=out, ldc=Cout, precision=prec, Kpad16=k16,
+              W_bf16x3=w3, **h2), dev)
+    ref = (A.double() @ W.double().t() + b.double()).clamp_min(0).view(groups_n, K, Cout).max(dim=1)[0]
+    assert (out.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    if prec == 3:
+        _check_out_amax(h2, out)
+
+
+@pytest.mark.parametrize("C1,Cout,epi", [(128, 128, 0), (128, 256, 1), (32, 64, 0)])
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_gemm_gather_mlp1(dev, C1, Cout, epi, prec, gemm_variant):
+    """First (xyz-only) SA layer evaluated inside the second layer's loader."""
+    g = torch.Generator(device="cpu").manual_seed(C1 + Cout + epi)
+    B, N, M, K = 2, 400, 21, 64
+    xyz = (torch.rand(B, 3, N, generator=g) * 0.2).to(dev)
+    cidx = torch.randint(0, N, (B, M), generator=g)
+    ctr = torch.stack([xyz[b][:, cidx[b]] for b in range(B)]).contiguous()
+    gidx = torch.randint(0, N, (B, M, K), generator=g).int().to(dev)
+    w1 = torch.randn(C1, 4, generator=g).to(dev)                   # wx, wy, wz, bias
+    W = (torch.randn(Cout, C1, generator=g) / C1 ** 0.5).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    P = B * M * K
+    rows = B * M if epi == 1 else P
+    out = torch.full((rows, Cout), float("nan"), device=dev)
+    Wp = _padk(W)
+    k16, w3 = _w3(W)
+    bound = float((w1[:, :3].abs().sum(1) * 0.4 + w1[:, 3].abs()).max())
+    h2 = _h2(W, floor=bound)
+    _run(dict(loader=3, epilogue=epi, groups=1, relu=1, P=P, Cin=C1, Kpad=Wp.shape[1], Cout=Cout,
+              W=Wp, bias=b, gidx=gidx, xyz=xyz, ctr=ctr, N=N, M=M, K=K, mlp1_w=w1, out=out,
+              ldc=Cout, precision=prec, Kpad16=k16, W_bf16x3=w3, **h2), dev)
+    rel = torch.stack([xyz[bi][:, gidx[bi].long()] - ctr[bi][:, :, None] for bi in range(B)])  # (B,3,M,K)
+    rel = rel.permute(0, 2, 3, 1).reshape(P, 3).double()
+    A = (rel @ w1[:, :3].double().t() + w1[:, 3].double()).clamp_min(0)
+    ref = (A @ W.double().t() + b.double()).clamp_min(0)
+    if epi == 1:
+        ref = ref.view(B * M, K, Cout).max(dim=1)[0]
+    assert (out.double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("prec", PRECISIONS)

@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from s4g_release_amd import _cabi  # noqa: E402
-from s4g_release_amd.fused import split_bf16x3, split_f16x2  # noqa: E402
+from s4g_release_amd.fused import fragment_order, split_bf16x3, split_f16x2  # noqa: E402
 
 
 def main():
@@ -35,6 +35,15 @@ def main():
     d.P, d.Cin, d.Kpad, d.Cout = P, K, K, N
     d.W, d.bias, d.A, d.lda, d.out, d.ldc = W.data_ptr(), b.data_ptr(), A.data_ptr(), K, out.data_ptr(), N
     d.precision, d.Kpad16, d.W_bf16x3 = a.prec, k16, w3.data_ptr()
+    wh2, winv = split_f16x2(w16)
+    amax_in = torch.zeros(64, device=dev)
+    amax_in[0] = A.abs().max()
+    amax_out = torch.zeros(64, device=dev)
+    d.W_f16x2, d.w_inv_scale = wh2.data_ptr(), winv.data_ptr()
+    d.a_amax, d.out_amax = amax_in.data_ptr(), amax_out.data_ptr()
+    if N % 32 == 0:
+        wfrag = fragment_order(wh2.view(2, 1, N, k16))
+        d.W_f16x2_frag = wfrag.data_ptr()
     wh2, winv = split_f16x2(w16)
     amax_in = torch.zeros(64, device=dev)
     amax_in[0] = A.abs().max()
