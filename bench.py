@@ -217,7 +217,9 @@ def main():
         pass
     try:
         with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            tr = json.load(f).get("mlp_gemm_bf16x3_kernel[step,B=%d,N=%d]" % (B, N))
+            kname = "mlp_gemm_f16x2_kernel" if getattr(runner, "precision", "") == "f16x2" \
+                else "mlp_gemm_bf16x3_kernel"
+            tr = json.load(f).get("%s[step,B=%d,N=%d]" % (kname, B, N))
         dense_traffic = (tr["traffic_bytes"], tr["source"]) if tr else None
     except (OSError, ValueError):
         dense_traffic = None
