@@ -303,6 +303,38 @@ int s4g_collision_counts_f32(const float *xyz_b3n, const float *g2l_bk44, int64_
                              int64_t N, int64_t K, const float *gripper6,
                              int32_t *counts_bk2, s4g_stream_t stream);
 
+/* ---- next row f3: cloud pre-processing on device -------------------------
+ * Single-scene passes in front of the network (reference
+ * grasp_proposal/cloud_processor/cloud_processor.py:12-42, constants
+ * configs/processing_config.py:17-23, caller grasp_detector.py:94-105).  The
+ * reference delegates voxelisation and outlier removal to open3d (>= 0.12,
+ * absent here) and discards their results; the semantics below restate open3d's
+ * published algorithms (oracle/preprocess.py; parity unpinned).
+ *
+ * s4g_crop_indices_f32: CloudPreProcessor.filter_work_space (:12-29).
+ *   workspace6 = {lo_x, hi_x, lo_y, hi_y, lo_z, hi_z} (HOST pointer); index_n
+ *   receives the ascending indices of the points strictly inside the box,
+ *   *count (device) their number.
+ * s4g_voxel_down_sample_f32: CloudPreProcessor.voxelize (:38-41) = open3d
+ *   VoxelDownSample.  origin3 / dims3 are HOST pointers: origin = min(points) -
+ *   voxel/2, dims = cells per axis (product < 2^32).  out_3n is (3, N) with row
+ *   stride N: the first *count columns hold the cell means (double sum in point
+ *   order, rounded once), cells in ascending (iz, iy, ix) order.
+ * s4g_radius_outlier_mask_f32: CloudPreProcessor.remove_outliers (:31-36) = open3d
+ *   RemoveRadiusOutliers.  keep_n[j] = 1 iff more than nb_points points (j itself
+ *   included) lie at squared distance < radius^2 (canonical fp32 arithmetic).
+ *   Workspace: s4g_radius_outlier_workspace_bytes(N) (0 for N > 65536: scan). */
+int s4g_crop_indices_f32(const float *xyz_3n, int64_t N, const float *workspace6,
+                         int32_t *index_n, int32_t *count, s4g_stream_t stream);
+size_t s4g_voxel_down_sample_workspace_bytes(int64_t N);
+int s4g_voxel_down_sample_f32(const float *xyz_3n, int64_t N, float voxel,
+                              const float *origin3, const int32_t *dims3, float *out_3n,
+                              int32_t *count, void *ws, size_t ws_bytes, s4g_stream_t stream);
+size_t s4g_radius_outlier_workspace_bytes(int64_t N);
+int s4g_radius_outlier_mask_f32(const float *xyz_3n, int64_t N, float radius,
+                                int32_t nb_points, uint8_t *keep_n, void *ws, size_t ws_bytes,
+                                int flags, s4g_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

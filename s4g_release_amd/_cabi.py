@@ -59,6 +59,12 @@ SIGNATURES = {
                                         _vp, _vp]),
     "s4g_query_group_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _vp, _sz,
                                    _int, _vp]),
+    "s4g_crop_indices_f32": (_int, [_vp, _i64, ctypes.POINTER(ctypes.c_float), _vp, _vp, _vp]),
+    "s4g_voxel_down_sample_workspace_bytes": (_sz, [_i64]),
+    "s4g_voxel_down_sample_f32": (_int, [_vp, _i64, _f32, ctypes.POINTER(ctypes.c_float),
+                                         ctypes.POINTER(ctypes.c_int32), _vp, _vp, _vp, _sz, _vp]),
+    "s4g_radius_outlier_workspace_bytes": (_sz, [_i64]),
+    "s4g_radius_outlier_mask_f32": (_int, [_vp, _i64, _f32, _i32, _vp, _vp, _sz, _int, _vp]),
     "s4g_abi_version": (_int, []),
     "s4g_error_string": (ctypes.c_char_p, [_int]),
     "s4g_workspace_bytes": (_sz, [_int, _i64, _i64, _i64, _i64]),
