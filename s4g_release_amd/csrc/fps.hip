@@ -20,6 +20,9 @@
 //   * larger clouds fall back to a streaming kernel (xyz from L2, min-distance
 //     in a global workspace).
 #include <stdlib.h>
+#include <string.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "s4g_common.h"
 
@@ -251,6 +254,403 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_stream_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Pruned variant (N > 5 120): same per-step exchange, but a step only rescans the
+// 64-point groups the new centroid can still change.
+//
+// The scene is put in Morton order first (fps_bbox / fps_morton kernels + one
+// radix sort); group g = sorted positions [64 g, 64 g + 64) is slot g / 8 of wave
+// g % 8, so a group is a compact patch and neighbouring patches sit in different
+// waves.  Lane l of a wave keeps, for "its" group (slot l), the bounding box and
+// the exact maximum Mg of the group's running min-distances.  A new centroid c
+// cannot lower any min-distance of a group whose box is at squared distance
+//   LB = ((tx*tx) + (ty*ty)) + (tz*tz) >= Mg,   t = lo - c | hi - c | 0 per axis,
+// because every fp32 operation of the distance contract is monotone: LB is a lower
+// bound of the ROUNDED distance of every point in the box.  Skipped groups keep
+// their min-distances and Mg bit for bit, so the selected index sequence is the
+// one of the full scan (tests compare against the oracle).  On the bench scenes a
+// centroid touches 9 of 400 groups on average (64 in the first 48 steps); the
+// first FPS_DENSE_STEPS steps use the full scan and the maxima are computed once
+// afterwards.  OPT-IN (S4G_FPS_MODE=pruned): see fps_use_pruned for why.
+// The winner is resolved lazily: wave max over the Mg lanes, then the lane(s) of
+// that group that hold it (static register index through a scalar branch tree),
+// original index and tie key from an LDS table.
+// ---------------------------------------------------------------------------
+constexpr int FPS_DENSE_STEPS = 48;
+
+__device__ __forceinline__ uint32_t f32_ordered(float v) {   // order-preserving float -> uint
+  const uint32_t b = __float_as_uint(v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_f32(uint32_t u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+
+__global__ __launch_bounds__(1024) void fps_bbox_kernel(const float* __restrict__ xyz, int N,
+                                                         float* __restrict__ bbox) {
+  __shared__ uint32_t red[6][16];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* p = xyz + (size_t)b * 3 * N;
+  uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+  for (int j = t; j < N; j += 1024)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const uint32_t v = f32_ordered(p[(size_t)a * N + j]);
+      lo[a] = min(lo[a], v);
+      hi[a] = max(hi[a], v);
+    }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const uint32_t l = wave_min_u32(lo[a]), h = wave_max_u32(hi[a]);
+    if (lane == 0) {
+      red[a][wave] = l;
+      red[3 + a][wave] = h;
+    }
+  }
+  __syncthreads();
+  if (t < 6) {
+    uint32_t v = red[t][0];
+    for (int w = 1; w < 16; ++w) v = t < 3 ? min(v, red[t][w]) : max(v, red[t][w]);
+    bbox[b * 6 + t] = ordered_f32(v);
+  }
+}
+
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {   // 10 bits -> every third bit
+  v &= 0x3FFu;
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+__global__ void fps_morton_kernel(const float* __restrict__ xyz, int N, int B,
+                                  const float* __restrict__ bbox, uint64_t* __restrict__ key,
+                                  int* __restrict__ val) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (j >= N) return;
+  const float* p = xyz + (size_t)b * 3 * N;
+  const float* bb = bbox + b * 6;
+  uint32_t q[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float ext = bb[3 + a] - bb[a];
+    const float u = ext > 0.f ? (p[(size_t)a * N + j] - bb[a]) / ext : 0.f;   // ordering only: any rounding will do
+    const float s = u * 1023.0f;
+    q[a] = (uint32_t)(s < 0.f ? 0.f : (s > 1023.f ? 1023.f : s));
+  }
+  const uint32_t m = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+  key[(size_t)b * N + j] = ((uint64_t)b << 30) | m;
+  val[(size_t)b * N + j] = j;
+}
+
+// Bounding box of every 64-point group of the sorted order: one wave per group.
+__global__ __launch_bounds__(256) void fps_group_box_kernel(const float* __restrict__ xyz,
+                                                            const int* __restrict__ perm, int N,
+                                                            int G, float* __restrict__ gbox) {
+  const int b = blockIdx.y;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (g >= G) return;
+  const float* p = xyz + (size_t)b * 3 * N;
+  const int s = 64 * g + lane;
+  const bool ok = s < N;
+  const int j = ok ? perm[(size_t)b * N + s] : 0;
+  float* o = gbox + ((size_t)b * G + g) * 6;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const uint32_t v = f32_ordered(p[(size_t)a * N + j]);
+    const uint32_t lo = wave_min_u32(ok ? v : 0xFFFFFFFFu), hi = wave_max_u32(ok ? v : 0u);
+    if (lane == 0) {
+      o[a] = ordered_f32(lo);
+      o[3 + a] = ordered_f32(hi);
+    }
+  }
+}
+
+// md[pw] of every lane for a wave-uniform slot pw (static register index per leaf)
+template <int PPT, int LO, int HI>
+__device__ __forceinline__ float fps_pick_md(const float (&md)[PPT], int pw) {
+  if constexpr (HI - LO == 1) {
+    float v = md[LO];
+    asm volatile("; fps pick %1" : "+v"(v) : "n"(LO));
+    return v;
+  } else {
+    constexpr int MID = (LO + HI) / 2;
+    if (pw < MID) return fps_pick_md<PPT, LO, MID>(md, pw);
+    return fps_pick_md<PPT, MID, HI>(md, pw);
+  }
+}
+
+// update of one group (slot P of this wave): distances, running minimum, new group maximum
+template <int PPT, int LO, int HI, bool FMAD>
+__device__ __forceinline__ void fps_update_slot(const float (&x)[PPT], const float (&y)[PPT],
+                                                const float (&z)[PPT], float (&md)[PPT], int p,
+                                                float cx, float cy, float cz, float& gmax) {
+  if constexpr (HI - LO == 1) {
+    // volatile: keeps this leaf behind its (wave-uniform) branch -- without it the
+    // compiler if-converts the tree and evaluates every slot's distance each step
+    // (the distance is computed from the asm's output, so it cannot be hoisted either)
+    float xl = x[LO];
+    asm volatile("; fps slot %1" : "+v"(xl) : "n"(LO));
+    const float d = dist2<FMAD>(cx, cy, cz, xl, y[LO], z[LO]);
+    float m;
+    asm volatile("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(d), "v"(md[LO]));
+    md[LO] = m;
+    const uint32_t g = wave_max_u32(__float_as_uint(m));   // m >= 0: the bit pattern orders like the value
+    gmax = __uint_as_float(g);
+  } else {
+    constexpr int MID = (LO + HI) / 2;
+    if (p < MID)
+      fps_update_slot<PPT, LO, MID, FMAD>(x, y, z, md, p, cx, cy, cz, gmax);
+    else
+      fps_update_slot<PPT, MID, HI, FMAD>(x, y, z, md, p, cx, cy, cz, gmax);
+  }
+}
+
+template <int THREADS, int PPT, bool FMAD, typename IdxT>
+__global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __restrict__ xyz,
+                                                             const int* __restrict__ perm,
+                                                             const float* __restrict__ gbox, int N,
+                                                             int M, IdxT* __restrict__ idx,
+                                                             float* __restrict__ ctr, int lg_bs) {
+  constexpr int WAVES = THREADS / 64;
+  constexpr int GPL = (PPT + 63) / 64;   // group registers per lane: slot p lives in lane p % 64, reg p / 64
+  __shared__ FpsSlot slots[2][FPS_MAX_WAVES];
+  extern __shared__ uint16_t orig[];   // [WAVES * PPT * 64] sorted position -> original index
+  const int b = blockIdx.x;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const float* __restrict__ px = xyz + (size_t)b * 3 * N;
+  const float* __restrict__ py = px + N;
+  const float* __restrict__ pz = py + N;
+  const int* __restrict__ pb = perm + (size_t)b * N;
+  IdxT* __restrict__ out = idx + (size_t)b * M;
+  float* __restrict__ cout = ctr ? ctr + (size_t)b * 3 * M : nullptr;
+  const uint32_t bs_mask = (1u << lg_bs) - 1u;
+  auto tie_key = [&](uint32_t j) { return ((__brev(j & bs_mask) >> (32 - lg_bs)) << 23) | j; };
+
+  // slot p of this lane = sorted position 64 * (WAVES * p + wave) + lane
+  float x[PPT], y[PPT], z[PPT], md[PPT];
+  float blx[GPL], bly[GPL], blz[GPL], bhx[GPL], bhy[GPL], bhz[GPL];   // boxes of this lane's groups
+  float mg[GPL];                                                      // their max min-distances
+  constexpr int G = WAVES * PPT;           // groups of this scene (fps_group_box_kernel's G)
+#pragma unroll
+  for (int r = 0; r < GPL; ++r) {
+    const int slot = 64 * r + lane;          // group slot of this lane: group WAVES * slot + wave
+    const float* gb = gbox + ((size_t)b * G + (slot < PPT ? WAVES * slot + wave : 0)) * 6;
+    blx[r] = gb[0]; bly[r] = gb[1]; blz[r] = gb[2];
+    bhx[r] = gb[3]; bhy[r] = gb[4]; bhz[r] = gb[5];
+    mg[r] = 0.f;
+  }
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    const int s = 64 * (WAVES * p + wave) + lane;
+    const bool ok = s < N;
+    const int j = ok ? pb[s] : 0;
+    x[p] = px[j];
+    y[p] = py[j];
+    z[p] = pz[j];
+    // padding lanes sit at min-distance 0: never a maximum unless every real point is at 0 too
+    md[p] = ok ? __builtin_inff() : 0.0f;
+    orig[s] = (uint16_t)j;
+  }
+  const uint32_t rkey = (__brev((uint32_t)t & bs_mask) >> (32 - lg_bs)) << 23;   // all-zero case only
+  __syncthreads();
+
+  int cur = 0;
+  float cx = px[0], cy = py[0], cz = pz[0];
+  if (t == 0) {
+    out[0] = 0;
+    if (cout) {
+      cout[0] = cx;
+      cout[M] = cy;
+      cout[2 * M] = cz;
+    }
+  }
+
+  auto publish = [&](int i, uint32_t wmax, uint32_t wtie, float sx, float sy, float sz) {
+    fps_block_exchange<WAVES>(slots[i & 1], wave, lane, wmax, wtie, sx, sy, sz, cur, cx, cy, cz);
+    if (t == 0) {
+      out[i] = (IdxT)cur;
+      if (cout) {
+        cout[i] = cx;
+        cout[M + i] = cy;
+        cout[2 * M + i] = cz;
+      }
+    }
+  };
+
+  // ---- dense phase: the first steps touch most groups; full scan -----------
+  const int dense_end = M < FPS_DENSE_STEPS ? M : FPS_DENSE_STEPS;
+  for (int i = 1; i < dense_end; ++i) {
+    float sx = cx, sy = cy, sz = cz;
+    float best = 0.0f;
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      const float d = dist2<FMAD>(cx, cy, cz, x[p], y[p], z[p]);
+      float m;
+      asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(d), "v"(md[p]));
+      md[p] = m;
+      best = fmaxf(best, m);
+    }
+    const uint32_t dbits = __float_as_uint(best);
+    const uint32_t wmax = wave_max_u32(dbits);
+    // a lane's slots are unrelated original indices: compare the keys of every slot
+    // that holds the wave maximum (dense steps are few)
+    uint32_t tie = 0xFFFFFFFFu;
+    int tp = -1;
+    if (wmax != 0u && dbits == wmax) {
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) {
+        const int s = 64 * (WAVES * p + wave) + lane;
+        if (__float_as_uint(md[p]) == wmax && s < N) {
+          const uint32_t k = tie_key(orig[s]);
+          if (k < tie) {
+            tie = k;
+            tp = p;
+          }
+        }
+      }
+    }
+    if (wmax == 0u) tie = rkey | (uint32_t)cur;   // nothing left above 0: repeat `cur`
+    const uint32_t wtie = wave_min_u32(tie);
+    const uint64_t win = __ballot(tie == wtie);
+    const int wl = __ffsll((unsigned long long)win) - 1;
+    const int pw = __builtin_amdgcn_readlane(tp, wl);
+    if (wmax != 0u && pw >= 0) fps_pick<PPT, 0, PPT>(x, y, z, pw, wl, sx, sy, sz);
+    publish(i, wmax, wtie, sx, sy, sz);
+  }
+  // exact group maxima, once
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    const uint32_t g = wave_max_u32(__float_as_uint(md[p]));
+    if (lane == (p & 63)) mg[p >> 6] = __uint_as_float(g);
+  }
+
+  // ---- pruned phase ---------------------------------------------------------
+  for (int i = dense_end; i < M; ++i) {
+    uint32_t wmax, wtie;
+    float sx = cx, sy = cy, sz = cz;
+    // 1. groups the new centroid can still change
+    uint32_t gbits[GPL];
+#pragma unroll
+    for (int r = 0; r < GPL; ++r) {
+      const bool live = 64 * r + lane < PPT;
+      const float tx = cx < blx[r] ? __fsub_rn(blx[r], cx) : (cx > bhx[r] ? __fsub_rn(bhx[r], cx) : 0.f);
+      const float ty = cy < bly[r] ? __fsub_rn(bly[r], cy) : (cy > bhy[r] ? __fsub_rn(bhy[r], cy) : 0.f);
+      const float tz = cz < blz[r] ? __fsub_rn(blz[r], cz) : (cz > bhz[r] ? __fsub_rn(bhz[r], cz) : 0.f);
+      float lb;
+      if constexpr (FMAD) {
+        lb = __fmaf_rn(tz, tz, __fmaf_rn(ty, ty, __fmul_rn(tx, tx)));
+      } else {
+        lb = __fadd_rn(__fadd_rn(__fmul_rn(tx, tx), __fmul_rn(ty, ty)), __fmul_rn(tz, tz));
+      }
+      uint64_t need = __ballot(live && lb < mg[r]);
+      while (need) {
+        const int p = 64 * r + __ffsll((unsigned long long)need) - 1;
+        need &= need - 1;
+        float g = 0.f;
+        fps_update_slot<PPT, 0, PPT, FMAD>(x, y, z, md, p, cx, cy, cz, g);
+        if (lane == (p & 63)) mg[r] = g;
+      }
+      gbits[r] = live ? __float_as_uint(mg[r]) : 0u;
+    }
+    // 2. this wave's candidate: the group(s) holding the largest maximum
+    uint32_t lmax = gbits[0];
+#pragma unroll
+    for (int r = 1; r < GPL; ++r) lmax = max(lmax, gbits[r]);
+    wmax = wave_max_u32(lmax);
+    if (wmax == 0u) {
+      wtie = wave_min_u32(rkey | (uint32_t)cur);   // every point of this wave is at distance 0
+    } else {
+      uint32_t best_key = 0xFFFFFFFFu;
+      int best_p = 0, best_l = 0;
+#pragma unroll
+      for (int r = 0; r < GPL; ++r) {
+        uint64_t gmask = __ballot(gbits[r] == wmax);
+        while (gmask) {                          // one group unless maxima tie across groups
+          const int pw = 64 * r + __ffsll((unsigned long long)gmask) - 1;
+          gmask &= gmask - 1;
+          const float mdv = fps_pick_md<PPT, 0, PPT>(md, pw);
+          const int s = 64 * (WAVES * pw + wave) + lane;
+          const bool hit = s < N && __float_as_uint(mdv) == wmax;
+          const uint64_t eq = __ballot(hit);
+          uint32_t k = 0xFFFFFFFFu;
+          if (hit) k = tie_key(orig[s]);
+          uint32_t kmin;
+          int wl;
+          if (__popcll(eq) == 1) {
+            wl = __ffsll((unsigned long long)eq) - 1;
+            kmin = __builtin_amdgcn_readlane(k, wl);
+          } else {
+            kmin = wave_min_u32(k);
+            wl = __ffsll((unsigned long long)__ballot(k == kmin)) - 1;
+          }
+          if (kmin < best_key) {
+            best_key = kmin;
+            best_p = pw;
+            best_l = wl;
+          }
+        }
+      }
+      wtie = best_key;
+      fps_pick<PPT, 0, PPT>(x, y, z, best_p, best_l, sx, sy, sz);
+    }
+    publish(i, wmax, wtie, sx, sy, sz);
+  }
+}
+
+struct FpsSortWs {
+  float* bbox;
+  float* gbox;
+  uint64_t *key_in, *key_out;
+  int *val_in, *val_out;
+  void* tmp;
+  size_t tmp_bytes, total;
+};
+
+static FpsSortWs fps_sort_ws(void* base, int64_t B, int64_t N) {
+  FpsSortWs w;
+  const size_t n = (size_t)B * (size_t)N;
+  size_t sort_bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr,
+                                  (int*)nullptr, (int*)nullptr, n);
+  w.tmp_bytes = sort_bytes;
+  char* p = (char*)base;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* r = p ? p + off : nullptr;
+    off += (bytes + 255) & ~(size_t)255;
+    return r;
+  };
+  w.bbox = (float*)take(sizeof(float) * 6 * B);
+  w.gbox = (float*)take(sizeof(float) * 6 * B * ((N + 63) / 64 + 256));
+  w.key_in = (uint64_t*)take(sizeof(uint64_t) * n);
+  w.key_out = (uint64_t*)take(sizeof(uint64_t) * n);
+  w.val_in = (int*)take(sizeof(int) * n);
+  w.val_out = (int*)take(sizeof(int) * n);
+  w.tmp = take(w.tmp_bytes);
+  w.total = off;
+  return w;
+}
+
+static bool fps_use_pruned(int64_t N) {
+  // S4G_FPS_MODE=pruned opts in (read per call).  The pruned kernel is exact (same
+  // index sequence, tests) and rescans 43x fewer points on the bench scenes, but as
+  // compiled today it is SLOWER than the full scan (19-36 ms vs 11.3 ms at SA1 size):
+  // the 100-leaf register-indexed dispatch makes the compiler shuttle the point
+  // arrays between VGPRs and AGPRs and reload spilled registers from scratch inside
+  // the step (PMC: 660 VALU + 38 vector-memory reads per wave per step).  It needs a
+  // hand-scheduled inner loop before it can become the default.
+  const char* e = getenv("S4G_FPS_MODE");
+  if (!e || e[0] != 'p') return false;
+  return N > 512 && N <= (int64_t)256 * 100;
+}
+
 static int ref_block_lg(int64_t n) {
   // get_block() of sampling_kernel.cu:34-42 with the switch's 16-thread floor.
   int cnt = 0;
@@ -270,6 +670,46 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
                       hipStream_t stream) {
   const int lg = ref_block_lg(N);
   const dim3 grid((unsigned)B);
+  if (fps_use_pruned(N)) {
+    FpsSortWs w = fps_sort_ws(ws, B, N);
+    if (ws && ws_bytes >= w.total && B < (1 << 16)) {
+      hipLaunchKernelGGL(fps_bbox_kernel, dim3((unsigned)B), dim3(1024), 0, stream, xyz, (int)N, w.bbox);
+      S4G_LAUNCH_CHECK();
+      hipLaunchKernelGGL(fps_morton_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256),
+                         0, stream, xyz, (int)N, (int)B, w.bbox, w.key_in, w.val_in);
+      S4G_LAUNCH_CHECK();
+      int bits = 30;
+      while ((1ll << (bits - 30)) < B) ++bits;
+      size_t tb = w.tmp_bytes;
+      const hipError_t e = rocprim::radix_sort_pairs(w.tmp, tb, w.key_in, w.key_out, w.val_in,
+                                                     w.val_out, (size_t)B * (size_t)N, 0, bits, stream);
+      if (e != hipSuccess) return (int)e;
+      // four waves (one per SIMD): 512 registers per lane, so all four arrays of the
+      // 100 points per lane stay on chip (the allocator parks the colder ones in AGPRs)
+#define S4G_FPS_PRUNED(T, P)                                                                       \
+  if (N <= (int64_t)T * P) {                                                                       \
+    const size_t lds = sizeof(uint16_t) * T * P;                                                   \
+    static const hipError_t attr = hipFuncSetAttribute(                                            \
+        reinterpret_cast<const void*>(&fps_pruned_kernel<T, P, FMAD, IdxT>),                       \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+    if (attr != hipSuccess) return (int)attr;                                                      \
+    constexpr int G = (T / 64) * P;                                                                \
+    hipLaunchKernelGGL(fps_group_box_kernel, dim3((G + 3) / 4, (unsigned)B), dim3(256), 0, stream, \
+                       xyz, w.val_out, (int)N, G, w.gbox);                                         \
+    S4G_LAUNCH_CHECK();                                                                            \
+    hipLaunchKernelGGL((fps_pruned_kernel<T, P, FMAD, IdxT>), grid, dim3(T), lds, stream, xyz,     \
+                       w.val_out, w.gbox, (int)N, (int)M, idx, ctr, lg);                           \
+    S4G_LAUNCH_CHECK();                                                                            \
+    return S4G_OK;                                                                                 \
+  }
+      S4G_FPS_PRUNED(256, 4)
+      S4G_FPS_PRUNED(256, 20)
+      S4G_FPS_PRUNED(256, 40)
+      S4G_FPS_PRUNED(256, 64)
+      S4G_FPS_PRUNED(256, 100)
+#undef S4G_FPS_PRUNED
+    }
+  }
   int variant = 0;  // S4G_FPS_VARIANT=1024x25 | 512x50 | 256x100 (tuning knob)
   if (const char* e = getenv("S4G_FPS_THREADS")) variant = atoi(e);
 #define S4G_FPS_CASE(T, P)                                                   \
@@ -301,7 +741,8 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
 }
 
 size_t fps_workspace_bytes(int64_t B, int64_t N) {
-  if (N <= (int64_t)512 * 50) return 0;
+  if (N <= 0 || B <= 0) return 0;
+  if (N <= (int64_t)512 * 50) return fps_use_pruned(N) ? fps_sort_ws(nullptr, B, N).total : 0;
   return (size_t)B * (size_t)N * sizeof(float);
 }
 

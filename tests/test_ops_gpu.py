@@ -45,6 +45,18 @@ def test_fps_full_size_sa1(F, oracle, dev, variant):
     assert np.array_equal(got, oracle.fps(pts, 5120))
 
 
+@pytest.mark.parametrize("N,M,variant", [(25600, 5120, "tabletop-v1"), (25600, 700, "dup-heavy"),
+                                         (20000, 300, "uniform-box"), (6000, 1500, "tabletop-v1"),
+                                         (700, 700, "dup-heavy")])
+def test_fps_pruned_variant_is_exact(F, oracle, dev, monkeypatch, N, M, variant):
+    """Opt-in group-pruned kernel (Morton order + per-group bounding boxes): skipping a
+    group is exact by monotonicity of the rounded distance, ties included."""
+    monkeypatch.setenv("S4G_FPS_MODE", "pruned")
+    pts = synth.make_batch([3, 5], N, variant=variant)
+    got = F.farthest_point_sample(_t(pts, dev), M).cpu().numpy()
+    assert np.array_equal(got, oracle.fps(pts, M))
+
+
 def test_fps_streaming_fallback_large_cloud(F, oracle, dev):
     pts = synth.make_batch([2], 51200)
     got = F.farthest_point_sample(_t(pts, dev), 300).cpu().numpy()
