@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--points", type=int, default=25600)
     ap.add_argument("--impl", default="auto", choices=["auto", "fused", "modules"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=1,
+    ap.add_argument("--in-flight", type=int, default=2,
                     help="batches kept in flight besides the one being collected")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="collect each batch before submitting the next")

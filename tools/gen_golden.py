@@ -15,6 +15,12 @@ Outputs:
   tests/golden/pn2_small.npz   reduced config, full state_dict + all outputs
   tests/golden/pn2_full.npz    shipped config (curvature_model.yaml), weights by
                                seed + sha256, index hashes, outputs at 64 positions
+  tests/golden/pn2_real.npz    the same for the reference's own sample scene
+                               (inference/2638_view_0.p, `point_cloud` (3, 48 902) f32,
+                               the input of grasp_proposal_test.py:17-32 / configs[0]):
+                               a SEEDED 25 600-point subsample is stored as data (the
+                               demo's np.random.choice is unseeded), shipped config,
+                               weights by seed (no checkpoint ships with the reference)
 """
 import hashlib
 import os
@@ -179,6 +185,34 @@ def main():
         blob["nn%d_head" % li] = a[:, :256].astype(np.int32)
     np.savez_compressed(os.path.join(out_dir, "pn2_full.npz"), **blob)
     print("pn2_full.npz: params %d, outputs at %d positions" % (blob["num_params"], len(pos)))
+
+    # ---- the reference's sample scene through the same network
+    import pickle
+    with open(os.path.join(REF, "2638_view_0.p"), "rb") as f:
+        scene = pickle.load(f)
+    cloud = np.ascontiguousarray(scene["point_cloud"], dtype=np.float32)      # (3, 48902)
+    pick = np.random.default_rng(2638).choice(cloud.shape[1], 25600, replace=False)
+    pts = np.ascontiguousarray(cloud[:, pick][None])                         # (1, 3, 25600)
+    captured.clear()
+    with torch.no_grad():
+        pred = net({"scene_points": torch.from_numpy(pts)})
+    blob = {"seed": np.int64(seed), "points": pts, "source_points": np.int64(cloud.shape[1]),
+            "subsample_seed": np.int64(2638), "state_dict_sha256": np.array(state_dict_sha256(sd)),
+            "positions": pos}
+    for k, v in pred.items():
+        blob["out/" + k] = _np(v)[:, :, pos]
+        blob["outsum/" + k] = np.float64(_np(v).astype(np.float64).sum())
+    for li, r in enumerate(captured["farthest_point_sample"]):
+        blob["fps%d_sha256" % li] = np.array(sha(_np(r)))
+        blob["fps%d_head" % li] = _np(r)[:, :256]
+    for li, (i, c) in enumerate(captured["ball_query"]):
+        blob["ball%d_sha256" % li] = np.array(sha(_np(i)))
+        blob["cnt%d_sha256" % li] = np.array(sha(_np(c)))
+    for li, (i, d) in enumerate(captured["point_search"]):
+        blob["nn%d_sha256" % li] = np.array(sha(_np(i)))
+        blob["nnd%d_sha256" % li] = np.array(sha(_np(d)))
+    np.savez_compressed(os.path.join(out_dir, "pn2_real.npz"), **blob)
+    print("pn2_real.npz: %d of %d points of 2638_view_0.p" % (pts.shape[2], cloud.shape[1]))
 
 
 if __name__ == "__main__":
