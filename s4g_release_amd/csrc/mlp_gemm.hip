@@ -957,7 +957,6 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
   const int li = lane & 31, lh = lane >> 5;
   constexpr int KS = K >> 4;                     // 16-deep steps per channel strip
   const int nstrip = p.Cout / (64 * CW);         // strips this wave walks
-  const int total = nstrip * KS;
   // fragment address of flattened step s (strip s / KS, k-step s % KS):
   // [n32 = (strip * CW + wc) * 2 + cb][ks][plane][lane][8 halves]
   // wave-uniform base (SGPRs) + one constant 32-bit lane offset: saddr-form global loads
@@ -985,28 +984,29 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
     ALoader<LOADER, RPT, RS> ld;
     ld.init(p, p0, g, t);
     const int chunk = t & 7, srow = t >> 3;
-    // K % 64 == 0: two 32-wide K tiles (2 RPT loads) in flight per round
-    for (int kt = 0; kt < K / 32; kt += 2) {
-      float4 ra[2][RPT];
+    // the whole panel is requested before any of it is split: ONE memory round
+    // trip per workgroup (K / 32 * RPT = 16 float4 per thread in flight)
+    constexpr int NKT = K / 32;
+    float4 ra[NKT][RPT];
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int s = 0; s < RPT; ++s) ra[u][s] = ld.load(p, s, (kt + u) * 32 + chunk * 4, t);
+      for (int s = 0; s < RPT; ++s) ra[kt][s] = ld.load(p, s, kt * 32 + chunk * 4, t);
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int s = 0; s < RPT; ++s) {
-          uint2 h, l;
-          split2_h<LOADER == LOAD_GATHER>(ra[u][s], sa, h, l);
-          uint16_t* dst = Ah + (srow + RS * s) * astr + (kt + u) * 32 + chunk * 4;
-          *reinterpret_cast<uint2*>(dst) = h;
-          *reinterpret_cast<uint2*>(dst + aplane) = l;
-        }
-    }
+      for (int s = 0; s < RPT; ++s) {
+        uint2 h, l;
+        split2_h<LOADER == LOAD_GATHER>(ra[kt][s], sa, h, l);
+        uint16_t* dst = Ah + (srow + RS * s) * astr + kt * 32 + chunk * 4;
+        *reinterpret_cast<uint2*>(dst) = h;
+        *reinterpret_cast<uint2*>(dst + aplane) = l;
+      }
   }
   __syncthreads();
 
   const uint16_t* a_lane = Ah + (wr * 64 + li) * astr + 8 * lh;
+  float* epi_s = reinterpret_cast<float*>(Ah + 2 * aplane) + wave * 128;   // [scale 64 | bias 64] per wave
   f32x16 acc[2][2];   // SWAP: [channel block][position block]; else [position block][channel block]
   auto zero_acc = [&]() {
 #pragma unroll
@@ -1025,29 +1025,30 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
     for (int pl = 0; pl < 2; ++pl)
       afn[rb][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(
           a_lane + pl * aplane + rb * 32 * astr));
-  int strip = 0, ks0 = 0;             // position of ring slot 0 in (strip, k-step)
   float e_sc = 0.f, e_bias = 0.f;     // epilogue scale / bias of channel n0 + lane (loaded a strip ahead)
-  for (int s0 = 0; s0 < total; s0 += GR_RING) {
-    if (ks0 == 0) {
+  // The K loop of a strip is fully unrolled: every LDS / fragment offset is an
+  // immediate off one wave-uniform strip pointer, ring slot = k-step % RING.
+  const char* wstrip = wf_u + (size_t)(wc_u * 2) * cb_stride;
+  for (int strip = 0; strip < nstrip; ++strip, wstrip += strip_stride) {
+    const int strip_done = strip;
+    {
       const int n = (strip * CW + wc) * 64 + lane;
       e_sc = inv_sa * wsc[n];
       e_bias = bg[n];
+      if constexpr (SWAP) {   // read back as float4 per register quad in the epilogue (same wave: in order)
+        epi_s[lane] = e_sc;
+        epi_s[64 + lane] = e_bias;
+      }
     }
-    // the slots refilled this round hold the steps RING ahead
-    int nstrip_ = strip, nks0 = ks0 + GR_RING;
-    if (nks0 == KS) {
-      nks0 = 0;
-      ++nstrip_;
-    }
-    if (nstrip_ == nstrip) {   // tail: re-read the last round (never used)
-      nstrip_ = strip;
-      nks0 = ks0;
-    }
+    // steps past this strip's end are the first steps of the next one (the last
+    // strip re-reads its own: harmless, never used)
+    const char* wnext = strip + 1 < nstrip ? wstrip + strip_stride : wstrip;
 #pragma unroll
-    for (int d = 0; d < GR_RING; ++d) {
-      // A fragments of the NEXT step are read from LDS before this step's MFMAs
-      // are issued (the panel is the same for every strip: k wraps around)
-      const int ksn = (ks0 + d + 1 == KS) ? 0 : ks0 + d + 1;
+    for (int ks = 0; ks < KS; ++ks) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int d = ks % GR_RING;
+      const int ksn = ks + 1 == KS ? 0 : ks + 1;   // next step's A fragments (k wraps: same panel)
       f16x8 af[2][2], bf[2][2];
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
@@ -1062,10 +1063,17 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) bf[cb][pl] = __builtin_bit_cast(f16x8, ring[d][cb][pl]);
       // refill this ring slot with the step RING ahead
+      {
+        const int kr = ks + GR_RING;
+        const char* src = kr < KS ? wstrip : wnext;
+        const int kk = kr < KS ? kr : kr - KS;
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) ring[d][cb][pl] = *wfrag_ptr(nstrip_, nks0 + d, cb, pl);
+          for (int pl = 0; pl < 2; ++pl)
+            ring[d][cb][pl] = *reinterpret_cast<const uint4*>(
+                src + ((size_t)cb * cb_stride + (size_t)(kk * 2 + pl) * 1024) + wf_lane);
+      }
 #define S4G_R_TERM(PA, PB)                                                                              \
   if constexpr (SWAP) {                                                                                 \
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0][PB], af[0][PA], acc[0][0], 0, 0, 0);       \
@@ -1082,17 +1090,19 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
       S4G_R_TERM(1, 0)
       S4G_R_TERM(0, 0)
 #undef S4G_R_TERM
+      // keep the scheduler from hoisting later steps' loads across this one (it would
+      // spill the ring); inside a step, spread the 4 reads + 4 loads over the MFMAs
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // KS % RING == 0: a strip can only end at the end of a ring round
-    const int strip_done = strip;
-    const bool done = ks0 + GR_RING == KS;
-    ks0 += GR_RING;
-    if (done) {
-      ks0 = 0;
-      ++strip;
-    }
-    if (!done) continue;
-      const int n0 = (strip_done * CW + wc) * 64;
+    const int n0 = (strip_done * CW + wc) * 64;
     float tmax = 0.f;
     if constexpr (SWAP) {
       // lane: position li of position block pb; registers 4 j .. 4 j + 3 = channels
@@ -1102,23 +1112,18 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int n = n0 + nb * 32 + 8 * j + 4 * lh;
-          float scv[4], bv[4];   // channel n + e lives in lane nb*32 + 8j + 4lh + e of e_sc / e_bias
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int c0 = nb * 32 + 8 * j + e;
-            const float s0v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e_sc), c0));
-            const float s1v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e_sc), c0 + 4));
-            const float b0v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e_bias), c0));
-            const float b1v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e_bias), c0 + 4));
-            scv[e] = lh ? s1v : s0v;
-            bv[e] = lh ? b1v : b0v;
-          }
+          // scale / bias of channels n .. n+3: staged per wave in LDS at strip start
+          const float4 sc4 = *reinterpret_cast<const float4*>(epi_s + nb * 32 + 8 * j + 4 * lh);
+          const float4 b4 = *reinterpret_cast<const float4*>(epi_s + 64 + nb * 32 + 8 * j + 4 * lh);
+          const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+          const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
           for (int pb = 0; pb < 2; ++pb) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              float x = acc[nb][pb][4 * j + e] * scv[e] + bv[e];
+              // the scale is a power of two, so the fused form rounds exactly like mul-then-add
+              float x = __fmaf_rn(acc[nb][pb][4 * j + e], scv[e], bv[e]);
               if (p.relu) x = fmaxf(x, 0.f);
               v[e] = x;
               tmax = fmaxf(tmax, fabsf(x));
@@ -1165,7 +1170,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
 template <int LOADER, int EPI, int RW, int KT>
 static int launch_gemm_f16x2_resident(const GemmParams& p, int groups, hipStream_t st) {
   constexpr int BM = 64 * RW;
-  constexpr size_t lds = sizeof(uint16_t) * 2 * BM * (size_t)(KT + 8);
+  constexpr size_t lds = sizeof(uint16_t) * 2 * BM * (size_t)(KT + 8) + sizeof(float) * 4 * 128;
   static_assert(lds <= 80 * 1024, "two workgroups per CU");
   static const hipError_t attr = hipFuncSetAttribute(
       reinterpret_cast<const void*>(&mlp_gemm_f16x2_resident_kernel<LOADER, EPI, RW, KT>),
@@ -1198,10 +1203,6 @@ static int launch_gemm_f16x2(const GemmParams& p, int groups, hipStream_t st) {
         return launch_gemm_f16x2_resident<LOADER, EPI, 1, 128>(p, groups, st);
       if (p.Kpad16 == 128 && p.Cout % 128 == 0)
         return launch_gemm_f16x2_resident<LOADER, EPI, 2, 128>(p, groups, st);
-      if (p.Kpad16 == 64 && p.Cout % 256 == 0)
-        return launch_gemm_f16x2_resident<LOADER, EPI, 1, 64>(p, groups, st);
-      if (p.Kpad16 == 64 && p.Cout % 128 == 0)
-        return launch_gemm_f16x2_resident<LOADER, EPI, 2, 64>(p, groups, st);
     }
   }
   // the INTERP / GATHER loaders hold too much per-row state for the wide tile's
