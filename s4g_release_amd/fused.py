@@ -290,7 +290,7 @@ class FusedPointNet2:
         """Everything that depends on coordinates only: the FPS pyramid, the ball
         queries and the 3-NN searches + weights of all levels."""
         B, _, N0 = xyz.shape
-        geo = dict(level_xyz=[xyz], level_n=[N0], sa=[], fp=[])
+        geo = dict(level_xyz=[xyz], level_n=[N0], sa=[], fp=[], sa_events=[])
         n_cur = N0
         for sa in self.sa:
             M, K = sa["M"], sa["K"]
@@ -299,6 +299,9 @@ class FusedPointNet2:
             idx, ctr = self._fps_gather(geo["level_xyz"][-1], M)
             gidx, gcnt = self._ball_query(geo["level_xyz"][-1], ctr, sa["radius"], K)
             geo["sa"].append((idx, ctr, gidx, gcnt))
+            # the contractions of this SA level only need its own sampling + grouping:
+            # they may start while the deeper levels' FPS / 3-NN are still running
+            geo["sa_events"].append(torch.cuda.current_stream().record_event())
             geo["level_xyz"].append(ctr)
             geo["level_n"].append(M)
             n_cur = M
@@ -326,9 +329,11 @@ class FusedPointNet2:
         rows = iter(amax.unbind(0))
         level_feat = [(None, None)]                  # (tensor, amax row)
         feat = feat_amax = None
+        cur = torch.cuda.current_stream()
         for li, sa in enumerate(self.sa):
             M, K = sa["M"], sa["K"]
             _, ctr, gidx, _ = geo["sa"][li]
+            cur.wait_event(geo["sa_events"][li])
             P = B * M * K
             layers = sa["layers"]
             x = x_amax = None
@@ -357,6 +362,7 @@ class FusedPointNet2:
             feat, feat_amax = x, x_amax
             level_feat.append((feat, feat_amax))
 
+        cur.wait_event(geo["done"])               # the 3-NN searches of the FP path
         (sparse_feat, sparse_amax), n_sparse = level_feat[-1], level_n[-1]
         for fi, fp in enumerate(self.fp):
             (dense_feat, dense_amax), n_dense = level_feat[-2 - fi], level_n[-2 - fi]
@@ -442,8 +448,8 @@ class FusedPointNet2:
             gs.wait_event(ev_in)
             with torch.cuda.stream(gs):
                 geo = self._geometry(xyz)
-                ev_geo = gs.record_event()
-            ds.wait_event(ev_geo)
+                geo["done"] = gs.record_event()
+            ds.wait_event(ev_in)
             with torch.cuda.stream(ds):
                 pred = self._dense(xyz, geo)
                 ev_out = ds.record_event()
