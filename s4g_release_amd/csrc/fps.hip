@@ -32,6 +32,8 @@ constexpr int FPS_THREADS = 1024;  // streaming fallback
 constexpr int FPS_MAX_WAVES = 16;
 constexpr uint32_t FPS_JMASK = 0x7FFFFFu;  // 23 bits of point index
 
+typedef float fps_v2f __attribute__((ext_vector_type(2)));
+
 struct FpsSlot {
   uint32_t d;
   uint32_t tie;
@@ -147,10 +149,34 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(
   for (int i = 1; i < M; ++i) {
     float best = 0.0f;
     int bestp = -1;
+    // two points per instruction where the ISA has packed fp32 forms (v_pk_add / v_pk_mul /
+    // v_pk_fma: IEEE per element, no contraction): 8 instead of 10 instructions per point
+    const fps_v2f cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
 #pragma unroll
-    for (int p = 0; p < PPT; ++p) {
+    for (int p = 0; p + 1 < PPT; p += 2) {
+      const fps_v2f xv = {x[p], x[p + 1]}, yv = {y[p], y[p + 1]}, zv = {z[p], z[p + 1]};
+      const fps_v2f dx = xv - cx2, dy = yv - cy2, dz = zv - cz2;
+      fps_v2f d;
+      if constexpr (FMAD) {
+        d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+      } else {
+        d = (dx * dx + dy * dy) + dz * dz;
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float m;  // one v_min_f32 (== (d < md) ? d : md for the non-NaN contract; fminf adds a canonicalising v_max)
+        asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(d[e]), "v"(md[p + e]));
+        md[p + e] = m;
+        if (m > best) {
+          best = m;
+          bestp = p + e;
+        }
+      }
+    }
+    if constexpr (PPT & 1) {
+      constexpr int p = PPT - 1;
       const float d = dist2<FMAD>(cx, cy, cz, x[p], y[p], z[p]);
-      float m;  // one v_min_f32 (== (d < md) ? d : md for the non-NaN contract; fminf adds a canonicalising v_max)
+      float m;
       asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(d), "v"(md[p]));
       md[p] = m;
       if (m > best) {
