@@ -215,6 +215,134 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(
   }
 }
 
+// Hybrid variant for 25 600 < N <= 51 200: x and the running min-distance of a
+// lane's 100 points stay in VGPRs (200 registers), y and z are re-read from L2 every
+// step (410 KB per step and scene, coalesced dword loads, batches of FB slots in
+// flight).  A step then moves 410 KB instead of the streaming kernel's 1 MB through the
+// CU's L2 port: 6.5 us per step (63 GB/s, the per-CU L2 read rate this access pattern
+// reaches; 8-byte (y, z) pair loads and 16 waves measured the same) against 16.6 us.  Same ownership
+// (j = t + 512 p), tie rule and exchange as fps_reg_kernel; the winner's coordinates
+// are re-read by index (three L2 hits) instead of through a 100-leaf register tree.
+template <int THREADS, int PPT, int FB, bool FMAD, typename IdxT>
+__global__ __launch_bounds__(THREADS) void fps_hybrid_kernel(const float* __restrict__ xyz, int N, int M,
+                                                             IdxT* __restrict__ idx,
+                                                             float* __restrict__ ctr, int lg_bs) {
+  constexpr int WAVES = THREADS / 64;
+  static_assert(PPT % FB == 0 && FB % 2 == 0, "batches of point pairs");
+  __shared__ FpsSlot slots[2][FPS_MAX_WAVES];
+  const int b = blockIdx.x;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const float* __restrict__ px = xyz + (size_t)b * 3 * N;
+  const float* __restrict__ py = px + N;
+  const float* __restrict__ pz = py + N;
+  IdxT* __restrict__ out = idx + (size_t)b * M;
+  float* __restrict__ cout = ctr ? ctr + (size_t)b * 3 * M : nullptr;
+
+  float x[PPT], md[PPT];
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    const int j = t + THREADS * p;
+    const bool ok = j < N;
+    x[p] = px[ok ? j : 0];
+    md[p] = ok ? __builtin_inff() : -1.0f;   // padding never beats best = 0
+  }
+  const uint32_t bs_mask = (1u << lg_bs) - 1u;
+  const uint32_t rkey = (__brev((uint32_t)t & bs_mask) >> (32 - lg_bs)) << 23;
+  const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)py, 0, N * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t z_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pz, 0, N * 4, 0x00020000);
+  const int voff = t * 4;
+
+  int cur = 0;
+  float cx = px[0], cy = py[0], cz = pz[0];
+  if (t == 0) {
+    out[0] = 0;
+    if (cout) {
+      cout[0] = cx;
+      cout[M] = cy;
+      cout[2 * M] = cz;
+    }
+  }
+
+  for (int i = 1; i < M; ++i) {
+    float best = 0.0f;
+    int bestp = -1;
+    const fps_v2f cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
+    // batches of FB slots, the next batch's loads in flight while this one is scanned
+    // (scheduling barriers keep the compiler from hoisting all 200 loads: spills)
+    float yb[2][FB], zb[2][FB];
+    // buffer loads: one VGPR lane offset (4 t), the slot offset is a scalar constant and the
+    // hardware range check returns 0 for padding slots -- no per-load address registers
+    auto fetch = [&](int p0, float (&yy)[FB], float (&zz)[FB]) {
+#pragma unroll
+      for (int e = 0; e < FB; ++e) {
+        const int soff = THREADS * 4 * (p0 + e);
+        yy[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(y_rsrc, voff, soff, 0));
+        zz[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(z_rsrc, voff, soff, 0));
+      }
+    };
+    fetch(0, yb[0], zb[0]);
+#pragma unroll
+    for (int p0 = 0; p0 < PPT; p0 += FB) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int cb = (p0 / FB) & 1;
+      if (p0 + FB < PPT) fetch(p0 + FB, yb[cb ^ 1], zb[cb ^ 1]);
+#pragma unroll
+      for (int e = 0; e < FB; e += 2) {
+        const int p = p0 + e;
+        const fps_v2f xv = {x[p], x[p + 1]}, yv = {yb[cb][e], yb[cb][e + 1]}, zv = {zb[cb][e], zb[cb][e + 1]};
+        const fps_v2f dx = xv - cx2, dy = yv - cy2, dz = zv - cz2;
+        fps_v2f d;
+        if constexpr (FMAD) {
+          d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+        } else {
+          d = (dx * dx + dy * dy) + dz * dz;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float m;
+          asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(d[q]), "v"(md[p + q]));
+          md[p + q] = m;
+          if (m > best) {
+            best = m;
+            bestp = p + q;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const uint32_t jbest = (bestp < 0) ? (uint32_t)cur : (uint32_t)(t + THREADS * bestp);
+    // this lane's candidate coordinates (L2 hits: the whole cloud was just read)
+    const float bx = px[jbest], by = py[jbest], bz = pz[jbest];
+    const uint32_t tie = rkey | jbest;
+    const uint32_t dbits = __float_as_uint(best);
+    const uint32_t wmax = wave_max_u32(dbits);
+    uint64_t win = __ballot(dbits == wmax);
+    uint32_t wtie;
+    if (__popcll(win) > 1) {
+      wtie = wave_min_u32((dbits == wmax) ? tie : 0xFFFFFFFFu);
+      win = __ballot(dbits == wmax && tie == wtie);
+    } else {
+      wtie = __builtin_amdgcn_readlane(tie, __ffsll((unsigned long long)win) - 1);
+    }
+    const int wl = __ffsll((unsigned long long)win) - 1;
+    const float sx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bx), wl));
+    const float sy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(by), wl));
+    const float sz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bz), wl));
+    fps_block_exchange<WAVES>(slots[i & 1], wave, lane, wmax, wtie, sx, sy, sz, cur, cx, cy, cz);
+    if (t == 0) {
+      out[i] = (IdxT)cur;
+      if (cout) {
+        cout[i] = cx;
+        cout[M + i] = cy;
+        cout[2 * M + i] = cz;
+      }
+    }
+  }
+}
+
 // Streaming fallback: any N < 2^23.  min-distance in `temp` (B,N) fp32.
 template <bool FMAD, typename IdxT>
 __global__ __launch_bounds__(FPS_THREADS) void fps_stream_kernel(
@@ -757,6 +885,12 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
   S4G_FPS_CASE(512, 20)
   S4G_FPS_CASE(512, 32)
   S4G_FPS_CASE(512, 50)
+  if (N <= (int64_t)512 * 100) {   // x + min-distance in registers, y / z streamed from L2
+    hipLaunchKernelGGL((fps_hybrid_kernel<512, 100, 10, FMAD, IdxT>), grid, dim3(512), 0, stream, xyz,
+                       (int)N, (int)M, idx, ctr, lg);
+    S4G_LAUNCH_CHECK();
+    return S4G_OK;
+  }
 #undef S4G_FPS_CASE
   if (ws_bytes < (size_t)B * (size_t)N * sizeof(float) || ws == nullptr)
     return S4G_EWORKSPACE;
@@ -769,6 +903,7 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
 size_t fps_workspace_bytes(int64_t B, int64_t N) {
   if (N <= 0 || B <= 0) return 0;
   if (N <= (int64_t)512 * 50) return fps_use_pruned(N) ? fps_sort_ws(nullptr, B, N).total : 0;
+  if (N <= (int64_t)512 * 100) return 0;   // hybrid kernel
   return (size_t)B * (size_t)N * sizeof(float);
 }
 

@@ -57,10 +57,21 @@ def test_fps_pruned_variant_is_exact(F, oracle, dev, monkeypatch, N, M, variant)
     assert np.array_equal(got, oracle.fps(pts, M))
 
 
-def test_fps_streaming_fallback_large_cloud(F, oracle, dev):
+def test_fps_hybrid_kernel_large_cloud(F, oracle, dev):
+    """25 600 < N <= 51 200: x + min-distance in registers, y / z re-read from L2."""
     pts = synth.make_batch([2], 51200)
     got = F.farthest_point_sample(_t(pts, dev), 300).cpu().numpy()
     assert np.array_equal(got, oracle.fps(pts, 300))
+    for n, variant in ((30000, "dup-heavy"), (48902, "tabletop-v1"), (25601, "uniform-box")):
+        pts = synth.make_batch([6], n, variant=variant)
+        got = F.farthest_point_sample(_t(pts, dev), 200).cpu().numpy()
+        assert np.array_equal(got, oracle.fps(pts, 200)), (n, variant)
+
+
+def test_fps_streaming_fallback_very_large_cloud(F, oracle, dev):
+    pts = synth.make_batch([2], 60000)
+    got = F.farthest_point_sample(_t(pts, dev), 100).cpu().numpy()
+    assert np.array_equal(got, oracle.fps(pts, 100))
 
 
 def test_fps_fmad_mode(F, oracle, dev):

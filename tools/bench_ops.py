@@ -43,6 +43,10 @@ def main():
                            ("fps 1024->256", c2, 256)):
             ms = timeit(lambda: F.farthest_point_sample(x, m), reps=3, warm=1)
             print("%-28s B=%d  %9.3f ms   %.3f us/step" % (name, B, ms, 1e3 * ms / (m - 1)))
+    if "fps51k" in ops:   # configs[4] cloud size: the hybrid kernel (x + min-distance in registers)
+        big = torch.from_numpy(synth.make_batch(list(range(B)), 51200, variant=a.variant)).to(dev)
+        ms = timeit(lambda: F.farthest_point_sample(big, 5120), reps=2, warm=1)
+        print("%-28s B=%d  %9.3f ms   %.3f us/step" % ("fps 51200->5120", B, ms, 1e3 * ms / 5119))
     if "ball" in ops:
         for name, x, c, r in (("ball 25600/5120 r.02", pts, c1, 0.02), ("ball 5120/1024 r.08", c1, c2, 0.08)):
             ms = timeit(lambda: F.ball_query(x, c, r, 64))
