@@ -351,6 +351,55 @@ extern "C" int s4g_three_nn_weights_grid_i32(const float* q_b3n1, const float* k
   return S4G_OK;
 }
 
+// Operator-API form of the grid search: int64 indices + squared distances, i.e. the
+// outputs of s4g_three_nn_f32, for callers that can name a cell edge (the host wrapper
+// derives one from the keys' extent).  Identical results for ANY cell: queries whose
+// third neighbour is not proven inside the 27 cells are answered by the index-order
+// scan kernel.
+extern "C" int s4g_three_nn_grid_f32(const float* q_b3n1, const float* k_b3n2, int64_t B,
+                                     int64_t N1, int64_t N2, float cell, int64_t* idx_bn3,
+                                     float* d2_bn3, void* ws, size_t ws_bytes, int flags,
+                                     s4g_stream_t stream) {
+  using namespace s4g;
+  if (B < 0 || N1 < 0 || N2 < 3 || B > 65535 || N2 > GR_MAX_POINTS || N1 >= (1ll << 31) ||
+      !(cell > 0.f) || !(cell < 1e18f))
+    return S4G_EINVAL;
+  if (B == 0 || N1 == 0) return S4G_OK;
+  if (!q_b3n1 || !k_b3n2 || !idx_bn3 || !d2_bn3 || !ws) return S4G_EINVAL;
+  if (ws_bytes < s4g_three_nn_grid_workspace_bytes(B, N1, N2)) return S4G_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const GridWs g = grid_ws_carve(ws, B, N2);
+  int* fail_count = reinterpret_cast<int*>((char*)ws + grid_ws_bytes(B, N2));
+  int* fail_list = fail_count + 16;
+  hipError_t e = hipMemsetAsync(fail_count, 0, sizeof(int), st);
+  if (e != hipSuccess) return (int)e;
+  const float inv_h = 1.0f / cell;
+  if (int rc = launch_grid_build(k_b3n2, B, N2, inv_h, g, st)) return rc;
+  const float edge = cell * (1.0f - 1e-3f);
+  const float d2_done = edge * edge;
+  const dim3 grid((unsigned)((N1 + NN_THREADS - 1) / NN_THREADS), (unsigned)B);
+  const bool fmad = (flags & S4G_FLAG_FMAD) != 0;
+  if (fmad)
+    hipLaunchKernelGGL((three_nn_grid_kernel<true, false, int64_t>), grid, dim3(NN_THREADS), 0, st,
+                       q_b3n1, k_b3n2, (int)N1, (int)N2, inv_h, d2_done, g, 0.f, idx_bn3, d2_bn3,
+                       fail_list, fail_count);
+  else
+    hipLaunchKernelGGL((three_nn_grid_kernel<false, false, int64_t>), grid, dim3(NN_THREADS), 0, st,
+                       q_b3n1, k_b3n2, (int)N1, (int)N2, inv_h, d2_done, g, 0.f, idx_bn3, d2_bn3,
+                       fail_list, fail_count);
+  S4G_LAUNCH_CHECK();
+  if (fmad)
+    hipLaunchKernelGGL((three_nn_fallback_kernel<true, false, int64_t>), dim3(512), dim3(NN_THREADS),
+                       0, st, q_b3n1, k_b3n2, (int)N1, (int)N2, 0.f, idx_bn3, d2_bn3, fail_list,
+                       fail_count);
+  else
+    hipLaunchKernelGGL((three_nn_fallback_kernel<false, false, int64_t>), dim3(512),
+                       dim3(NN_THREADS), 0, st, q_b3n1, k_b3n2, (int)N1, (int)N2, 0.f, idx_bn3,
+                       d2_bn3, fail_list, fail_count);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
+
 extern "C" int s4g_interp_weights_f32(const float* d2_bn3, int64_t B,
                                       int64_t N1, float eps, float* w_bn3,
                                       s4g_stream_t stream) {

@@ -222,6 +222,24 @@ def test_three_nn_matches_oracle(F, oracle, dev, N1, N2):
     assert torch.equal(i2, idx) and torch.equal(dd, d2)
 
 
+@pytest.mark.parametrize("variant,N1,N2", [("dup-heavy", 9000, 4096), ("uniform-box", 12000, 2048),
+                                           ("tabletop-v1", 3000, 2500)])
+def test_three_nn_operator_api_grid_routing(F, oracle, dev, monkeypatch, variant, N1, N2):
+    """search_nn_distance routes N2 >= 2048 through the cell grid with a cell derived from
+    the keys' extent: indices AND squared distances must equal the scan's, bit for bit, on
+    tie-heavy, volume-filling and surface-like clouds; queries far from every key included."""
+    pts = synth.make_batch([4, 9], N1, variant=variant)
+    keys = oracle.gather_points(pts, oracle.fps(pts, N2))
+    q = pts.copy()
+    q[:, :, :7] += np.float32(5.0)                       # isolated queries: fallback scan
+    idx, d2 = F.search_nn_distance(_t(q, dev), _t(keys, dev), 3)
+    ridx, rd2 = oracle.three_nn(q, keys)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d2.cpu().numpy(), rd2)
+    monkeypatch.setenv("S4G_NN_MODE", "scan")
+    idx_s, d2_s = F.search_nn_distance(_t(q, dev), _t(keys, dev), 3)
+    assert torch.equal(idx_s, idx) and torch.equal(d2_s, d2)
+
+
 @pytest.mark.parametrize("variant,N1,N2,cell", [
     ("tabletop-v1", 25600, 5120, 0.02),     # FP3 of the shipped config
     ("tabletop-v1", 5120, 2048, 0.08),
