@@ -86,6 +86,13 @@ int s4g_group_points_f32(const float *in_bcn, const int64_t *idx_bmk, int64_t B,
 /* GroupPointsBackward(grad_output (B,C,M,K), index, N) -> grad_input (B,C,N)
  * replaces csrc/grouping.h:11-14, csrc/grouping_kernel.cu:106-152.
  * grad_in is zeroed by the call, then scatter-added (fp32 atomics). */
+/* group_points for C == 3 (the xyz grouping of QueryGrouper, modules.py:42) through an
+ * index-ordered (x, y, z, 0) copy in `ws` (B * N * 16 bytes): one 16-byte gather per
+ * neighbour.  Same output as s4g_group_points_f32(C = 3); without a (large enough,
+ * 16-byte aligned) workspace or with M*K % 4 != 0 it IS that call. */
+int s4g_group_points_xyz_f32(const float *xyz_b3n, const int64_t *idx_bmk, int64_t B, int64_t N,
+                             int64_t M, int64_t K, float *out_b3mk, void *ws, size_t ws_bytes,
+                             s4g_stream_t stream);
 int s4g_group_points_backward_f32(const float *gout_bcmk,
                                   const int64_t *idx_bmk, int64_t B, int64_t C,
                                   int64_t N, int64_t M, int64_t K,

@@ -204,10 +204,19 @@ def _group_points_forward(points, index):
     _, M, K = index.shape
     out = torch.empty((B, C, M, K), dtype=torch.float32, device=points.device)
     with torch.cuda.device(points.device):
-        with _timed("group_points[C=%d,N=%d,M=%d,K=%d]" % (C, N, M, K),
-                    B * (4 * C * N + 8 * M * K + 4 * C * M * K)):
-            rc = _cabi.lib().s4g_group_points_f32(_ptr(points), _ptr(index), B, C, N, M, K,
-                                                  _ptr(out), _stream())
+        if C == 3 and B > 0 and (M * K) % 4 == 0 and M * K >= 4096:
+            # xyz grouping: one 16-byte gather per neighbour out of an (x, y, z, 0) copy
+            aos = torch.empty((B * N, 4), dtype=torch.float32, device=points.device)
+            with _timed("group_points[C=%d,N=%d,M=%d,K=%d]" % (C, N, M, K),
+                        B * (4 * C * N + 8 * M * K + 4 * C * M * K)):
+                rc = _cabi.lib().s4g_group_points_xyz_f32(_ptr(points), _ptr(index), B, N, M, K,
+                                                          _ptr(out), aos.data_ptr(), aos.numel() * 4,
+                                                          _stream())
+        else:
+            with _timed("group_points[C=%d,N=%d,M=%d,K=%d]" % (C, N, M, K),
+                        B * (4 * C * N + 8 * M * K + 4 * C * M * K)):
+                rc = _cabi.lib().s4g_group_points_f32(_ptr(points), _ptr(index), B, C, N, M, K,
+                                                      _ptr(out), _stream())
     _cabi.check(rc, "group_points_forward")
     return out
 
