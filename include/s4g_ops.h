@@ -122,6 +122,12 @@ int s4g_three_interpolate_f32(const float *feat_bcn2, const int64_t *idx_bn3,
 
 /* InterpolateBackward(grad_output (B,C,N1), index, weight, N2) -> (B,C,N2)
  * replaces csrc/interpolate.h:18-22, csrc/interpolate_kernel.cu:296-341. */
+/* s4g_three_interpolate_f32 through a channels-last copy of the sparse features in `ws`
+ * (B * N2 * C floats): a quad of channels is one 16-byte gather.  Bit-identical output;
+ * without a (large enough, 16-byte aligned) workspace or with C % 4 != 0 it IS that call. */
+int s4g_three_interpolate_ws_f32(const float *feat_bcn2, const int64_t *idx_bn3, const float *w_bn3,
+                                 int64_t B, int64_t C, int64_t N2, int64_t N1, float *out_bcn1,
+                                 void *ws, size_t ws_bytes, int flags, s4g_stream_t stream);
 int s4g_three_interpolate_backward_f32(const float *gout_bcn1,
                                        const int64_t *idx_bn3,
                                        const float *w_bn3, int64_t B, int64_t C,

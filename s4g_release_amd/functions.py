@@ -305,11 +305,20 @@ def _interpolate_forward(feature, index, weight):
         raise RuntimeError("weight must be (batch_size, N, 3)")  # :204-206
     out = torch.empty((B, C, N1), dtype=torch.float32, device=feature.device)
     with torch.cuda.device(feature.device):
-        with _timed("three_interpolate[C=%d,N2=%d,N1=%d]" % (C, N2, N1),
-                    B * (4 * C * N2 + 24 * N1 + 12 * N1 + 4 * C * N1)):
-            rc = _cabi.lib().s4g_three_interpolate_f32(_ptr(feature), _ptr(index), _ptr(weight), B,
-                                                       C, N2, N1, _ptr(out), _DIST_FLAGS,
-                                                       _stream())
+        if C % 4 == 0 and C >= 16 and B * N1 > 0 and N1 >= N2:
+            # channels-last copy of the sparse features: one 16-byte gather per channel quad
+            ws = torch.empty((B * N2, C), dtype=torch.float32, device=feature.device)
+            with _timed("three_interpolate[C=%d,N2=%d,N1=%d]" % (C, N2, N1),
+                        B * (4 * C * N2 + 24 * N1 + 12 * N1 + 4 * C * N1)):
+                rc = _cabi.lib().s4g_three_interpolate_ws_f32(_ptr(feature), _ptr(index), _ptr(weight),
+                                                              B, C, N2, N1, _ptr(out), ws.data_ptr(),
+                                                              ws.numel() * 4, _DIST_FLAGS, _stream())
+        else:
+            with _timed("three_interpolate[C=%d,N2=%d,N1=%d]" % (C, N2, N1),
+                        B * (4 * C * N2 + 24 * N1 + 12 * N1 + 4 * C * N1)):
+                rc = _cabi.lib().s4g_three_interpolate_f32(_ptr(feature), _ptr(index), _ptr(weight), B,
+                                                           C, N2, N1, _ptr(out), _DIST_FLAGS,
+                                                           _stream())
     _cabi.check(rc, "interpolate_forward")
     return out
 
