@@ -432,3 +432,31 @@ def test_fused_equals_modules_path_batch(dev):
     b = FusedPointNet2(net)({"scene_points": pts})
     for k in a:
         assert (a[k] - b[k]).abs().max().item() < TOL, k
+
+
+@pytest.mark.parametrize("streams", [("1", "1"), ("3", "2")])
+def test_pipelined_submissions_match_sequential(dev, monkeypatch, streams):
+    """`submit` keeps several batches in flight on separate geometry / dense streams:
+    every handle must return exactly what a lone forward of its batch returns."""
+    from s4g_release_amd import synth
+    from s4g_release_amd.fused import FusedPointNet2
+    from s4g_release_amd.model import PointNet2, randomize_bn_
+    monkeypatch.setenv("S4G_GEO_STREAMS", streams[0])
+    monkeypatch.setenv("S4G_DENSE_STREAMS", streams[1])
+    cfg = dict(score_classes=3, num_centroids=(600, 150, 40), radius=(0.04, 0.1, 0.3),
+               num_neighbours=(64, 32, 16), sa_channels=((32, 32, 64), (64, 64, 128), (128, 128, 256)),
+               fp_channels=((256, 256), (128, 128), (64, 64, 64)), num_fp_neighbours=(3, 3, 3),
+               seg_channels=(128, 64, 64, 32), num_removal_directions=5, dropout_prob=0.5)
+    torch.manual_seed(5)
+    net = randomize_bn_(PointNet2(**cfg), 6).to(dev).eval()
+    fast = FusedPointNet2(net)
+    batches = [torch.from_numpy(synth.make_batch([10 * i, 10 * i + 1], 3000)).to(dev) for i in range(5)]
+    with torch.no_grad():
+        ref = [{k: v.clone() for k, v in fast({"scene_points": b}).items()} for b in batches]
+        torch.cuda.synchronize()
+        handles = [fast.submit({"scene_points": b}) for b in batches]      # all in flight
+        outs = [h.result() for h in handles]
+        torch.cuda.synchronize()
+    for r, o in zip(ref, outs):
+        for k in r:
+            assert torch.equal(r[k], o[k]), k
