@@ -168,7 +168,7 @@ int s4g_interp_weights_f32(const float *d2_bn3, int64_t B, int64_t N1,
  *                               ranges cf_start[h]..cf_start[h+1], sigmoid on
  *                               channels >= cf_sigmoid_from
  * W is [groups][Cout][Kpad] with Kpad % 8 == 0 (zero padded), bias
- * [groups][Cout].  Cf, C2 must be multiples of 32; lda, a_coff, C1 of 4.
+ * [groups][Cout].  Cf, C2, lda, a_coff, C1 must be multiples of 4.
  * ------------------------------------------------------------------------- */
 #define S4G_GEMM_LOAD_PLAIN 0
 #define S4G_GEMM_LOAD_GATHER 1

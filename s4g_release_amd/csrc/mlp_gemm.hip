@@ -137,7 +137,7 @@ struct ALoader {
         const int m = (pp - b * MK) / p.K;
         const int j = p.gidx[pp];
         src0[s] = p.feat ? p.feat + ((size_t)b * p.N + j) * p.Cf : nullptr;
-        if ((t & 7) == 0) {
+        if ((t & 7) == ((p.Cf & 31) >> 2)) {   // the lane whose 4-float chunk holds the xyz columns
           const float* x = p.xyz + (size_t)b * 3 * p.N;
           const float* c = p.ctr + (size_t)b * 3 * p.M;
           // group_xyz -= new_xyz (modules.py:44): one rounded subtraction
@@ -1302,7 +1302,7 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   if (d->loader == S4G_GEMM_LOAD_PLAIN) {
     if (!d->A || (d->lda & 3) || (d->a_coff & 3) || (d->a_gcol & 3) || (d->Cin & 3)) return S4G_EINVAL;
   } else if (d->loader == S4G_GEMM_LOAD_GATHER) {
-    if (!d->gidx || !d->xyz || !d->ctr || (d->Cf & 31) || (d->Cf > 0 && !d->feat) ||
+    if (!d->gidx || !d->xyz || !d->ctr || (d->Cf & 3) || (d->Cf > 0 && !d->feat) ||
         d->K <= 0 || d->M <= 0 || d->N <= 0 || d->groups != 1)
       return S4G_EINVAL;
   } else if (d->loader == S4G_GEMM_LOAD_GATHER_MLP1) {
@@ -1310,7 +1310,7 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
         d->N <= 0 || d->groups != 1 || ((uintptr_t)d->mlp1_w & 15))
       return S4G_EINVAL;
   } else if (d->loader == S4G_GEMM_LOAD_INTERP) {
-    if (!d->nidx || !d->nw || !d->sparse || (d->C2 & 31) || (d->C1 & 3) ||
+    if (!d->nidx || !d->nw || !d->sparse || (d->C2 & 3) || (d->C1 & 3) ||
         (d->C1 > 0 && !d->dense) || d->N1 <= 0 || d->N2 <= 0 || d->groups != 1)
       return S4G_EINVAL;
   } else {

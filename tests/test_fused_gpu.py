@@ -136,7 +136,7 @@ def test_gemm_grouped_column_slices(dev, prec, Cin, Cout, gemm_variant):
 
 
 @pytest.mark.parametrize("K", [16, 32, 64])
-@pytest.mark.parametrize("Cf", [0, 64])
+@pytest.mark.parametrize("Cf", [0, 24, 64, 88])
 @pytest.mark.parametrize("prec", PRECISIONS)
 def test_gemm_gather_max(dev, K, Cf, prec):
     g = torch.Generator(device="cpu").manual_seed(K + Cf)
@@ -232,7 +232,7 @@ def test_gemm_gather_mlp1(dev, C1, Cout, epi, prec, gemm_variant):
 @pytest.mark.parametrize("prec", PRECISIONS)
 def test_gemm_interp_store(dev, prec):
     g = torch.Generator(device="cpu").manual_seed(5)
-    B, N1, N2, C2, C1, Cout = 2, 333, 50, 64, 32, 72
+    B, N1, N2, C2, C1, Cout = 2, 333, 50, 68, 32, 72
     sparse = torch.randn(B * N2, C2, generator=g).to(dev)
     dense = torch.randn(B * N1, C1, generator=g).to(dev)
     nidx = torch.randint(0, N2, (B, N1, 3), generator=g).int().to(dev)
@@ -244,8 +244,9 @@ def test_gemm_interp_store(dev, prec):
         Wc = W[:, :C2 + c1].contiguous()
         out = torch.full((P, Cout), float("nan"), device=dev)
         k16, w3 = _w3(Wc)
-        _run(dict(loader=2, epilogue=0, groups=1, relu=1, P=P, Cin=C2 + c1, Kpad=C2 + c1, Cout=Cout,
-                  W=Wc, bias=b, nidx=nidx, nw=nw, sparse=sparse, dense=dn, C2=C2, C1=c1, N2=N2,
+        Wp = _padk(Wc)
+        _run(dict(loader=2, epilogue=0, groups=1, relu=1, P=P, Cin=C2 + c1, Kpad=Wp.shape[1], Cout=Cout,
+                  W=Wp, bias=b, nidx=nidx, nw=nw, sparse=sparse, dense=dn, C2=C2, C1=c1, N2=N2,
                   N1=N1, out=out, ldc=Cout, precision=prec, Kpad16=k16, W_bf16x3=w3,
                   **_h2(Wc, sparse, dn)), dev)
         sp = sparse.view(B, N2, C2)
@@ -460,3 +461,36 @@ def test_pipelined_submissions_match_sequential(dev, monkeypatch, streams):
     for r, o in zip(ref, outs):
         for k in r:
             assert torch.equal(r[k], o[k]), k
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fused_equals_modules_random_configs(dev, seed):
+    """Random small architectures / cloud sizes (odd point counts, 16/32/64 neighbours,
+    channel counts that miss every tile size): fast path == reference-shaped modules path."""
+    from s4g_release_amd import synth
+    from s4g_release_amd.fused import FusedPointNet2
+    from s4g_release_amd.model import PointNet2, randomize_bn_
+    rng = np.random.default_rng(100 + seed)
+    n_pts = int(rng.integers(900, 2600))
+    m1 = int(rng.integers(200, 400))
+    m2 = int(rng.integers(48, m1 // 2))
+    m3 = int(rng.integers(8, m2 // 2))
+    ch = lambda lo, hi: int(rng.integers(lo, hi)) * 4       # noqa: E731  (fast path needs C % 4 == 0)
+    sa = tuple((ch(4, 24), ch(4, 24), ch(8, 40)) for _ in range(3))
+    fp = ((ch(8, 40), ch(8, 40)), (ch(8, 32), ch(8, 32)), (ch(4, 24), ch(4, 24), ch(4, 24)))
+    cfg = dict(score_classes=3, num_centroids=(m1, m2, m3), radius=(0.05, 0.12, 0.4),
+               num_neighbours=tuple(int(rng.choice([16, 32, 64])) for _ in range(3)), sa_channels=sa,
+               fp_channels=fp, num_fp_neighbours=(3, 3, 3),
+               seg_channels=(ch(8, 32), ch(4, 24), ch(4, 24), ch(2, 12)), num_removal_directions=5,
+               dropout_prob=0.5)
+    torch.manual_seed(seed)
+    net = randomize_bn_(PointNet2(**cfg), seed + 50).to(dev).eval()
+    variant = ["tabletop-v1", "dup-heavy", "uniform-box"][seed % 3]
+    pts = torch.from_numpy(synth.make_batch([seed, seed + 1, seed + 2][: 1 + seed % 3], n_pts, variant=variant)).to(dev)
+    with torch.no_grad():
+        a = net({"scene_points": pts})
+    for precision in ("f16x2", "bf16x3"):
+        b = FusedPointNet2(net, precision=precision)({"scene_points": pts})
+        for k in a:
+            scale = max(1.0, float(a[k].abs().max()))
+            assert (a[k] - b[k]).abs().max().item() < TOL * scale, (k, precision, cfg)
