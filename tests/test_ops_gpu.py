@@ -373,3 +373,43 @@ def test_runs_on_current_stream(F, oracle, dev):
         idx = F.farthest_point_sample(x, 128)
     s.synchronize()
     assert np.array_equal(idx.cpu().numpy(), oracle.fps(pts, 128))
+
+
+# ------------------------------------------------------------------ randomized cross-checks
+@pytest.mark.parametrize("seed", range(20))
+def test_random_geometry_pipeline_matches_oracle(F, oracle, dev, seed):
+    """Random sizes / radii / neighbour counts through FPS -> ball_query -> group_points ->
+    3-NN -> interpolate, every stage against the oracle (bit-exact), on rotating cloud kinds.
+    Sizes straddle the dispatch thresholds (grid vs scan ball query, grid vs scan 3-NN,
+    vector vs scalar group kernels, AoS / channels-last variants)."""
+    rng = np.random.default_rng(1000 + seed)
+    variant = ["tabletop-v1", "dup-heavy", "uniform-box"][seed % 3]
+    B = int(rng.integers(1, 4))
+    N = int(rng.choice([777, 2048, 5000, 8192, 9001, 12000]))
+    M = int(rng.integers(3, min(N, 2500)))
+    K = int(rng.choice([1, 7, 16, 32, 64, 100]))
+    radius = float(rng.choice([0.01, 0.03, 0.08, 0.5]))
+    pts = synth.make_batch(list(range(seed, seed + B)), N, variant=variant)
+    tp = _t(pts, dev)
+    fps = F.farthest_point_sample(tp, M)
+    rfps = oracle.fps(pts, M)
+    assert np.array_equal(fps.cpu().numpy(), rfps), (N, M, variant)
+    ctr = oracle.gather_points(pts, rfps)
+    assert np.array_equal(F.gather_points(tp, fps).cpu().numpy(), ctr)
+    idx, cnt = F.ball_query(tp, _t(ctr, dev), radius, K)
+    ridx, rcnt = oracle.ball_query(pts, ctr, radius, K)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(cnt.cpu().numpy(), rcnt), (N, M, K, radius)
+    grouped = F.group_points(tp, idx)
+    assert np.array_equal(grouped.cpu().numpy(), oracle.group_points(pts, ridx))
+    C = int(rng.choice([1, 4, 6, 20]))
+    feat = rng.standard_normal((B, C, N)).astype(np.float32)
+    assert np.array_equal(F.group_points(_t(feat, dev), idx).cpu().numpy(), oracle.group_points(feat, ridx))
+    if M >= 3:
+        nidx, nd2 = F.search_nn_distance(tp, _t(ctr, dev), 3)
+        rn, rd = oracle.three_nn(pts, ctr)
+        assert np.array_equal(nidx.cpu().numpy(), rn) and np.array_equal(nd2.cpu().numpy(), rd), (N, M, variant)
+        w = F.interp_weights(nd2)
+        sparse = rng.standard_normal((B, C, M)).astype(np.float32)
+        got = F.feature_interpolate(_t(sparse, dev), nidx, w).cpu().numpy()
+        ref = oracle.three_interpolate(sparse, rn, w.cpu().numpy())
+        assert np.array_equal(got, ref)
