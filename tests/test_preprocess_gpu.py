@@ -93,3 +93,26 @@ def test_sample_single_cloud_fps_mode(dev):
     assert torch.equal(out, p[:, idx])
     short = PP.sample_single_cloud(p[:, :100], 256, seed=2, mode="fps")   # falls back to repetition
     assert short.shape == (3, 256)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_preprocessing_matches_oracle(dev, seed):
+    """Random cloud kinds / sizes / voxel edges / radii / thresholds through crop, voxel
+    down-sample and radius-outlier removal, each against the oracle (bit-exact)."""
+    from s4g_release_amd import preprocess as PP
+    rng = np.random.default_rng(500 + seed)
+    variant = ["tabletop-v1", "dup-heavy", "uniform-box"][seed % 3]
+    n = int(rng.choice([37, 1000, 4097, 9000, 15000]))
+    p = _scene(n, seed, variant=variant)
+    t = torch.from_numpy(p).to(dev)
+    lo, hi = np.percentile(p, rng.uniform(0, 30), axis=1), np.percentile(p, rng.uniform(60, 100), axis=1)
+    ws = (lo[0], hi[0], lo[1], hi[1], lo[2], hi[2])
+    assert np.array_equal(PP.filter_work_space(t, ws).cpu().numpy(), OP.filter_work_space(p, ws))
+    voxel = float(rng.choice([0.002, 0.005, 0.013, 0.04]))
+    got = PP.voxel_down_sample(t, voxel).cpu().numpy()
+    ref = OP.voxel_down_sample(p, voxel)
+    assert got.shape == ref.shape and np.array_equal(got, ref), (n, voxel, variant)
+    radius = float(rng.choice([0.008, 0.02, 0.05]))
+    nb = int(rng.choice([1, 4, 16, 32]))
+    gm = PP.radius_outlier_mask(torch.from_numpy(ref).to(dev), nb, radius).cpu().numpy()
+    assert np.array_equal(gm, OP.remove_radius_outlier(ref, nb, radius)), (n, nb, radius, variant)
