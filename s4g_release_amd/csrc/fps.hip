@@ -107,7 +107,9 @@ __device__ __forceinline__ void fps_pick(const float (&x)[PPT],
 template <int THREADS, int PPT, bool FMAD, typename IdxT>
 __global__ __launch_bounds__(THREADS) void fps_reg_kernel(
     const float* __restrict__ xyz, int N, int M, IdxT* __restrict__ idx,
-    float* __restrict__ ctr, int lg_bs) {
+    float* __restrict__ ctr, int lg_bs, int M_run, float* __restrict__ md_out) {
+  // M_run <= M steps are computed (outputs keep stride M); md_out (or NULL) receives the
+  // running min-distances afterwards -- the hand-over to fps_pruned_kernel
   constexpr int WAVES = THREADS / 64;
   __shared__ FpsSlot slots[2][FPS_MAX_WAVES];
   const int b = blockIdx.x;
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(
     }
   }
 
-  for (int i = 1; i < M; ++i) {
+  for (int i = 1; i < M_run; ++i) {
     float best = 0.0f;
     int bestp = -1;
     // two points per instruction where the ISA has packed fp32 forms (v_pk_add / v_pk_mul /
@@ -211,6 +213,13 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(
         cout[M + i] = cy;
         cout[2 * M + i] = cz;
       }
+    }
+  }
+  if (md_out) {
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      const int j = t + THREADS * p;
+      if (j < N) md_out[(size_t)b * N + j] = md[p];
     }
   }
 }
@@ -425,8 +434,12 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_stream_kernel(
 // their min-distances and Mg bit for bit, so the selected index sequence is the
 // one of the full scan (tests compare against the oracle).  On the bench scenes a
 // centroid touches 9 of 400 groups on average (64 in the first 48 steps); the
-// first FPS_DENSE_STEPS steps use the full scan and the maxima are computed once
-// afterwards.  OPT-IN (S4G_FPS_MODE=pruned): see fps_use_pruned for why.
+// first FPS_DENSE_STEPS steps are run by the full-scan kernel, which hands its
+// min-distances over through the workspace.  Updates are dispatched by straight-line
+// guarded blocks (one rarely-taken scalar branch per 8 slots, one per slot) with static
+// register indices; a group's maximum is only re-reduced when a point that held it came
+// closer; the winner's slot is fetched by one walk of a 6-level scalar branch tree.
+// 25 600 -> 5 120: 6.7 ms against 10.9 ms for the full scan (S4G_FPS_MODE=dense).
 // The winner is resolved lazily: wave max over the Mg lanes, then the lane(s) of
 // that group that hold it (static register index through a scalar branch tree),
 // original index and tie key from an LDS table.
@@ -538,6 +551,26 @@ __device__ __forceinline__ float fps_pick_md(const float (&md)[PPT], int pw) {
   }
 }
 
+// x / y / z / md of slot pw for every lane in one walk of the tree
+template <int PPT, int LO, int HI>
+__device__ __forceinline__ void fps_pick_slot(const float (&x)[PPT], const float (&y)[PPT],
+                                              const float (&z)[PPT], const float (&md)[PPT], int pw,
+                                              float& vx, float& vy, float& vz, float& vm) {
+  if constexpr (HI - LO == 1) {
+    vx = x[LO];
+    vy = y[LO];
+    vz = z[LO];
+    vm = md[LO];
+    asm volatile("; fps pick" : "+v"(vx), "+v"(vy), "+v"(vz), "+v"(vm));
+  } else {
+    constexpr int MID = (LO + HI) / 2;
+    if (pw < MID)
+      fps_pick_slot<PPT, LO, MID>(x, y, z, md, pw, vx, vy, vz, vm);
+    else
+      fps_pick_slot<PPT, MID, HI>(x, y, z, md, pw, vx, vy, vz, vm);
+  }
+}
+
 // update of one group (slot P of this wave): distances, running minimum, new group maximum
 template <int PPT, int LO, int HI, bool FMAD>
 __device__ __forceinline__ void fps_update_slot(const float (&x)[PPT], const float (&y)[PPT],
@@ -567,8 +600,9 @@ __device__ __forceinline__ void fps_update_slot(const float (&x)[PPT], const flo
 template <int THREADS, int PPT, bool FMAD, typename IdxT>
 __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __restrict__ xyz,
                                                              const int* __restrict__ perm,
-                                                             const float* __restrict__ gbox, int N,
-                                                             int M, IdxT* __restrict__ idx,
+                                                             const float* __restrict__ gbox,
+                                                             const float* __restrict__ md_in, int i0,
+                                                             int N, int M, IdxT* __restrict__ idx,
                                                              float* __restrict__ ctr, int lg_bs) {
   constexpr int WAVES = THREADS / 64;
   constexpr int GPL = (PPT + 63) / 64;   // group registers per lane: slot p lives in lane p % 64, reg p / 64
@@ -608,23 +642,16 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
     x[p] = px[j];
     y[p] = py[j];
     z[p] = pz[j];
-    // padding lanes sit at min-distance 0: never a maximum unless every real point is at 0 too
-    md[p] = ok ? __builtin_inff() : 0.0f;
+    // min-distances after the first i0 steps (full-scan kernel); padding lanes sit at 0:
+    // never a maximum unless every real point is at 0 too
+    md[p] = ok ? md_in[(size_t)b * N + j] : 0.0f;
     orig[s] = (uint16_t)j;
   }
   const uint32_t rkey = (__brev((uint32_t)t & bs_mask) >> (32 - lg_bs)) << 23;   // all-zero case only
   __syncthreads();
 
-  int cur = 0;
-  float cx = px[0], cy = py[0], cz = pz[0];
-  if (t == 0) {
-    out[0] = 0;
-    if (cout) {
-      cout[0] = cx;
-      cout[M] = cy;
-      cout[2 * M] = cz;
-    }
-  }
+  int cur = (int)out[i0 - 1];
+  float cx = px[cur], cy = py[cur], cz = pz[cur];
 
   auto publish = [&](int i, uint32_t wmax, uint32_t wtie, float sx, float sy, float sz) {
     fps_block_exchange<WAVES>(slots[i & 1], wave, lane, wmax, wtie, sx, sy, sz, cur, cx, cy, cz);
@@ -638,46 +665,6 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
     }
   };
 
-  // ---- dense phase: the first steps touch most groups; full scan -----------
-  const int dense_end = M < FPS_DENSE_STEPS ? M : FPS_DENSE_STEPS;
-  for (int i = 1; i < dense_end; ++i) {
-    float sx = cx, sy = cy, sz = cz;
-    float best = 0.0f;
-#pragma unroll
-    for (int p = 0; p < PPT; ++p) {
-      const float d = dist2<FMAD>(cx, cy, cz, x[p], y[p], z[p]);
-      float m;
-      asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(d), "v"(md[p]));
-      md[p] = m;
-      best = fmaxf(best, m);
-    }
-    const uint32_t dbits = __float_as_uint(best);
-    const uint32_t wmax = wave_max_u32(dbits);
-    // a lane's slots are unrelated original indices: compare the keys of every slot
-    // that holds the wave maximum (dense steps are few)
-    uint32_t tie = 0xFFFFFFFFu;
-    int tp = -1;
-    if (wmax != 0u && dbits == wmax) {
-#pragma unroll
-      for (int p = 0; p < PPT; ++p) {
-        const int s = 64 * (WAVES * p + wave) + lane;
-        if (__float_as_uint(md[p]) == wmax && s < N) {
-          const uint32_t k = tie_key(orig[s]);
-          if (k < tie) {
-            tie = k;
-            tp = p;
-          }
-        }
-      }
-    }
-    if (wmax == 0u) tie = rkey | (uint32_t)cur;   // nothing left above 0: repeat `cur`
-    const uint32_t wtie = wave_min_u32(tie);
-    const uint64_t win = __ballot(tie == wtie);
-    const int wl = __ffsll((unsigned long long)win) - 1;
-    const int pw = __builtin_amdgcn_readlane(tp, wl);
-    if (wmax != 0u && pw >= 0) fps_pick<PPT, 0, PPT>(x, y, z, pw, wl, sx, sy, sz);
-    publish(i, wmax, wtie, sx, sy, sz);
-  }
   // exact group maxima, once
 #pragma unroll
   for (int p = 0; p < PPT; ++p) {
@@ -686,7 +673,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
   }
 
   // ---- pruned phase ---------------------------------------------------------
-  for (int i = dense_end; i < M; ++i) {
+  for (int i = i0; i < M; ++i) {
     uint32_t wmax, wtie;
     float sx = cx, sy = cy, sz = cz;
     // 1. groups the new centroid can still change
@@ -703,13 +690,39 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
       } else {
         lb = __fadd_rn(__fadd_rn(__fmul_rn(tx, tx), __fmul_rn(ty, ty)), __fmul_rn(tz, tz));
       }
-      uint64_t need = __ballot(live && lb < mg[r]);
-      while (need) {
-        const int p = 64 * r + __ffsll((unsigned long long)need) - 1;
-        need &= need - 1;
-        float g = 0.f;
-        fps_update_slot<PPT, 0, PPT, FMAD>(x, y, z, md, p, cx, cy, cz, g);
-        if (lane == (p & 63)) mg[r] = g;
+      const uint64_t need = __ballot(live && lb < mg[r]);
+      // straight-line dispatch: one (rarely taken) scalar branch per 8 slots, then one per
+      // slot; every leaf indexes its registers statically.  The volatile asm pins a leaf's
+      // arithmetic behind its branch (the compiler would otherwise evaluate all of them).
+      if (need) {
+#pragma unroll
+        for (int p8 = 0; p8 < 64 && 64 * r + p8 < PPT; p8 += 8) {
+          if (__builtin_expect(((need >> p8) & 0xFFull) != 0ull, 0)) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              constexpr int dummy = 0;
+              (void)dummy;
+              const int p = 64 * r + p8 + e;
+              if (p < PPT) {
+                if ((need >> (p8 + e)) & 1ull) {
+                  float xl = x[p];
+                  asm volatile("; fps slot" : "+v"(xl));
+                  const float d = dist2<FMAD>(cx, cy, cz, xl, y[p], z[p]);
+                  float m;
+                  const float old = md[p];
+                  asm volatile("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(d), "v"(old));
+                  md[p] = m;
+                  // the group maximum only moves if a point that held it came closer
+                  const uint32_t gm = __builtin_amdgcn_readlane(__float_as_uint(mg[r]), p8 + e);
+                  if (__ballot(__float_as_uint(old) == gm && m < old)) {
+                    const uint32_t g = wave_max_u32(__float_as_uint(m));
+                    if (lane == p8 + e) mg[r] = __uint_as_float(g);
+                  }
+                }
+              }
+            }
+          }
+        }
       }
       gbits[r] = live ? __float_as_uint(mg[r]) : 0u;
     }
@@ -722,19 +735,20 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
       wtie = wave_min_u32(rkey | (uint32_t)cur);   // every point of this wave is at distance 0
     } else {
       uint32_t best_key = 0xFFFFFFFFu;
-      int best_p = 0, best_l = 0;
 #pragma unroll
       for (int r = 0; r < GPL; ++r) {
         uint64_t gmask = __ballot(gbits[r] == wmax);
         while (gmask) {                          // one group unless maxima tie across groups
           const int pw = 64 * r + __ffsll((unsigned long long)gmask) - 1;
           gmask &= gmask - 1;
-          const float mdv = fps_pick_md<PPT, 0, PPT>(md, pw);
           const int s = 64 * (WAVES * pw + wave) + lane;
-          const bool hit = s < N && __float_as_uint(mdv) == wmax;
+          // every lane reads its original index early (the LDS read overlaps the tree walk)
+          const uint32_t kk = tie_key(orig[s < N ? s : 0]);
+          float vx, vy, vz, vm;
+          fps_pick_slot<PPT, 0, PPT>(x, y, z, md, pw, vx, vy, vz, vm);
+          const bool hit = s < N && __float_as_uint(vm) == wmax;
           const uint64_t eq = __ballot(hit);
-          uint32_t k = 0xFFFFFFFFu;
-          if (hit) k = tie_key(orig[s]);
+          const uint32_t k = hit ? kk : 0xFFFFFFFFu;
           uint32_t kmin;
           int wl;
           if (__popcll(eq) == 1) {
@@ -746,13 +760,13 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
           }
           if (kmin < best_key) {
             best_key = kmin;
-            best_p = pw;
-            best_l = wl;
+            sx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vx), wl));
+            sy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vy), wl));
+            sz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vz), wl));
           }
         }
       }
       wtie = best_key;
-      fps_pick<PPT, 0, PPT>(x, y, z, best_p, best_l, sx, sy, sz);
     }
     publish(i, wmax, wtie, sx, sy, sz);
   }
@@ -761,6 +775,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
 struct FpsSortWs {
   float* bbox;
   float* gbox;
+  float* md;
   uint64_t *key_in, *key_out;
   int *val_in, *val_out;
   void* tmp;
@@ -783,6 +798,7 @@ static FpsSortWs fps_sort_ws(void* base, int64_t B, int64_t N) {
   };
   w.bbox = (float*)take(sizeof(float) * 6 * B);
   w.gbox = (float*)take(sizeof(float) * 6 * B * ((N + 63) / 64 + 256));
+  w.md = (float*)take(sizeof(float) * n);
   w.key_in = (uint64_t*)take(sizeof(uint64_t) * n);
   w.key_out = (uint64_t*)take(sizeof(uint64_t) * n);
   w.val_in = (int*)take(sizeof(int) * n);
@@ -793,16 +809,14 @@ static FpsSortWs fps_sort_ws(void* base, int64_t B, int64_t N) {
 }
 
 static bool fps_use_pruned(int64_t N) {
-  // S4G_FPS_MODE=pruned opts in (read per call).  The pruned kernel is exact (same
-  // index sequence, tests) and rescans 43x fewer points on the bench scenes, but as
-  // compiled today it is SLOWER than the full scan (19-36 ms vs 11.3 ms at SA1 size):
-  // the 100-leaf register-indexed dispatch makes the compiler shuttle the point
-  // arrays between VGPRs and AGPRs and reload spilled registers from scratch inside
-  // the step (PMC: 660 VALU + 38 vector-memory reads per wave per step).  It needs a
-  // hand-scheduled inner loop before it can become the default.
+  // S4G_FPS_MODE=dense|pruned (read per call).  Default: pruned where a lane holds more
+  // than 20 points (N > 10 240) -- below that the full scan is cheaper than the
+  // bookkeeping (SA2 size: 0.94 ms dense vs 1.28 ms pruned).
   const char* e = getenv("S4G_FPS_MODE");
-  if (!e || e[0] != 'p') return false;
-  return N > 512 && N <= (int64_t)256 * 100;
+  if (e && e[0] == 'd') return false;
+  if (N > (int64_t)512 * 50) return false;
+  if (e && e[0] == 'p') return N > 512 * 5;
+  return N > 512 * 20;
 }
 
 static int ref_block_lg(int64_t n) {
@@ -824,54 +838,46 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
                       hipStream_t stream) {
   const int lg = ref_block_lg(N);
   const dim3 grid((unsigned)B);
-  if (fps_use_pruned(N)) {
-    FpsSortWs w = fps_sort_ws(ws, B, N);
-    if (ws && ws_bytes >= w.total && B < (1 << 16)) {
-      hipLaunchKernelGGL(fps_bbox_kernel, dim3((unsigned)B), dim3(1024), 0, stream, xyz, (int)N, w.bbox);
-      S4G_LAUNCH_CHECK();
-      hipLaunchKernelGGL(fps_morton_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256),
-                         0, stream, xyz, (int)N, (int)B, w.bbox, w.key_in, w.val_in);
-      S4G_LAUNCH_CHECK();
-      int bits = 30;
-      while ((1ll << (bits - 30)) < B) ++bits;
-      size_t tb = w.tmp_bytes;
-      const hipError_t e = rocprim::radix_sort_pairs(w.tmp, tb, w.key_in, w.key_out, w.val_in,
-                                                     w.val_out, (size_t)B * (size_t)N, 0, bits, stream);
-      if (e != hipSuccess) return (int)e;
-      // four waves (one per SIMD): 512 registers per lane, so all four arrays of the
-      // 100 points per lane stay on chip (the allocator parks the colder ones in AGPRs)
-#define S4G_FPS_PRUNED(T, P)                                                                       \
-  if (N <= (int64_t)T * P) {                                                                       \
-    const size_t lds = sizeof(uint16_t) * T * P;                                                   \
-    static const hipError_t attr = hipFuncSetAttribute(                                            \
-        reinterpret_cast<const void*>(&fps_pruned_kernel<T, P, FMAD, IdxT>),                       \
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
-    if (attr != hipSuccess) return (int)attr;                                                      \
-    constexpr int G = (T / 64) * P;                                                                \
-    hipLaunchKernelGGL(fps_group_box_kernel, dim3((G + 3) / 4, (unsigned)B), dim3(256), 0, stream, \
-                       xyz, w.val_out, (int)N, G, w.gbox);                                         \
-    S4G_LAUNCH_CHECK();                                                                            \
-    hipLaunchKernelGGL((fps_pruned_kernel<T, P, FMAD, IdxT>), grid, dim3(T), lds, stream, xyz,     \
-                       w.val_out, w.gbox, (int)N, (int)M, idx, ctr, lg);                           \
-    S4G_LAUNCH_CHECK();                                                                            \
-    return S4G_OK;                                                                                 \
-  }
-      S4G_FPS_PRUNED(256, 4)
-      S4G_FPS_PRUNED(256, 20)
-      S4G_FPS_PRUNED(256, 40)
-      S4G_FPS_PRUNED(256, 64)
-      S4G_FPS_PRUNED(256, 100)
-#undef S4G_FPS_PRUNED
-    }
-  }
-  int variant = 0;  // S4G_FPS_VARIANT=1024x25 | 512x50 | 256x100 (tuning knob)
+  int variant = 0;  // S4G_FPS_THREADS=1024 (tuning knob)
   if (const char* e = getenv("S4G_FPS_THREADS")) variant = atoi(e);
+
+  // opt-in pruned variant: Morton order + group boxes, the first FPS_DENSE_STEPS steps by
+  // the full-scan kernel (which leaves its min-distances in the workspace), the rest pruned
+  FpsSortWs w = {};
+  bool pruned = false;
+  if (fps_use_pruned(N) && M > FPS_DENSE_STEPS && B < (1 << 16)) {
+    w = fps_sort_ws(ws, B, N);
+    pruned = ws && ws_bytes >= w.total;
+  }
+  int m_run = (int)M;
+  float* md_out = nullptr;
+  int dense_steps = FPS_DENSE_STEPS;
+  if (const char* e = getenv("S4G_FPS_DENSE_STEPS")) dense_steps = atoi(e) > 1 ? atoi(e) : 2;
+  if (dense_steps >= M) pruned = false;
+  if (pruned) {
+    hipLaunchKernelGGL(fps_bbox_kernel, dim3((unsigned)B), dim3(1024), 0, stream, xyz, (int)N, w.bbox);
+    S4G_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fps_morton_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256),
+                       0, stream, xyz, (int)N, (int)B, w.bbox, w.key_in, w.val_in);
+    S4G_LAUNCH_CHECK();
+    int bits = 30;
+    while ((1ll << (bits - 30)) < B) ++bits;
+    size_t tb = w.tmp_bytes;
+    const hipError_t e = rocprim::radix_sort_pairs(w.tmp, tb, w.key_in, w.key_out, w.val_in,
+                                                   w.val_out, (size_t)B * (size_t)N, 0, bits, stream);
+    if (e != hipSuccess) return (int)e;
+    m_run = dense_steps;
+    md_out = w.md;
+  }
+
+  bool launched = false;
 #define S4G_FPS_CASE(T, P)                                                   \
-  if (N <= (int64_t)T * P) {                                                 \
+  if (!launched && N <= (int64_t)T * P) {                                    \
     hipLaunchKernelGGL((fps_reg_kernel<T, P, FMAD, IdxT>), grid, dim3(T), 0, \
-                       stream, xyz, (int)N, (int)M, idx, ctr, lg);           \
+                       stream, xyz, (int)N, (int)M, idx, ctr, lg, m_run,     \
+                       md_out);                                              \
     S4G_LAUNCH_CHECK();                                                      \
-    return S4G_OK;                                                           \
+    launched = true;                                                         \
   }
   if (variant == 1024) {
     S4G_FPS_CASE(1024, 25)
@@ -885,13 +891,37 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
   S4G_FPS_CASE(512, 20)
   S4G_FPS_CASE(512, 32)
   S4G_FPS_CASE(512, 50)
+#undef S4G_FPS_CASE
+  if (launched && pruned) {
+#define S4G_FPS_PRUNED(T, P)                                                                       \
+  if (N <= (int64_t)T * P) {                                                                       \
+    const size_t lds = sizeof(uint16_t) * T * P;                                                   \
+    static const hipError_t attr = hipFuncSetAttribute(                                            \
+        reinterpret_cast<const void*>(&fps_pruned_kernel<T, P, FMAD, IdxT>),                       \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+    if (attr != hipSuccess) return (int)attr;                                                      \
+    constexpr int G = (T / 64) * P;                                                                \
+    hipLaunchKernelGGL(fps_group_box_kernel, dim3((G + 3) / 4, (unsigned)B), dim3(256), 0, stream, \
+                       xyz, w.val_out, (int)N, G, w.gbox);                                         \
+    S4G_LAUNCH_CHECK();                                                                            \
+    hipLaunchKernelGGL((fps_pruned_kernel<T, P, FMAD, IdxT>), grid, dim3(T), lds, stream, xyz,     \
+                       w.val_out, w.gbox, w.md, dense_steps, (int)N, (int)M, idx, ctr, lg);            \
+    S4G_LAUNCH_CHECK();                                                                            \
+    return S4G_OK;                                                                                 \
+  }
+    S4G_FPS_PRUNED(512, 10)
+    S4G_FPS_PRUNED(512, 20)
+    S4G_FPS_PRUNED(512, 32)
+    S4G_FPS_PRUNED(512, 50)
+#undef S4G_FPS_PRUNED
+  }
+  if (launched) return S4G_OK;
   if (N <= (int64_t)512 * 100) {   // x + min-distance in registers, y / z streamed from L2
     hipLaunchKernelGGL((fps_hybrid_kernel<512, 100, 10, FMAD, IdxT>), grid, dim3(512), 0, stream, xyz,
                        (int)N, (int)M, idx, ctr, lg);
     S4G_LAUNCH_CHECK();
     return S4G_OK;
   }
-#undef S4G_FPS_CASE
   if (ws_bytes < (size_t)B * (size_t)N * sizeof(float) || ws == nullptr)
     return S4G_EWORKSPACE;
   hipLaunchKernelGGL((fps_stream_kernel<FMAD, IdxT>), grid, dim3(FPS_THREADS), 0, stream,

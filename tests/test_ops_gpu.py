@@ -49,12 +49,15 @@ def test_fps_full_size_sa1(F, oracle, dev, variant):
                                          (20000, 300, "uniform-box"), (6000, 1500, "tabletop-v1"),
                                          (700, 700, "dup-heavy")])
 def test_fps_pruned_variant_is_exact(F, oracle, dev, monkeypatch, N, M, variant):
-    """Opt-in group-pruned kernel (Morton order + per-group bounding boxes): skipping a
-    group is exact by monotonicity of the rounded distance, ties included."""
+    """Group-pruned kernel (Morton order + per-group bounding boxes; default above 10 240
+    points, forced here for the small sizes too): skipping a group is exact by monotonicity
+    of the rounded distance, ties included.  The full scan must agree as well."""
     monkeypatch.setenv("S4G_FPS_MODE", "pruned")
     pts = synth.make_batch([3, 5], N, variant=variant)
     got = F.farthest_point_sample(_t(pts, dev), M).cpu().numpy()
     assert np.array_equal(got, oracle.fps(pts, M))
+    monkeypatch.setenv("S4G_FPS_MODE", "dense")
+    assert np.array_equal(F.farthest_point_sample(_t(pts, dev), M).cpu().numpy(), got)
 
 
 def test_fps_hybrid_kernel_large_cloud(F, oracle, dev):
@@ -72,6 +75,16 @@ def test_fps_streaming_fallback_very_large_cloud(F, oracle, dev):
     pts = synth.make_batch([2], 60000)
     got = F.farthest_point_sample(_t(pts, dev), 100).cpu().numpy()
     assert np.array_equal(got, oracle.fps(pts, 100))
+
+
+def test_fps_fmad_mode_pruned_size(F, oracle, dev):
+    pts = synth.make_batch([4], 12000)
+    try:
+        F.set_distance_mode("fmad")
+        got = F.farthest_point_sample(_t(pts, dev), 700).cpu().numpy()
+    finally:
+        F.set_distance_mode("strict")
+    assert np.array_equal(got, oracle.fps(pts, 700, fmad=1))
 
 
 def test_fps_fmad_mode(F, oracle, dev):
