@@ -102,17 +102,22 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void ball_query_scan_kerne
 // ---------------------------------------------------------------- GRID path
 // (grid layout, slot mapping and workspace carving: grid.h)
 __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
-    const float* __restrict__ xyz, int N, float inv_h, GridWs ws, int write_aos) {
+    const float* __restrict__ xyz, int N, float inv_h, GridWs ws, int write_aos,
+    const float* __restrict__ ctr, int M, CellWs cw) {
   __shared__ uint32_t hist[GR_RANGE_SLOTS];
   __shared__ uint32_t wsum[GR_BUILD_THREADS / 64];
+  __shared__ uint32_t wsum2[GR_BUILD_THREADS / 64];
   const int b = blockIdx.y;
-  const int g = blockIdx.x;
+  const int g = blockIdx.x & (GR_RANGES - 1);
+  const bool queries = blockIdx.x >= GR_RANGES;  // workgroups 8..15 bin the queries
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
-  const float* __restrict__ px = xyz + (size_t)b * 3 * N;
-  const float* __restrict__ py = px + N;
-  const float* __restrict__ pz = py + N;
-  const float ox = px[0], oy = py[0], oz = pz[0];
+  const float* __restrict__ p0 = xyz + (size_t)b * 3 * N;
+  const float ox = p0[0], oy = p0[N], oz = p0[2 * (size_t)N];  // origin: the scene's first point
+  const int n = queries ? M : N;
+  const float* __restrict__ px = queries ? ctr + (size_t)b * 3 * M : p0;
+  const float* __restrict__ py = px + n;
+  const float* __restrict__ pz = py + n;
 
   for (int s = t; s < GR_RANGE_SLOTS; s += GR_BUILD_THREADS) hist[s] = 0;
   __syncthreads();
@@ -120,19 +125,19 @@ __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
   // The point loops issue GR_BUILD_U independent plane loads per lane before
   // touching them: the slab workgroups are latency-, not bandwidth-bound.
   int bad = 0;
-  for (int j0 = t; j0 < N; j0 += GR_BUILD_THREADS * GR_BUILD_U) {
+  for (int j0 = t; j0 < n; j0 += GR_BUILD_THREADS * GR_BUILD_U) {
     float x[GR_BUILD_U], y[GR_BUILD_U], z[GR_BUILD_U];
 #pragma unroll
     for (int u = 0; u < GR_BUILD_U; ++u) {
       const int j = j0 + u * GR_BUILD_THREADS;
-      const int jj = j < N ? j : 0;
+      const int jj = j < n ? j : 0;
       x[u] = px[jj];
       y[u] = py[jj];
       z[u] = pz[jj];
     }
 #pragma unroll
     for (int u = 0; u < GR_BUILD_U; ++u) {
-      if (j0 + u * GR_BUILD_THREADS < N) {
+      if (j0 + u * GR_BUILD_THREADS < n) {
         if (!(grid_coord_ok(x[u], ox, inv_h) && grid_coord_ok(y[u], oy, inv_h) &&
               grid_coord_ok(z[u], oz, inv_h)))
           bad = 1;
@@ -143,39 +148,62 @@ __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
     }
   }
   bad = __syncthreads_or(bad);
-  if (g == 0 && t == 0) ws.flags[b] = bad ? 1 : 0;
+  if (!queries && g == 0 && t == 0) ws.flags[b] = bad ? 1 : 0;
 
   // exclusive scan of the 4096 counts: 4 consecutive entries per thread
   const uint32_t v0 = hist[4 * t], v1 = hist[4 * t + 1], v2 = hist[4 * t + 2], v3 = hist[4 * t + 3];
   const uint32_t s = v0 + v1 + v2 + v3;
-  uint32_t incl = s;
+  const uint32_t nzc = s != 0u ? 1u : 0u;  // non-empty x-quads
+  // counts and non-empty-cell counts scanned together (both < 2^16 per workgroup here?
+  // no: n may reach 2^16 points, so keep two scans)
+  uint32_t incl = s, incl2 = nzc;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const uint32_t o = __shfl_up(incl, off);
-    if (lane >= off) incl += o;
+    const uint32_t o2 = __shfl_up(incl2, off);
+    if (lane >= off) {
+      incl += o;
+      incl2 += o2;
+    }
   }
-  if (lane == 63) wsum[wave] = incl;
+  if (lane == 63) {
+    wsum[wave] = incl;
+    wsum2[wave] = incl2;
+  }
   __syncthreads();
-  uint32_t wbase = 0;
-  for (int w = 0; w < wave; ++w) wbase += wsum[w];
-  const uint32_t base = (uint32_t)g * (uint32_t)N + wbase + (incl - s);
+  uint32_t wbase = 0, wbase2 = 0;
+  for (int w = 0; w < wave; ++w) {
+    wbase += wsum[w];
+    wbase2 += wsum2[w];
+  }
+  const uint32_t base = (uint32_t)g * (uint32_t)n + wbase + (incl - s);
   hist[4 * t] = base;  // each thread rewrites only the four entries it read
   hist[4 * t + 1] = base + v0;
   hist[4 * t + 2] = base + v0 + v1;
   hist[4 * t + 3] = base + v0 + v1 + v2;
-  int* __restrict__ st = ws.starts + ((size_t)b * GR_RANGES + g) * GR_START_STRIDE;
-  *reinterpret_cast<int4*>(st + 4 * t) =
-      make_int4((int)base, (int)(base + v0), (int)(base + v0 + v1), (int)(base + v0 + v1 + v2));
-  if (t == GR_BUILD_THREADS - 1) st[GR_RANGE_SLOTS] = (int)(base + s);
+  if (!queries) {
+    int* __restrict__ st = ws.starts + ((size_t)b * GR_RANGES + g) * GR_START_STRIDE;
+    *reinterpret_cast<int4*>(st + 4 * t) =
+        make_int4((int)base, (int)(base + v0), (int)(base + v0 + v1), (int)(base + v0 + v1 + v2));
+    if (t == GR_BUILD_THREADS - 1) st[GR_RANGE_SLOTS] = (int)(base + s);
+  } else {
+    // compact list of the non-empty x-quads (4 x-adjacent cells = this thread's 4 slots,
+    // whose records are contiguous): (first slot, first record, count)
+    int4* __restrict__ ce = cw.cells + ((size_t)b * GR_RANGES + g) * GR_RANGE_SLOTS;
+    const uint32_t pos = wbase2 + (incl2 - nzc);
+    if (s) ce[pos] = make_int4((g << 12) | (4 * t), (int)base, (int)s, 0);
+    if (t == GR_BUILD_THREADS - 1) cw.ncell[b * GR_RANGES + g] = (int)(pos + (s ? 1u : 0u));
+  }
   __syncthreads();
 
-  float4* __restrict__ rec = ws.sorted + (size_t)b * GR_RANGES * N;
-  for (int j0 = t; j0 < N; j0 += GR_BUILD_THREADS * GR_BUILD_U) {
+  float4* __restrict__ rec = queries ? cw.sorted + (size_t)b * GR_RANGES * M
+                                     : ws.sorted + (size_t)b * GR_RANGES * N;
+  for (int j0 = t; j0 < n; j0 += GR_BUILD_THREADS * GR_BUILD_U) {
     float x[GR_BUILD_U], y[GR_BUILD_U], z[GR_BUILD_U];
 #pragma unroll
     for (int u = 0; u < GR_BUILD_U; ++u) {
       const int j = j0 + u * GR_BUILD_THREADS;
-      const int jj = j < N ? j : 0;
+      const int jj = j < n ? j : 0;
       x[u] = px[jj];
       y[u] = py[jj];
       z[u] = pz[jj];
@@ -183,8 +211,9 @@ __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
 #pragma unroll
     for (int u = 0; u < GR_BUILD_U; ++u) {
       const int j = j0 + u * GR_BUILD_THREADS;
-      if (j < N) {
-        if (g == 0 && write_aos) ws.xyz4[(size_t)b * N + j] = make_float4(x[u], y[u], z[u], 0.f);
+      if (j < n) {
+        if (!queries && g == 0 && write_aos)
+          ws.xyz4[(size_t)b * N + j] = make_float4(x[u], y[u], z[u], 0.f);
         const int slot = grid_slot(grid_coord(x[u], ox, inv_h), grid_coord(y[u], oy, inv_h),
                                    grid_coord(z[u], oz, inv_h));
         if ((slot >> 12) == g) {
@@ -194,6 +223,57 @@ __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
       }
     }
   }
+}
+
+// Reads a wave's hit bitmap back in index order: lane l owns words [l*W, (l+1)*W),
+// the first K set bits land in row[0..), touched words are cleared.  Returns the
+// number of set bits (may exceed K).
+template <int WPL>
+__device__ __forceinline__ int bq_bitmap_readback(uint32_t* __restrict__ bm, int lane,
+                                                  int words_per_lane, int K,
+                                                  int* __restrict__ row) {
+  uint32_t* mine = bm + lane * words_per_lane;
+  int local = 0;
+  uint32_t nz = 0;  // which of this lane's words are non-zero
+  if constexpr (WPL > 0) {
+    uint32_t wv[WPL];
+#pragma unroll
+    for (int w = 0; w < WPL; ++w) wv[w] = mine[w];
+#pragma unroll
+    for (int w = 0; w < WPL; ++w) {
+      local += __popc(wv[w]);
+      nz |= (wv[w] != 0u ? 1u : 0u) << w;
+    }
+  } else {
+    for (int w = 0; w < words_per_lane; ++w) local += __popc(mine[w]);
+  }
+  const int incl = (int)wave_inclusive_scan_u32((uint32_t)local);
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  int pos = incl - local;
+  if constexpr (WPL > 0) {
+    while (nz) {  // only the touched words; clear them for the next centroid
+      const int w = __ffs(nz) - 1;
+      nz &= nz - 1;
+      uint32_t bits = mine[w];
+      mine[w] = 0u;
+      while (bits && pos < K) {
+        const int bit = __ffs(bits) - 1;
+        row[pos++] = (lane * WPL + w) * 32 + bit;
+        bits &= bits - 1;
+      }
+    }
+  } else if (local > 0) {
+    for (int w = 0; w < words_per_lane; ++w) {
+      uint32_t bits = mine[w];
+      if (bits) mine[w] = 0u;
+      while (bits && pos < K) {
+        const int bit = __ffs(bits) - 1;
+        row[pos++] = (lane * words_per_lane + w) * 32 + bit;
+        bits &= bits - 1;
+      }
+    }
+  }
+  return total;
 }
 
 // One wave per centroid.  Dynamic LDS per wave: bitmap of N bits + K-entry row.
@@ -303,48 +383,7 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void bq_grid_query_kernel(
           j += 7 * BQ_REC;
         }
       }
-      // read the bitmap back in index order: lane l owns words [l*W, (l+1)*W)
-      uint32_t* mine = bm + lane * words_per_lane;
-      int local = 0;
-      uint32_t nz = 0;  // which of this lane's words are non-zero
-      if constexpr (WPL > 0) {
-        uint32_t wv[WPL];
-#pragma unroll
-        for (int w = 0; w < WPL; ++w) wv[w] = mine[w];
-#pragma unroll
-        for (int w = 0; w < WPL; ++w) {
-          local += __popc(wv[w]);
-          nz |= (wv[w] != 0u ? 1u : 0u) << w;
-        }
-      } else {
-        for (int w = 0; w < words_per_lane; ++w) local += __popc(mine[w]);
-      }
-      const int incl = (int)wave_inclusive_scan_u32((uint32_t)local);
-      const int total = __builtin_amdgcn_readlane(incl, 63);
-      int pos = incl - local;
-      if constexpr (WPL > 0) {
-        while (nz) {  // only the touched words; clear them for the next centroid
-          const int w = __ffs(nz) - 1;
-          nz &= nz - 1;
-          uint32_t bits = mine[w];
-          mine[w] = 0u;
-          while (bits && pos < K) {
-            const int bit = __ffs(bits) - 1;
-            row[pos++] = (lane * WPL + w) * 32 + bit;
-            bits &= bits - 1;
-          }
-        }
-      } else if (local > 0) {
-        for (int w = 0; w < words_per_lane; ++w) {
-          uint32_t bits = mine[w];
-          if (bits) mine[w] = 0u;
-          while (bits && pos < K) {
-            const int bit = __ffs(bits) - 1;
-            row[pos++] = (lane * words_per_lane + w) * 32 + bit;
-            bits &= bits - 1;
-          }
-        }
-      }
+      const int total = bq_bitmap_readback<WPL>(bm, lane, words_per_lane, K, row);
       const int cnt = total < K ? total : K;
       const int first = cnt > 0 ? row[0] : 0;
       for (int k = lane; k < K; k += 64) {
@@ -370,20 +409,336 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void bq_grid_query_kernel(
   }
 }
 
+// ---------------------------------------------------------------- CELL path
+// Cell-centric query: the centres are binned into the same grid (build workgroups
+// 8..15) and ONE WORKGROUP TAKES ONE NON-EMPTY X-QUAD OF CENTRE CELLS (4 x-adjacent
+// cells) AT A TIME.  All its centres share the 6 x 3 x 3 cell candidate set, so the
+// workgroup
+//   1. loads the candidate records once, marks their point indices in ONE LDS
+//      bitmap and turns the bitmap into ranks (prefix popcounts): a counting sort
+//      BY POINT INDEX that costs one bitmap sweep per quad instead of one per centre;
+//   2. scatters the records into LDS in rank order (windows of 1024 ranks);
+//   3. hands the centres to its waves round-robin; a wave answers a centre with the
+//      index-order scan of the SCAN path (ballot + mbcnt rank, early exit at K) over
+//      the staged records -- hits leave for global memory already in the
+//      reference's order, and the grouped coordinates come out of the same records
+//      (no gather).  Per-centre state (count, first hit) lives in lane j of the
+//      owning wave between windows.
+// Centres outside the exactness range take the index-order scan over the cloud.
+__device__ __forceinline__ float bq_readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+constexpr int BQC_THREADS = 256;
+constexpr int BQC_WAVES = BQC_THREADS / 64;
+constexpr int BQC_WIN = 1024;                   // ranks per window = records staged in LDS
+constexpr int BQC_RPT = BQC_WIN / BQC_THREADS;  // records per thread per window
+
+template <bool FMAD, typename IdxT, bool GROUP>
+__global__ __launch_bounds__(BQC_THREADS) void bq_cell_query_kernel(
+    const float* __restrict__ xyz, int N, int M, float r2, float inv_h, int K, GridWs ws,
+    CellWs cw, IdxT* __restrict__ idx, IdxT* __restrict__ cnt_out,
+    float* __restrict__ grouped, int bm_words, int wgs_per_scene) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int b = blockIdx.y;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  // bm_words: multiple of 4 * BQC_THREADS (thread t owns words [t*wpt, (t+1)*wpt))
+  const int wpt = bm_words / BQC_THREADS;
+  uint32_t* __restrict__ bm = lds;
+  uint16_t* __restrict__ pre = (uint16_t*)(bm + bm_words);          // prefix per bitmap word
+  float4* __restrict__ stage = (float4*)(bm + bm_words + bm_words / 2);  // records in rank order
+  uint32_t* __restrict__ wsum = bm + bm_words + bm_words / 2 + 4 * BQC_WIN;
+  // per-wave output row (index + grouped x, y, z), written out coalesced
+  const int Kp = (K + 3) & ~3;
+  int* __restrict__ orow = (int*)(wsum + 8) + wave * (GROUP ? 4 : 1) * Kp;
+  float* __restrict__ ogx = (float*)(orow + Kp);
+  for (int w = 4 * t; w < bm_words; w += 4 * BQC_THREADS)
+    *reinterpret_cast<uint4*>(bm + w) = make_uint4(0u, 0u, 0u, 0u);
+
+  const float* __restrict__ px = xyz + (size_t)b * 3 * N;
+  const float* __restrict__ py = px + N;
+  const float* __restrict__ pz = py + N;
+  const float ox = px[0], oy = py[0], oz = pz[0];
+  const bool scene_ok = ws.flags[b] == 0;
+  const float4* __restrict__ rec = ws.sorted + (size_t)b * GR_RANGES * N;
+  const int* __restrict__ starts_b = ws.starts + (size_t)b * GR_RANGES * GR_START_STRIDE;
+  const float4* __restrict__ crec = cw.sorted + (size_t)b * GR_RANGES * M;
+  const int4* __restrict__ cells_b = cw.cells + (size_t)b * GR_RANGES * GR_RANGE_SLOTS;
+  const size_t MK = (size_t)M * K;
+
+  // non-empty centre quads of this scene: 8 stripe lists, addressed as one range
+  const int ncl = lane < GR_RANGES ? cw.ncell[b * GR_RANGES + lane] : 0;
+  const int ninc = (int)wave_inclusive_scan_u32((uint32_t)ncl);
+  const int nitems = __builtin_amdgcn_readlane(ninc, 63);
+  __syncthreads();
+
+  for (int item = blockIdx.x; item < nitems; item += wgs_per_scene) {
+    const int g = __popcll(__ballot(lane < GR_RANGES && ninc <= item));
+    const int e = item - (__shfl(ninc, g) - __shfl(ncl, g));
+    const int4 ce = cells_b[(size_t)g * GR_RANGE_SLOTS + e];
+    const int slot = __builtin_amdgcn_readfirstlane(ce.x);
+    const int cstart = __builtin_amdgcn_readfirstlane(ce.y);
+    const int ccount = __builtin_amdgcn_readfirstlane(ce.z);
+    // record ranges of the 9 (dy, dz) rows, 6 cells [x - 1, x + 4] each: lanes 0..8 first
+    // piece, 9..17 the part that wrapped around x (first / last quad of a row only)
+    int pbeg = 0, plen = 0;
+    {
+      const int local = slot & (GR_RANGE_SLOTS - 1);
+      const int icx = local & 31, icy = (((local >> 5) & 3) << 3) | (slot >> 12), icz = local >> 7;
+      if (lane < 18) {
+        const int r = lane < 9 ? lane : lane - 9;
+        const int dz = r / 3 - 1, dy = r % 3 - 1;
+        const int zz = (icz + dz) & 31, yy = (icy + dy) & 31;
+        const int* __restrict__ st = starts_b + grid_range(yy, zz) * GR_START_STRIDE +
+                                     grid_local_row(yy, zz);
+        if (icx == 0) {           // cells 31 | 0..4
+          pbeg = lane < 9 ? st[31] : st[0];
+          plen = (lane < 9 ? st[32] : st[5]) - pbeg;
+        } else if (icx == 28) {   // cells 27..31 | 0
+          pbeg = lane < 9 ? st[27] : st[0];
+          plen = (lane < 9 ? st[32] : st[1]) - pbeg;
+        } else if (lane < 9) {
+          pbeg = st[icx - 1];
+          plen = st[icx + 5] - pbeg;
+        }
+      }
+    }
+    const int pinc = (int)wave_inclusive_scan_u32((uint32_t)plen);
+    const int poff = pbeg - (pinc - plen);
+    const int tot = __builtin_amdgcn_readlane(pinc, 17);
+    const bool wrapped = tot != __builtin_amdgcn_readlane(pinc, 8);
+    // flat candidate number q -> record index: q + off_i for the piece i that holds q
+    auto record_of = [&](int q) {
+      int off = __builtin_amdgcn_readlane(poff, 0);
+#pragma unroll
+      for (int i = 1; i < 9; ++i)
+        off = q >= __builtin_amdgcn_readlane(pinc, i - 1) ? __builtin_amdgcn_readlane(poff, i) : off;
+      if (wrapped) {
+#pragma unroll
+        for (int i = 9; i < 18; ++i)
+          off = q >= __builtin_amdgcn_readlane(pinc, i - 1) ? __builtin_amdgcn_readlane(poff, i) : off;
+      }
+      return q + off;
+    };
+    auto load_records = [&](float4 (&r)[BQC_RPT], int q0) {
+#pragma unroll
+      for (int u = 0; u < BQC_RPT; ++u) {
+        const int q = q0 + BQC_THREADS * u + t;
+        r[u] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        if (q0 + BQC_THREADS * u < tot && q < tot) r[u] = rec[record_of(q)];
+      }
+    };
+
+    // ---- 1. candidates -> bitmap over the point index -> prefix popcounts
+    float4 p[BQC_RPT];  // window 0's records stay in registers
+    load_records(p, 0);
+#pragma unroll
+    for (int u = 0; u < BQC_RPT; ++u) {
+      const int pi = __float_as_int(p[u].w);
+      if (pi >= 0) atomicOr(&bm[pi >> 5], 1u << (pi & 31));
+    }
+    for (int q0 = BQC_WIN; q0 < tot; q0 += BQC_WIN) {
+      float4 r[BQC_RPT];
+      load_records(r, q0);
+#pragma unroll
+      for (int u = 0; u < BQC_RPT; ++u) {
+        const int pi = __float_as_int(r[u].w);
+        if (pi >= 0) atomicOr(&bm[pi >> 5], 1u << (pi & 31));
+      }
+    }
+    __syncthreads();
+    {
+      int local_cnt = 0;
+      for (int w = 0; w < wpt; w += 4) {
+        const uint4 v = *reinterpret_cast<const uint4*>(bm + t * wpt + w);
+        local_cnt += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+      }
+      const int incl = (int)wave_inclusive_scan_u32((uint32_t)local_cnt);
+      if (lane == 63) wsum[wave] = (uint32_t)incl;
+      __syncthreads();
+      int run = incl - local_cnt;
+      for (int w = 0; w < wave; ++w) run += (int)wsum[w];
+      for (int w = 0; w < wpt; w += 4) {
+        const uint4 v = *reinterpret_cast<const uint4*>(bm + t * wpt + w);
+        const int r0 = run, r1 = r0 + __popc(v.x), r2_ = r1 + __popc(v.y), r3 = r2_ + __popc(v.z);
+        run = r3 + __popc(v.w);
+        *reinterpret_cast<uint2*>(pre + t * wpt + w) =
+            make_uint2((uint32_t)r0 | ((uint32_t)r1 << 16), (uint32_t)r2_ | ((uint32_t)r3 << 16));
+      }
+    }
+    __syncthreads();
+    // records whose rank falls into [win0, win0 + WIN) -> stage[rank - win0]
+    auto stage_records = [&](const float4 (&r)[BQC_RPT], int win0) {
+#pragma unroll
+      for (int u = 0; u < BQC_RPT; ++u) {
+        const int pi = __float_as_int(r[u].w);
+        if (pi >= 0) {
+          const int w = pi >> 5;
+          const int rank = pre[w] + __popc(bm[w] & ((1u << (pi & 31)) - 1u)) - win0;
+          if ((unsigned)rank < (unsigned)BQC_WIN) stage[rank] = r[u];
+        }
+      }
+    };
+    if (tot <= BQC_WIN) stage_records(p, 0);  // stays staged for every centre group
+
+    // ---- the quad's centres: wave w owns centres w, w + 4, ...; lane j holds centre
+    // c0 + w + 4 j and its running state
+    for (int c0 = 0; c0 < ccount; c0 += 64 * BQC_WAVES) {
+      const int ngrp = min(64 * BQC_WAVES, ccount - c0);
+      const int nmine = (ngrp - wave + BQC_WAVES - 1) / BQC_WAVES;  // centres of this wave
+      const float4 lc = crec[cstart + c0 + wave + BQC_WAVES * (lane < nmine ? lane : 0)];
+      const bool lexact = scene_ok && grid_coord_ok(lc.x, ox, inv_h) &&
+                          grid_coord_ok(lc.y, oy, inv_h) && grid_coord_ok(lc.z, oz, inv_h);
+      int st_cnt = 0, st_first = 0;
+      float st_fx = ox, st_fy = oy, st_fz = oz;  // rows without a hit are zeros = point 0
+      for (int win0 = 0; win0 < tot || win0 == 0; win0 += BQC_WIN) {
+        const bool last_win = win0 + BQC_WIN >= tot;
+        // ---- 2. ranks [win0, win0 + WIN) -> LDS
+        if (tot > BQC_WIN) {
+          __syncthreads();  // the previous window's readers are done
+          for (int q0 = 0; q0 < tot; q0 += BQC_WIN) {
+            float4 r[BQC_RPT];
+            load_records(r, q0);
+            stage_records(r, win0);
+          }
+        }
+        __syncthreads();
+        const int nwin = min(BQC_WIN, tot - win0);
+        // ---- 3. this wave's centres: index-order scan over the staged records
+        for (int j = 0; j < nmine; ++j) {
+          const float cx = bq_readlane_f(lc.x, j), cy = bq_readlane_f(lc.y, j),
+                      cz = bq_readlane_f(lc.z, j);
+          const int m = __builtin_amdgcn_readlane(__float_as_int(lc.w), j);
+          const bool exact = __builtin_amdgcn_readlane((int)lexact, j) != 0;
+          IdxT* __restrict__ out_row = idx + ((size_t)b * M + m) * K;
+          IdxT* __restrict__ out_cnt = cnt_out + (size_t)b * M + m;
+          float* __restrict__ gx = GROUP ? grouped + (size_t)b * 3 * MK + (size_t)m * K : nullptr;
+          if (!exact) {
+            if (win0 == 0) {
+              bq_scan_centroid<FMAD, IdxT>(px, py, pz, N, cx, cy, cz, r2, K, lane, out_row,
+                                           out_cnt);
+              if constexpr (GROUP) {
+                __threadfence_block();
+                for (int k = lane; k < K; k += 64) {
+                  const int v = (int)out_row[k];
+                  gx[k] = px[v];
+                  gx[MK + k] = py[v];
+                  gx[2 * MK + k] = pz[v];
+                }
+              }
+            }
+            continue;
+          }
+          int cnt = __builtin_amdgcn_readlane(st_cnt, j);
+          if (cnt >= K) continue;  // finished in an earlier window
+          const int cnt0 = cnt;    // out_row[0 .. cnt0) left with the earlier windows
+          int first = __builtin_amdgcn_readlane(st_first, j);
+          float fx = bq_readlane_f(st_fx, j), fy = bq_readlane_f(st_fy, j),
+                fz = bq_readlane_f(st_fz, j);
+          for (int u0 = 0; u0 < nwin && cnt < K; u0 += 64 * BQ_UNROLL) {
+            float4 s[BQ_UNROLL];
+#pragma unroll
+            for (int u = 0; u < BQ_UNROLL; ++u)
+              if (u0 + 64 * u < nwin) s[u] = stage[min(u0 + 64 * u + lane, BQC_WIN - 1)];
+#pragma unroll
+            for (int u = 0; u < BQ_UNROLL; ++u) {
+              if (u0 + 64 * u < nwin && cnt < K) {
+                const bool hit = (u0 + 64 * u + lane < nwin) &&
+                                 dist2<FMAD>(cx, cy, cz, s[u].x, s[u].y, s[u].z) < r2;
+                const uint64_t mask = __ballot(hit);
+                if (mask != 0) {
+                  const int pos = cnt + mask_rank(mask);
+                  if (hit && pos < K) {
+                    orow[pos] = __float_as_int(s[u].w);
+                    if constexpr (GROUP) {
+                      ogx[pos] = s[u].x;
+                      ogx[Kp + pos] = s[u].y;
+                      ogx[2 * Kp + pos] = s[u].z;
+                    }
+                  }
+                  if (cnt == 0) {
+                    const int fl = __ffsll((unsigned long long)mask) - 1;
+                    first = __builtin_amdgcn_readlane(__float_as_int(s[u].w), fl);
+                    if constexpr (GROUP) {
+                      fx = bq_readlane_f(s[u].x, fl);
+                      fy = bq_readlane_f(s[u].y, fl);
+                      fz = bq_readlane_f(s[u].z, fl);
+                    }
+                  }
+                  cnt += __popcll(mask);
+                }
+              }
+            }
+          }
+          if (last_win || cnt >= K) {
+            if (cnt > K) cnt = K;
+            if (lane == j) st_cnt = K;
+            for (int k = cnt0 + lane; k < K; k += 64) {
+              out_row[k] = (IdxT)(k < cnt ? orow[k] : first);
+              if constexpr (GROUP) {
+                gx[k] = k < cnt ? ogx[k] : fx;
+                gx[MK + k] = k < cnt ? ogx[Kp + k] : fy;
+                gx[2 * MK + k] = k < cnt ? ogx[2 * Kp + k] : fz;
+              }
+            }
+            if (lane == 0) *out_cnt = (IdxT)cnt;
+          } else {
+            for (int k = cnt0 + lane; k < cnt; k += 64) {  // this window's hits
+              out_row[k] = (IdxT)orow[k];
+              if constexpr (GROUP) {
+                gx[k] = ogx[k];
+                gx[MK + k] = ogx[Kp + k];
+                gx[2 * MK + k] = ogx[2 * Kp + k];
+              }
+            }
+            if (lane == j) {
+              st_cnt = cnt;
+              st_first = first;
+              st_fx = fx;
+              st_fy = fy;
+              st_fz = fz;
+            }
+          }
+        }
+        if (!last_win &&
+            __syncthreads_and((int)__all(lane >= nmine || !lexact || st_cnt >= K)))
+          break;
+      }
+    }
+    __syncthreads();  // every rank lookup and staged read of this quad is done
+    for (int w = 0; w < wpt; w += 4)  // clean bitmap for the next quad
+      *reinterpret_cast<uint4*>(bm + t * wpt + w) = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
 int launch_grid_build(const float* xyz, int64_t B, int64_t N, float inv_h, GridWs ws,
                       hipStream_t st, bool write_aos) {
   hipLaunchKernelGGL(bq_grid_build_kernel, dim3(GR_RANGES, (unsigned)B), dim3(GR_BUILD_THREADS),
-                     0, st, xyz, (int)N, inv_h, ws, write_aos ? 1 : 0);
+                     0, st, xyz, (int)N, inv_h, ws, write_aos ? 1 : 0, (const float*)nullptr, 0,
+                     CellWs{nullptr, nullptr, nullptr});
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }
 
-enum { BQ_AUTO = 0, BQ_SCAN = 1, BQ_GRID = 2 };
+int launch_grid_build_queries(const float* xyz, const float* ctr, int64_t B, int64_t N,
+                              int64_t M, float inv_h, GridWs ws, CellWs cw, hipStream_t st,
+                              bool write_aos) {
+  hipLaunchKernelGGL(bq_grid_build_kernel, dim3(2 * GR_RANGES, (unsigned)B),
+                     dim3(GR_BUILD_THREADS), 0, st, xyz, (int)N, inv_h, ws, write_aos ? 1 : 0,
+                     ctr, (int)M, cw);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
 
-static int bq_mode() {  // S4G_BQ_MODE=scan|grid|auto (tuning / test knob, read per call)
+enum { BQ_AUTO = 0, BQ_SCAN = 1, BQ_GRID = 2, BQ_CELL = 3 };
+
+static int bq_mode() {  // S4G_BQ_MODE=scan|grid|cell|auto (tuning / test knob, read per call)
   const char* e = getenv("S4G_BQ_MODE");
   if (e && e[0] == 's') return BQ_SCAN;
   if (e && e[0] == 'g') return BQ_GRID;
+  if (e && e[0] == 'c') return BQ_CELL;
   return BQ_AUTO;
 }
 
@@ -391,13 +746,20 @@ static bool bq_use_grid(int64_t N, int64_t K) {
   if (N > GR_MAX_POINTS || K > 1024) return false;
   const int mode = bq_mode();
   if (mode == BQ_SCAN) return false;
-  if (mode == BQ_GRID) return true;
+  if (mode == BQ_GRID || mode == BQ_CELL) return true;
   return N >= 8192;
 }
 
+// centre-quad query instead of the per-centre one (needs the centres binned too).
+// OPT-IN (S4G_BQ_MODE=cell): exact, but as built it is slower than the per-centre
+// kernel (SA1, 16 scenes: 0.142 ms against 0.116 ms) -- see the CELL path's header.
+static bool bq_use_cell(int64_t M) {
+  return bq_mode() == BQ_CELL && M >= 1 && M < (1 << 24);
+}
+
 size_t ball_query_workspace_bytes(int64_t B, int64_t N, int64_t M, int64_t K) {
-  (void)M;
-  return bq_use_grid(N, K) ? grid_ws_bytes(B, N) : 0;
+  if (!bq_use_grid(N, K)) return 0;
+  return grid_ws_bytes(B, N) + (bq_use_cell(M) ? cell_ws_bytes(B, M) : 0);
 }
 
 template <typename IdxT>
@@ -435,10 +797,37 @@ static int ball_query_dispatch(const float* xyz, const float* ctr, int64_t B,
   const GridWs g = grid_ws_carve(ws, B, N);
   const float h = radius * (1.0f + 1.0f / 256.0f);
   const float inv_h = 1.0f / h;
-  if (int rc = launch_grid_build(xyz, B, N, inv_h, g, st, grouped != nullptr)) return rc;
   const int words = (int)((N + 31) / 32);
   int wpl = (words + 63) / 64;
   if ((wpl & 1) == 0) ++wpl;  // odd stride: conflict-free per-lane word runs
+  if (bq_use_cell(M) && ws_bytes >= grid_ws_bytes(B, N) + cell_ws_bytes(B, M)) {
+    const CellWs cw = cell_ws_carve((char*)ws + grid_ws_bytes(B, N), B, M);
+    if (int rc = launch_grid_build_queries(xyz, ctr, B, N, M, inv_h, g, cw, st, false)) return rc;
+    // workgroups per scene: a workgroup strides over the scene's non-empty centre quads
+    int64_t wps = 4096 / B;
+    if (const char* e = getenv("S4G_BQ_CELL_WGS")) wps = atoi(e);
+    if (wps < 32) wps = 32;
+    const int64_t max_quads = (M < GR_RANGES * GR_RANGE_SLOTS / 4) ? M : GR_RANGES * GR_RANGE_SLOTS / 4;
+    if (wps > max_quads) wps = max_quads;
+    const int per = 4 * BQC_THREADS;  // bitmap words: multiple of 4 per thread
+    const int bmw = (words + per - 1) / per * per;
+    const size_t clds = sizeof(uint32_t) * (size_t)(bmw + bmw / 2 + 4 * BQC_WIN + 8 +
+                                                    BQC_WAVES * (grouped ? 4 : 1) * ((K + 3) & ~3));
+    const dim3 cgrid((unsigned)wps, (unsigned)B);
+#define S4G_BQC_LAUNCH(F, G)                                                                 \
+  hipLaunchKernelGGL((bq_cell_query_kernel<F, IdxT, G>), cgrid, dim3(BQC_THREADS), clds, st, \
+                     xyz, (int)N, (int)M, r2, inv_h, (int)K, g, cw, idx, cnt, grouped, bmw,  \
+                     (int)wps)
+    if (grouped) {
+      if (fmad) S4G_BQC_LAUNCH(true, true); else S4G_BQC_LAUNCH(false, true);
+    } else {
+      if (fmad) S4G_BQC_LAUNCH(true, false); else S4G_BQC_LAUNCH(false, false);
+    }
+#undef S4G_BQC_LAUNCH
+    S4G_LAUNCH_CHECK();
+    return S4G_OK;
+  }
+  if (int rc = launch_grid_build(xyz, B, N, inv_h, g, st, grouped != nullptr)) return rc;
   const size_t lds = sizeof(uint32_t) * BQ_WAVES_PER_BLOCK * (size_t)(64 * wpl + ((K + 3) & ~3));
 #define S4G_BQ_LAUNCH4(F, G, W, C)                                                        \
   hipLaunchKernelGGL((bq_grid_query_kernel<F, IdxT, G, W, C>), qgrid, block, lds, st, xyz, \

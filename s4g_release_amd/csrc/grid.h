@@ -40,6 +40,31 @@ inline GridWs grid_ws_carve(void* ws, int64_t B, int64_t N) {
   return g;
 }
 
+// Queries (ball centres) binned into the same cells, for the cell-centric ball query:
+// a compact list of the non-empty x-quads (4 x-adjacent cells) per stripe, each with its
+// contiguous run of query records.
+struct CellWs {
+  float4* sorted;  // [B][GR_RANGES * M] records (x, y, z, query index bits)
+  int4* cells;     // [B][GR_RANGES][GR_RANGE_SLOTS] (first slot, first record, count, 0), compacted
+  int* ncell;      // [B][GR_RANGES] entries used in `cells`
+};
+
+inline size_t cell_ws_bytes(int64_t B, int64_t M) {
+  return (size_t)B * ((size_t)GR_RANGES * M * sizeof(float4) +
+                      (size_t)GR_RANGES * GR_RANGE_SLOTS * sizeof(int4) + 64);
+}
+
+inline CellWs cell_ws_carve(void* ws, int64_t B, int64_t M) {
+  CellWs c;
+  char* p = (char*)ws;
+  c.sorted = (float4*)p;
+  p += (size_t)B * GR_RANGES * M * sizeof(float4);
+  c.cells = (int4*)p;
+  p += (size_t)B * GR_RANGES * GR_RANGE_SLOTS * sizeof(int4);
+  c.ncell = (int*)p;
+  return c;
+}
+
 __device__ __forceinline__ int grid_coord(float v, float o, float inv_h) {
   return (int)floorf(__fmul_rn(__fsub_rn(v, o), inv_h));
 }
@@ -63,5 +88,10 @@ __device__ __forceinline__ int grid_slot(int cx, int cy, int cz) {
 // write_aos also fills ws.xyz4 (only the fused query+group epilogue reads it).
 int launch_grid_build(const float* xyz, int64_t B, int64_t N, float inv_h, GridWs ws,
                       hipStream_t st, bool write_aos = false);
+// Same launch, plus 8 more workgroups per scene that bin the M queries `ctr` (B,3,M)
+// into `cw` (cells relative to the same origin as the points').
+int launch_grid_build_queries(const float* xyz, const float* ctr, int64_t B, int64_t N,
+                              int64_t M, float inv_h, GridWs ws, CellWs cw, hipStream_t st,
+                              bool write_aos);
 
 }  // namespace s4g

@@ -53,6 +53,11 @@ def main():
             N, M = x.shape[2], c.shape[2]
             nb = B * (12 * N + 12 * M + 8 * M * 64 + 8 * M)
             print("%-28s B=%d  %9.3f ms   %.1f GB/s alg" % (name, B, ms, nb / ms / 1e6))
+    if "qgroup" in ops:
+        ms = timeit(lambda: F.query_and_group(pts, c1, 0.02, 64))
+        nb = B * (12 * 25600 + 12 * 5120 + 8 * 5120 * 64 + 8 * 5120) + \
+            B * (4 * 3 * 25600 + 8 * 5120 * 64 + 4 * 3 * 5120 * 64)
+        print("%-28s B=%d  %9.3f ms   %.1f GB/s alg" % ("query+group SA1 one pass", B, ms, nb / ms / 1e6))
     if "group" in ops:
         gi, _ = F.ball_query(pts, c1, 0.02, 64)
         ms = timeit(lambda: F.group_points(pts, gi))
