@@ -79,7 +79,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     _cabi.lib()   # no HIP library -> fail loudly, never a fallback
-    if world > 1:
+    # S4G_BENCH_FORCE_DIST=1: take the RCCL path (init, all-gather, barrier, max-reduce)
+    # even with one rank, so the multi-GPU code can be exercised on a 1-GPU box
+    use_dist = world > 1 or (os.environ.get("S4G_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
@@ -113,7 +116,7 @@ def main():
     pipelined = impl == "fused" and not args.no_pipeline
 
     def finish(pred):
-        if world > 1:
+        if use_dist:
             return sdist.all_gather_outputs(pred)   # one RCCL all-gather of (B,21,N)
         return pred
 
@@ -141,7 +144,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -152,13 +155,13 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     F.OpTimer.enabled = False
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -323,7 +326,7 @@ def main():
         "cpu_baseline": cpu_baseline,
     }
     print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

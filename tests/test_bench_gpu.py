@@ -35,3 +35,20 @@ def test_bench_prints_one_contract_line():
     assert c["kind"] == "port" and c["max_abs_err_gpu_vs_cpu"] < 1e-4
     p = d["roofline_ball_query_group_points"]
     assert p["bound"] == "hbm" and p["unit"] == "GB/s" and 0 < p["frac"] < 1
+
+
+def test_bench_under_torchrun_takes_the_rccl_path():
+    """The driver's N > 1 launch line with one rank: RCCL init, the per-batch all-gather,
+    barrier and max-reduce all run (S4G_BENCH_FORCE_DIST=1), and the line stays one."""
+    env = dict(os.environ, S4G_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
+                          "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
+                          "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert "all-gather" in d["config"]["parallelism"]
