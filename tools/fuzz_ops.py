@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Time-boxed randomized parity sweep of the geometry operators against the CPU oracle
+(bit-exact), at sizes around every dispatch threshold: FPS register / pruned / hybrid /
+streaming kernels, ball query scan / grid / cell, 3-NN scan / grid.  Not part of the test
+suite (needs minutes); usage on a GPU box:
+    python tools/fuzz_ops.py [--seconds 240] [--seed 0]
+Prints one line per case and exits non-zero at the first mismatch."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as O                      # noqa: E402  (checker only)
+from s4g_release_amd import functions as F, synth   # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(a.seed)
+    t0 = time.time()
+    case = 0
+    sizes = [511, 512, 513, 2559, 2560, 2561, 5120, 8191, 8192, 10239, 10240, 10241, 13333,
+             16384, 19999, 25599, 25600, 25601, 30011, 40000, 51200, 51201, 60000, 65536, 70001]
+    while time.time() - t0 < a.seconds:
+        case += 1
+        variant = ["tabletop-v1", "dup-heavy", "uniform-box"][int(rng.integers(3))]
+        N = int(rng.choice(sizes))
+        B = int(rng.integers(1, 3))
+        M = int(rng.integers(1, min(N, 3000) + 1))
+        K = int(rng.choice([1, 5, 16, 64, 65, 128]))
+        radius = float(rng.choice([0.005, 0.02, 0.05, 0.2, 1.5]))
+        fps_mode = str(rng.choice(["", "dense", "pruned"]))
+        bq_mode = str(rng.choice(["", "grid", "cell", "scan"]))
+        fmad = bool(rng.integers(4) == 0)
+        for k, v in (("S4G_FPS_MODE", fps_mode), ("S4G_BQ_MODE", bq_mode)):
+            if v:
+                os.environ[k] = v
+            else:
+                os.environ.pop(k, None)
+        pts = synth.make_batch([int(rng.integers(1 << 20)) for _ in range(B)], N, variant=variant)
+        if rng.integers(3) == 0:      # a few far-away / repeated points
+            pts[0, :, int(rng.integers(N))] += np.float32(rng.choice([3.0, 400.0]))
+            pts[0, :, int(rng.integers(N))] = pts[0, :, 0]
+        tag = "case %d %s B=%d N=%d M=%d K=%d r=%g fps=%s bq=%s fmad=%d" % (
+            case, variant, B, N, M, K, radius, fps_mode or "auto", bq_mode or "auto", fmad)
+        tp = torch.from_numpy(pts).to(dev)
+        F.set_distance_mode("fmad" if fmad else "strict")
+        try:
+            fps = F.farthest_point_sample(tp, M).cpu().numpy()
+            rfps = O.fps(pts, M, fmad=int(fmad))
+            assert np.array_equal(fps, rfps), "fps"
+            ctr = O.gather_points(pts, rfps)
+            idx, cnt = F.ball_query(tp, torch.from_numpy(ctr).to(dev), radius, K)
+            ridx, rcnt = O.ball_query(pts, ctr, radius, K, fmad=int(fmad))
+            assert np.array_equal(cnt.cpu().numpy(), rcnt), "ball_query count"
+            assert np.array_equal(idx.cpu().numpy(), ridx), "ball_query index"
+            i2, c2, g2 = F.query_and_group(tp, torch.from_numpy(ctr).to(dev), radius, K)
+            assert np.array_equal(i2.cpu().numpy(), ridx), "query_and_group index"
+            assert np.array_equal(g2.cpu().numpy(), O.group_points(pts, ridx)), "query_and_group xyz"
+            if M >= 3:
+                nidx, nd2 = F.search_nn_distance(tp, torch.from_numpy(ctr).to(dev), 3)
+                rn, rd = O.three_nn(pts, ctr, fmad=int(fmad))
+                assert np.array_equal(nidx.cpu().numpy(), rn), "three_nn index"
+                assert np.array_equal(nd2.cpu().numpy(), rd), "three_nn distance"
+        except AssertionError as e:
+            print("MISMATCH (%s): %s" % (e, tag))
+            sys.exit(1)
+        finally:
+            F.set_distance_mode("strict")
+        print("ok  " + tag, flush=True)
+    print("%d cases, no mismatch" % case)
+
+
+if __name__ == "__main__":
+    main()
