@@ -313,6 +313,26 @@ def test_three_interpolate_matches_oracle(F, oracle, dev, C, N2, N1):
     assert np.array_equal(out.cpu().numpy(), oracle.three_interpolate(feat, idx, rw))
 
 
+@pytest.mark.parametrize("mode", ["tile", "lane"])
+@pytest.mark.parametrize("C,N2,N1", [(4, 7, 63), (68, 300, 1001), (132, 50, 4098), (512, 1024, 5120)])
+def test_three_interpolate_channels_last_kernels(F, oracle, dev, monkeypatch, mode, C, N2, N1):
+    """Both channels-last forms (64 x 64 tile through LDS; lane per point), ragged tiles:
+    C not a multiple of the 64-channel slice, N1 not a multiple of 4 / 64; FMAD mode too."""
+    monkeypatch.setenv("S4G_INTERP_MODE", mode)
+    rng = np.random.default_rng(C + N1)
+    feat = rng.standard_normal((3, C, N2)).astype(np.float32)
+    idx = rng.integers(0, N2, size=(3, N1, 3))
+    w = rng.random((3, N1, 3), dtype=np.float32)
+    out = F.feature_interpolate(_t(feat, dev), _t(idx, dev), _t(w, dev))
+    assert np.array_equal(out.cpu().numpy(), oracle.three_interpolate(feat, idx, w))
+    try:
+        F.set_distance_mode("fmad")
+        out = F.feature_interpolate(_t(feat, dev), _t(idx, dev), _t(w, dev))
+    finally:
+        F.set_distance_mode("strict")
+    assert np.array_equal(out.cpu().numpy(), oracle.three_interpolate(feat, idx, w, fmad=1))
+
+
 def test_three_interpolate_backward(F, oracle, dev):
     rng = np.random.default_rng(4)
     feat = torch.from_numpy(rng.standard_normal((2, 6, 20)).astype(np.float32)).to(dev)
