@@ -93,6 +93,13 @@ int s4g_group_points_f32(const float *in_bcn, const int64_t *idx_bmk, int64_t B,
 int s4g_group_points_xyz_f32(const float *xyz_b3n, const int64_t *idx_bmk, int64_t B, int64_t N,
                              int64_t M, int64_t K, float *out_b3mk, void *ws, size_t ws_bytes,
                              s4g_stream_t stream);
+/* s4g_group_points_f32 through a channels-last copy of the features in `ws` (B * N * C
+ * floats): 64 channels of a neighbour are one 256-byte read and the channel-first rows
+ * leave as 16-byte stores.  Bit-identical output; without a (large enough, 16-byte
+ * aligned) workspace or with C % 4 != 0 it IS that call. */
+int s4g_group_points_ws_f32(const float *feat_bcn, const int64_t *idx_bmk, int64_t B, int64_t C,
+                            int64_t N, int64_t M, int64_t K, float *out_bcmk, void *ws,
+                            size_t ws_bytes, s4g_stream_t stream);
 int s4g_group_points_backward_f32(const float *gout_bcmk,
                                   const int64_t *idx_bmk, int64_t B, int64_t C,
                                   int64_t N, int64_t M, int64_t K,

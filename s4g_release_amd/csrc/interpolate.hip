@@ -201,6 +201,59 @@ __global__ __launch_bounds__(256) void three_interpolate_tile_kernel(
   }
 }
 
+// group_points as the same tile: out[b][c][j] = feat[b][c][idx[b][j]], j over M*K.  The
+// lane-per-output kernel in group.hip issues 64 four-byte gathers per wave instruction (64
+// cache lines: the L1 tag rate bounds it); here 16 lanes read one neighbour's 64 channels
+// as 256 contiguous bytes and the channel-first rows leave as 16-byte stores.
+__global__ __launch_bounds__(256) void group_points_tile_kernel(
+    const float* __restrict__ featT, const int64_t* __restrict__ idx, int C, int N, int64_t MK,
+    float* __restrict__ out, int tiles_x, int tiles_y, int nslices) {
+  __shared__ float tile[IPT_PTS * IPT_STRIDE];
+  const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+  const int slice = (kk / tiles_x) * 8 + xcd;
+  if (slice >= nslices) return;
+  const int b = slice / tiles_y;
+  const int64_t n0 = (int64_t)(kk % tiles_x) * IPT_PTS;
+  const int c0 = (slice % tiles_y) * IPT_CH;
+  const int t = threadIdx.x;
+  const int c4 = t % IPT_LPR, pr = t / IPT_LPR;
+  const float* __restrict__ base = featT + (size_t)b * N * C;
+  const bool cok = c0 + 4 * c4 < C;
+#pragma unroll
+  for (int i = 0; i < IPT_PTS / IPT_RPP; ++i) {
+    const int r = pr + IPT_RPP * i;
+    const int64_t n = n0 + r;
+    if (n < MK && cok) {
+      const int j = (int)idx[(size_t)b * MK + n];
+      const float4 a = *reinterpret_cast<const float4*>(base + (size_t)j * C + c0 + 4 * c4);
+      tile[r * IPT_STRIDE + 4 * c4 + 0] = a.x;
+      tile[r * IPT_STRIDE + 4 * c4 + 1] = a.y;
+      tile[r * IPT_STRIDE + 4 * c4 + 2] = a.z;
+      tile[r * IPT_STRIDE + 4 * c4 + 3] = a.w;
+    }
+  }
+  __syncthreads();
+  const int nq = t % IPT_NQ, cc = t / IPT_NQ;
+  const int64_t n = n0 + 4 * nq;
+  const bool vec = (MK & 3) == 0 && n + 3 < MK;
+#pragma unroll
+  for (int k = 0; k < IPT_CH / IPT_CPP; ++k) {
+    const int ch = cc + IPT_CPP * k;
+    if (c0 + ch >= C || n >= MK) continue;
+    float* __restrict__ dst = out + ((size_t)b * C + c0 + ch) * MK + n;
+    const float v0 = tile[(4 * nq + 0) * IPT_STRIDE + ch], v1 = tile[(4 * nq + 1) * IPT_STRIDE + ch],
+                v2 = tile[(4 * nq + 2) * IPT_STRIDE + ch], v3 = tile[(4 * nq + 3) * IPT_STRIDE + ch];
+    if (vec) {
+      *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
+    } else {
+      dst[0] = v0;
+      if (n + 1 < MK) dst[1] = v1;
+      if (n + 2 < MK) dst[2] = v2;
+      if (n + 3 < MK) dst[3] = v3;
+    }
+  }
+}
+
 __global__ __launch_bounds__(IP_THREADS) void three_interpolate_backward_kernel(
     const float* __restrict__ gout, const int64_t* __restrict__ idx,
     const float* __restrict__ w, int C, int N2, int N1,
@@ -317,6 +370,33 @@ extern "C" int s4g_three_interpolate_backward_f32(
   hipLaunchKernelGGL(s4g::three_interpolate_backward_kernel, grid,
                      dim3(s4g::IP_THREADS), 0, st, gout_bcn1, idx_bn3, w_bn3,
                      (int)C, (int)N2, (int)N1, gin_bcn2);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
+
+extern "C" int s4g_group_points_ws_f32(const float* feat_bcn, const int64_t* idx_bmk, int64_t B,
+                                       int64_t C, int64_t N, int64_t M, int64_t K, float* out_bcmk,
+                                       void* ws, size_t ws_bytes, s4g_stream_t stream) {
+  const int64_t MK = M * K;
+  const int64_t tiles_x = (MK + s4g::IPT_PTS - 1) / s4g::IPT_PTS;
+  const int64_t tiles_y = (C + s4g::IPT_CH - 1) / s4g::IPT_CH;
+  // anything the channels-last form does not cover is the plain call: same results
+  if (!ws || ws_bytes < (size_t)B * (size_t)N * (size_t)C * sizeof(float) || (C & 3) != 0 ||
+      ((uintptr_t)ws & 15) != 0 || ((uintptr_t)out_bcmk & 15) != 0 || B <= 0 || B > 65535 || C <= 0 ||
+      N <= 0 || N >= (1ll << 31) || MK <= 0 || (C + 31) / 32 > 65535 ||
+      (tiles_y * B + 7) / 8 * 8 * tiles_x >= (1ll << 31))
+    return s4g_group_points_f32(feat_bcn, idx_bmk, B, C, N, M, K, out_bcmk, stream);
+  if (!feat_bcn || !idx_bmk || !out_bcmk) return S4G_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  float* featT = (float*)ws;
+  hipLaunchKernelGGL(s4g::feat_to_channels_last_kernel,
+                     dim3((unsigned)((N + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B), dim3(256), 0,
+                     st, feat_bcn, (int)C, (int)N, featT);
+  S4G_LAUNCH_CHECK();
+  const int nslices = (int)(tiles_y * B);
+  const dim3 tgrid((unsigned)((nslices + 7) / 8 * 8) * (unsigned)tiles_x);
+  hipLaunchKernelGGL(s4g::group_points_tile_kernel, tgrid, dim3(256), 0, st, featT, idx_bmk, (int)C,
+                     (int)N, MK, out_bcmk, (int)tiles_x, (int)tiles_y, nslices);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }

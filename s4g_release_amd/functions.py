@@ -212,6 +212,15 @@ def _group_points_forward(points, index):
                 rc = _cabi.lib().s4g_group_points_xyz_f32(_ptr(points), _ptr(index), B, N, M, K,
                                                           _ptr(out), aos.data_ptr(), aos.numel() * 4,
                                                           _stream())
+        elif C % 4 == 0 and C >= 16 and B > 0 and M * K >= 4096:
+            # feature grouping: 64 channels of a neighbour are one 256-byte read of a
+            # channels-last copy, the channel-first rows leave through an LDS tile
+            cl = torch.empty((B * N, C), dtype=torch.float32, device=points.device)
+            with _timed("group_points[C=%d,N=%d,M=%d,K=%d]" % (C, N, M, K),
+                        B * (4 * C * N + 8 * M * K + 4 * C * M * K)):
+                rc = _cabi.lib().s4g_group_points_ws_f32(_ptr(points), _ptr(index), B, C, N, M, K,
+                                                         _ptr(out), cl.data_ptr(), cl.numel() * 4,
+                                                         _stream())
         else:
             with _timed("group_points[C=%d,N=%d,M=%d,K=%d]" % (C, N, M, K),
                         B * (4 * C * N + 8 * M * K + 4 * C * M * K)):

@@ -191,7 +191,8 @@ def test_ball_query_empty_balls_and_padding(F, oracle, dev):
 
 
 # ------------------------------------------------------------------ group / gather
-@pytest.mark.parametrize("C,N,M,K", [(3, 25600, 5120, 64), (256, 5120, 1024, 64), (5, 100, 7, 3)])
+@pytest.mark.parametrize("C,N,M,K", [(3, 25600, 5120, 64), (256, 5120, 1024, 64), (5, 100, 7, 3),
+                                     (68, 1000, 131, 33), (16, 300, 64, 64), (132, 77, 257, 16)])
 def test_group_points_matches_oracle(F, oracle, dev, C, N, M, K):
     rng = np.random.default_rng(C)
     feat = rng.standard_normal((2, C, N)).astype(np.float32)

@@ -63,6 +63,13 @@ def main():
         ms = timeit(lambda: F.group_points(pts, gi))
         nb = B * (4 * 3 * 25600 + 8 * 5120 * 64 + 4 * 3 * 5120 * 64)
         print("%-28s B=%d  %9.3f ms   %.1f GB/s alg" % ("group xyz SA1", B, ms, nb / ms / 1e6))
+    if "groupfeat" in ops:   # feature grouping of the reference-shaped modules path (SA2 / SA3 sizes)
+        for name, C, N, M, r, src, ctr in (("group feat SA2 C=256", 256, 5120, 1024, 0.08, c1, c2),):
+            gi, _ = F.ball_query(src, ctr, r, 64)
+            feat = torch.randn(B, C, N, device=dev)
+            ms = timeit(lambda: F.group_points(feat, gi))
+            nb = B * (4 * C * N + 8 * M * 64 + 4 * C * M * 64)
+            print("%-28s B=%d  %9.3f ms   %.1f GB/s alg" % (name, B, ms, nb / ms / 1e6))
     if "nn" in ops:
         for name, q, k in (("3nn 25600<-5120", pts, c1), ("3nn 5120<-1024", c1, c2)):
             ms = timeit(lambda: F.search_nn_distance(q, k, 3))
