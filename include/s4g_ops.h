@@ -281,8 +281,9 @@ int s4g_three_nn_weights_grid_i32(const float *q_b3n1, const float *k_b3n2, int6
                                   size_t ws_bytes, int flags, s4g_stream_t stream);
 
 /* s4g_three_nn_f32's outputs (int64 indices, squared distances) through the same grid:
- * for operator-API callers that can name a cell edge (functions.py derives one from the
- * keys' extent).  Same workspace; identical results for any cell. */
+ * for operator-API callers.  cell > 0: the caller names the cell edge; cell < 0: the call
+ * derives one on the device (1.75 x the mean third-neighbour distance of 64 sample keys,
+ * no host read).  Same workspace; identical results for any cell. */
 int s4g_three_nn_grid_f32(const float *q_b3n1, const float *k_b3n2, int64_t B, int64_t N1,
                           int64_t N2, float cell, int64_t *idx_bn3, float *d2_bn3, void *ws,
                           size_t ws_bytes, int flags, s4g_stream_t stream);

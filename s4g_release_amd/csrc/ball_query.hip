@@ -103,7 +103,8 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void ball_query_scan_kerne
 // (grid layout, slot mapping and workspace carving: grid.h)
 __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
     const float* __restrict__ xyz, int N, float inv_h, GridWs ws, int write_aos,
-    const float* __restrict__ ctr, int M, CellWs cw) {
+    const float* __restrict__ ctr, int M, CellWs cw, const float* __restrict__ inv_h_dev) {
+  if (inv_h_dev) inv_h = *inv_h_dev;  // cell edge chosen on the device (3-NN operator API)
   __shared__ uint32_t hist[GR_RANGE_SLOTS];
   __shared__ uint32_t wsum[GR_BUILD_THREADS / 64];
   __shared__ uint32_t wsum2[GR_BUILD_THREADS / 64];
@@ -714,10 +715,10 @@ __global__ __launch_bounds__(BQC_THREADS) void bq_cell_query_kernel(
 }
 
 int launch_grid_build(const float* xyz, int64_t B, int64_t N, float inv_h, GridWs ws,
-                      hipStream_t st, bool write_aos) {
+                      hipStream_t st, bool write_aos, const float* inv_h_dev) {
   hipLaunchKernelGGL(bq_grid_build_kernel, dim3(GR_RANGES, (unsigned)B), dim3(GR_BUILD_THREADS),
                      0, st, xyz, (int)N, inv_h, ws, write_aos ? 1 : 0, (const float*)nullptr, 0,
-                     CellWs{nullptr, nullptr, nullptr});
+                     CellWs{nullptr, nullptr, nullptr}, inv_h_dev);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }
@@ -727,7 +728,7 @@ int launch_grid_build_queries(const float* xyz, const float* ctr, int64_t B, int
                               bool write_aos) {
   hipLaunchKernelGGL(bq_grid_build_kernel, dim3(2 * GR_RANGES, (unsigned)B),
                      dim3(GR_BUILD_THREADS), 0, st, xyz, (int)N, inv_h, ws, write_aos ? 1 : 0,
-                     ctr, (int)M, cw);
+                     ctr, (int)M, cw, (const float*)nullptr);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }

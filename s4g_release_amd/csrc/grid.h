@@ -86,8 +86,9 @@ __device__ __forceinline__ int grid_slot(int cx, int cy, int cz) {
 
 // Builds the grid of `xyz` (B,3,N) with cell edge 1/inv_h into `ws` (one launch);
 // write_aos also fills ws.xyz4 (only the fused query+group epilogue reads it).
+// inv_h_dev (optional): the cell edge's reciprocal lives in device memory (replaces inv_h).
 int launch_grid_build(const float* xyz, int64_t B, int64_t N, float inv_h, GridWs ws,
-                      hipStream_t st, bool write_aos = false);
+                      hipStream_t st, bool write_aos = false, const float* inv_h_dev = nullptr);
 // Same launch, plus 8 more workgroups per scene that bin the M queries `ctr` (B,3,M)
 // into `cw` (cells relative to the same origin as the points').
 int launch_grid_build_queries(const float* xyz, const float* ctr, int64_t B, int64_t N,

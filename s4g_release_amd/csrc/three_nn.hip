@@ -14,6 +14,8 @@
 // runs when some lane of the wave needs it (wave-uniform branch).
 #include "grid.h"
 
+#include <stdlib.h>
+
 namespace s4g {
 
 constexpr int NN_THREADS = 256;
@@ -110,11 +112,85 @@ __device__ __forceinline__ void nn_write(IdxT* __restrict__ idx, float* __restri
   }
 }
 
+// Cell edge for the operator-API grid search, chosen on the device (no host read):
+// `factor` x the mean distance from a key to its third-nearest other key, measured on 64
+// sample keys spread over the batch (one wave per sample scans its scene's keys, lanes
+// keep their four smallest squared distances, four wave-min rounds merge them).  The
+// search cost grows with (cell / key spacing)^2..3 and every query whose third neighbour
+// is farther than one cell pays an O(N2) scan, so the spacing has to be measured: a
+// bounding-box estimate is off by 3x on surface-like clouds.  ANY value gives the same
+// results; out = (1 / cell, (cell (1 - 1e-3))^2), or (1, -1) = "accept nothing" when no
+// positive finite spacing comes out (all keys coincide, NaN / inf coordinates).
+constexpr int NN_SAMPLES = 64;
+
+__global__ __launch_bounds__(1024) void nn_auto_cell_kernel(const float* __restrict__ key, int B,
+                                                            int N2, float* __restrict__ out,
+                                                            float factor) {
+  __shared__ float d3s[NN_SAMPLES];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int s = wave; s < NN_SAMPLES; s += 16) {
+    const int b = s % B;
+    const int j = (int)(((unsigned long long)s * 2654435761ull + 12345ull) % (unsigned)N2);
+    const float* __restrict__ kx = key + (size_t)b * 3 * N2;
+    const float x = kx[j], y = kx[N2 + j], z = kx[2 * N2 + j];
+    float a0 = __builtin_inff(), a1 = a0, a2 = a0, a3 = a0;   // ascending
+    for (int i = lane; i < N2; i += 64) {
+      const float dx = kx[i] - x, dy = kx[N2 + i] - y, dz = kx[2 * N2 + i] - z;
+      const float d = dx * dx + dy * dy + dz * dz;
+      if (d < a3) {
+        a3 = d;
+        if (a3 < a2) { const float q = a2; a2 = a3; a3 = q; }
+        if (a2 < a1) { const float q = a1; a1 = a2; a2 = q; }
+        if (a1 < a0) { const float q = a0; a0 = a1; a1 = q; }
+      }
+    }
+    float kth = 0.f;   // 4th smallest over the wave = third-nearest OTHER key (self is 0)
+    for (int r = 0; r < 4; ++r) {
+      const float m = __uint_as_float(wave_min_u32(__float_as_uint(a0)));   // d >= 0: bit order = value order
+      kth = m;
+      const uint64_t own = __ballot(a0 == m);
+      if (lane == (int)(__ffsll((unsigned long long)own) - 1)) {
+        a0 = a1;
+        a1 = a2;
+        a2 = a3;
+        a3 = __builtin_inff();
+      }
+    }
+    if (lane == 0) d3s[s] = kth;
+  }
+  __syncthreads();
+  if (t == 0) {
+    float sum = 0.f;
+    int n = 0;
+    for (int s = 0; s < NN_SAMPLES; ++s) {
+      const float d = d3s[s];
+      if (d > 0.f && d < __builtin_inff()) {
+        sum += sqrtf(d);
+        ++n;
+      }
+    }
+    const float cell = n > 0 ? factor * sum / (float)n : 0.f;
+    if (!(cell > 0.f) || !(cell < 1e18f)) {
+      out[0] = 1.0f;
+      out[1] = -1.0f;
+    } else {
+      const float edge = cell * (1.0f - 1e-3f);
+      out[0] = 1.0f / cell;
+      out[1] = edge * edge;
+    }
+  }
+}
+
 template <bool FMAD, bool WEIGHTS, typename IdxT>
 __global__ __launch_bounds__(NN_THREADS) void three_nn_grid_kernel(
     const float* __restrict__ q, const float* __restrict__ key, int N1, int N2, float inv_h,
     float d2_done, GridWs ws, float eps, IdxT* __restrict__ idx, float* __restrict__ out,
-    int* __restrict__ fail_list, int* __restrict__ fail_count) {
+    int* __restrict__ fail_list, int* __restrict__ fail_count,
+    const float* __restrict__ cell_dev = nullptr) {
+  if (cell_dev) {  // (1 / cell, acceptance bound) chosen by nn_auto_cell_kernel
+    inv_h = cell_dev[0];
+    d2_done = cell_dev[1];
+  }
   const int b = blockIdx.y;
   const int i = blockIdx.x * NN_THREADS + threadIdx.x;
   if (i >= N1) return;
@@ -361,8 +437,9 @@ extern "C" int s4g_three_nn_grid_f32(const float* q_b3n1, const float* k_b3n2, i
                                      float* d2_bn3, void* ws, size_t ws_bytes, int flags,
                                      s4g_stream_t stream) {
   using namespace s4g;
+  const bool auto_cell = cell < 0.f;   // pick the cell edge on the device
   if (B < 0 || N1 < 0 || N2 < 3 || B > 65535 || N2 > GR_MAX_POINTS || N1 >= (1ll << 31) ||
-      !(cell > 0.f) || !(cell < 1e18f))
+      (!auto_cell && (!(cell > 0.f) || !(cell < 1e18f))))
     return S4G_EINVAL;
   if (B == 0 || N1 == 0) return S4G_OK;
   if (!q_b3n1 || !k_b3n2 || !idx_bn3 || !d2_bn3 || !ws) return S4G_EINVAL;
@@ -373,8 +450,16 @@ extern "C" int s4g_three_nn_grid_f32(const float* q_b3n1, const float* k_b3n2, i
   int* fail_list = fail_count + 16;
   hipError_t e = hipMemsetAsync(fail_count, 0, sizeof(int), st);
   if (e != hipSuccess) return (int)e;
+  float* cell_dev = nullptr;   // header words 4, 5 of the fail list
+  if (auto_cell) {
+    cell_dev = reinterpret_cast<float*>(fail_count + 4);
+    static const float factor = [] { const char* e = getenv("S4G_NN_CELL_FACTOR"); return e ? (float)atof(e) : 1.75f; }();
+    hipLaunchKernelGGL(nn_auto_cell_kernel, dim3(1), dim3(1024), 0, st, k_b3n2, (int)B, (int)N2, cell_dev, factor);
+    S4G_LAUNCH_CHECK();
+    cell = 1.0f;
+  }
   const float inv_h = 1.0f / cell;
-  if (int rc = launch_grid_build(k_b3n2, B, N2, inv_h, g, st)) return rc;
+  if (int rc = launch_grid_build(k_b3n2, B, N2, inv_h, g, st, false, cell_dev)) return rc;
   const float edge = cell * (1.0f - 1e-3f);
   const float d2_done = edge * edge;
   const dim3 grid((unsigned)((N1 + NN_THREADS - 1) / NN_THREADS), (unsigned)B);
@@ -382,11 +467,11 @@ extern "C" int s4g_three_nn_grid_f32(const float* q_b3n1, const float* k_b3n2, i
   if (fmad)
     hipLaunchKernelGGL((three_nn_grid_kernel<true, false, int64_t>), grid, dim3(NN_THREADS), 0, st,
                        q_b3n1, k_b3n2, (int)N1, (int)N2, inv_h, d2_done, g, 0.f, idx_bn3, d2_bn3,
-                       fail_list, fail_count);
+                       fail_list, fail_count, (const float*)cell_dev);
   else
     hipLaunchKernelGGL((three_nn_grid_kernel<false, false, int64_t>), grid, dim3(NN_THREADS), 0, st,
                        q_b3n1, k_b3n2, (int)N1, (int)N2, inv_h, d2_done, g, 0.f, idx_bn3, d2_bn3,
-                       fail_list, fail_count);
+                       fail_list, fail_count, (const float*)cell_dev);
   S4G_LAUNCH_CHECK();
   if (fmad)
     hipLaunchKernelGGL((three_nn_fallback_kernel<true, false, int64_t>), dim3(512), dim3(NN_THREADS),

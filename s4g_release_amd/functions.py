@@ -262,10 +262,11 @@ def _point_search(query_xyz, key_xyz, num_neighbours):
     index = torch.empty((B, N1, 3), dtype=torch.int64, device=query_xyz.device)
     dist = torch.empty((B, N1, 3), dtype=torch.float32, device=query_xyz.device)
     nbytes_alg = B * (12 * N2 + 12 * N1 + 24 * N1 + 12 * N1)
-    cell = _nn_cell(key_xyz) if (2048 <= N2 <= 65536 and B * N1 > 0 and
-                                 os.environ.get("S4G_NN_MODE", "grid") != "scan") else 0.0
+    use_grid = (2048 <= N2 <= 65536 and B * N1 > 0 and
+                os.environ.get("S4G_NN_MODE", "grid") != "scan")
+    cell = -1.0   # the library derives the cell edge from the keys' extent on the device
     with torch.cuda.device(query_xyz.device):
-        if cell > 0.0:
+        if use_grid:
             # keys binned into a cell grid, 27 cells per query, index-order scan for the
             # queries it cannot answer: same indices and distances as the scan, whatever the cell
             nbytes = _cabi.lib().s4g_three_nn_grid_workspace_bytes(B, N1, N2)
@@ -281,25 +282,6 @@ def _point_search(query_xyz, key_xyz, num_neighbours):
                                                   _stream())
     _cabi.check(rc, "point_search")
     return index, dist
-
-
-def _nn_cell(key_xyz):
-    """Cell edge for the grid 3-NN of the operator API (any value gives the same result,
-    this one keeps ~30-130 candidates per query): 1.5 x the larger of the key spacing of
-    a surface-like cloud (sqrt(largest face area / N2)) and of a volume-filling one
-    (cbrt(volume / N2)).  One host read of six floats per call."""
-    lo = key_xyz.amin(dim=(0, 2))
-    hi = key_xyz.amax(dim=(0, 2))
-    ext = (hi - lo).double().cpu()
-    n2 = key_xyz.size(2)
-    if not bool(torch.isfinite(ext).all()):
-        return 0.0
-    ex, ey, ez = [float(v) for v in ext]
-    area = max(ex * ey, ex * ez, ey * ez)
-    s2d = (area / n2) ** 0.5
-    s3d = (ex * ey * ez / n2) ** (1.0 / 3.0)
-    cell = 1.5 * max(s2d, s3d)
-    return cell if 0.0 < cell < 1e18 else 0.0
 
 
 def _interpolate_forward(feature, index, weight):
