@@ -61,9 +61,9 @@ def all_gather_outputs(pred, group=None):
     Every rank passes its local dict (B_local, C, N); every rank receives the
     dict for all world*B_local scenes in rank order.  One collective."""
     packed, chans = pack_outputs(pred)
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return unpack_outputs(packed, chans)
+    world = dist.get_world_size(group)   # a 1-rank group still takes the collective
     gathered = torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]),
                            dtype=packed.dtype, device=packed.device)
     dist.all_gather_into_tensor(gathered, packed, group=group)
