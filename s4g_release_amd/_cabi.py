@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libs4g_hip.so")
 
-S4G_ABI_VERSION = 2
+S4G_ABI_VERSION = 3
 S4G_FLAG_FMAD = 1
 S4G_OP_FPS, S4G_OP_BALL_QUERY, S4G_OP_THREE_NN = 1, 2, 3
 
@@ -39,6 +39,7 @@ class GemmDesc(ctypes.Structure):
         ("precision", _i32), ("Kpad16", _i32), ("W_bf16x3", _vp), ("mlp1_w", _vp),
         ("W_f16x2", _vp), ("w_inv_scale", _vp), ("a_amax", _vp), ("a_amax2", _vp),
         ("a_amax_floor", _f32), ("out_amax", _vp), ("W_f16x2_frag", _vp),
+        ("W2_f16x2_frag", _vp), ("w2_inv_scale", _vp), ("bias2", _vp), ("Cout2", _i32), ("relu2", _i32),
     ]
 
 

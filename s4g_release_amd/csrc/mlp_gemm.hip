@@ -96,6 +96,11 @@ struct GemmParams {
   float a_amax_floor;
   uint32_t* out_amax;          // 64 slots or NULL
   const uint16_t* Wfrag;       // f16x2 planes in MFMA-fragment order (resident-A kernel) or NULL
+  // fused second layer (mlp_gemm_f16x2_fused2_kernel): out = max_K relu(bn(W2 relu(bn(W A))))
+  const uint16_t* Wfrag2;
+  const float* w_inv_scale2;
+  const float* bias2;
+  int Cout2, relu2;
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -1167,6 +1172,266 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
     }
 }
 
+// ---------------------------------------------------------------------------
+// f16x2, two fused layers (the last two layers of an SA level whose widths allow it:
+// K = 128 -> 128 -> Cout2, max over the 64 neighbours): the resident-A kernel run twice
+// on ONE LDS panel.  A workgroup owns 128 positions (two centroids).  Phase 1 contracts
+// the loader's panel with W (operands swapped: a lane ends up with 4 consecutive channels
+// of one position), applies scale / bias / ReLU, finds the TILE maximum (one barrier --
+// which is also the point where nobody reads the old panel any more), splits the
+// activations with the tile's own power-of-two scale and writes them over the panel.
+// Phase 2 is the resident kernel's strip loop on that panel with the max epilogue.  The
+// 128-channel intermediate never leaves the CU: no 2.7 GB store + load + re-split, no
+// amax round trip through HBM (a per-tile scale is as exact as the per-tensor one: both
+// are powers of two undone in the epilogue).
+// ---------------------------------------------------------------------------
+template <int LOADER>
+__global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const GemmParams p) {
+  constexpr int CW = 2, BM = 128, K = 128;
+  constexpr int RPT = BM / 32, RS = 32;
+  constexpr int astr = K + 8, aplane = BM * astr, KS = K >> 4;
+  extern __shared__ __attribute__((aligned(16))) float smemf[];
+  uint16_t* Ah = reinterpret_cast<uint16_t*>(smemf);   // [2][BM][K + 8]
+  float* scr = reinterpret_cast<float*>(Ah + 2 * aplane);   // [4 waves][128] scale | bias, then 4 tile maxima
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int p0 = blockIdx.x * BM;
+
+  float amax = p.a_amax_floor;
+  if (p.a_amax) amax = fmaxf(amax, amax_slots(p.a_amax, lane));
+  if (p.a_amax2) amax = fmaxf(amax, amax_slots(p.a_amax2, lane));
+  uint32_t ex = __float_as_uint(amax) >> 23;
+  ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
+  ex = __builtin_amdgcn_readfirstlane(ex);
+  const float sa = __uint_as_float((268u - ex) << 23);
+  const float inv_sa = __uint_as_float((ex - 14u) << 23);
+
+  const int wr = wave / CW, wc = wave % CW;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wc_u = __builtin_amdgcn_readfirstlane(wc);
+  const uint32_t wf_lane = (uint32_t)lane * 16u;
+  constexpr size_t cb_stride = (size_t)KS * 2048;               // bytes between n32 and n32 + 1
+  constexpr size_t strip_stride = (size_t)CW * 2 * cb_stride;   // bytes between 128-channel strips
+  const char* __restrict__ w1 = reinterpret_cast<const char*>(p.Wfrag) + (size_t)(wc_u * 2) * cb_stride;
+  const char* __restrict__ w2 = reinterpret_cast<const char*>(p.Wfrag2) + (size_t)(wc_u * 2) * cb_stride;
+  const int nstrip2 = p.Cout2 / (64 * CW);
+
+  uint4 ring[GR_RING][2][2];
+#pragma unroll
+  for (int d = 0; d < GR_RING; ++d)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        ring[d][cb][pl] = *reinterpret_cast<const uint4*>(
+            w1 + ((size_t)cb * cb_stride + (size_t)(d * 2 + pl) * 1024) + wf_lane);
+
+  {  // prologue: the loader's panel -> two fp16 planes in LDS
+    ALoader<LOADER, RPT, RS> ld;
+    ld.init(p, p0, 0, t);
+    const int chunk = t & 7, srow = t >> 3;
+    constexpr int NKT = K / 32;
+    float4 ra[NKT][RPT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int s = 0; s < RPT; ++s) ra[kt][s] = ld.load(p, s, kt * 32 + chunk * 4, t);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int s = 0; s < RPT; ++s) {
+        uint2 h, l;
+        split2_h<false>(ra[kt][s], sa, h, l);
+        uint16_t* dst = Ah + (srow + RS * s) * astr + kt * 32 + chunk * 4;
+        *reinterpret_cast<uint2*>(dst) = h;
+        *reinterpret_cast<uint2*>(dst + aplane) = l;
+      }
+  }
+  __syncthreads();
+
+  const uint16_t* a_lane = Ah + (wr * 64 + li) * astr + 8 * lh;
+  float* epi_s = scr + wave * 128;
+  f32x16 acc[2][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  f16x8 afn[2][2];
+  auto prime_a = [&]() {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        afn[rb][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(
+            a_lane + pl * aplane + rb * 32 * astr));
+  };
+
+  // one 128-deep strip: 8 steps of 12 MFMAs; W fragments through the ring, refilled RING
+  // steps ahead from this strip (wcur) or the next one (wnext)
+#define S4G_F2_STRIP(SWAPPED, wcur, wnext)                                                             \
+  _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                  \
+    const int d = ks % GR_RING;                                                                        \
+    const int ksn = ks + 1 == KS ? 0 : ks + 1;                                                         \
+    f16x8 af[2][2], bf[2][2];                                                                          \
+    _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) { \
+      af[rb][pl] = afn[rb][pl];                                                                        \
+      afn[rb][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(                         \
+          a_lane + pl * aplane + rb * 32 * astr + ksn * 16));                                          \
+    }                                                                                                  \
+    _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)   \
+      bf[cb][pl] = __builtin_bit_cast(f16x8, ring[d][cb][pl]);                                         \
+    {                                                                                                  \
+      const int kr = ks + GR_RING;                                                                     \
+      const char* src = kr < KS ? (wcur) : (wnext);                                                    \
+      const int kk = kr < KS ? kr : kr - KS;                                                           \
+      _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) \
+        ring[d][cb][pl] = *reinterpret_cast<const uint4*>(                                             \
+            src + ((size_t)cb * cb_stride + (size_t)(kk * 2 + pl) * 1024) + wf_lane);                  \
+    }                                                                                                  \
+    S4G_F2_TERM(SWAPPED, 0, 1)                                                                         \
+    S4G_F2_TERM(SWAPPED, 1, 0)                                                                         \
+    S4G_F2_TERM(SWAPPED, 0, 0)                                                                         \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                    \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                               \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                               \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                               \
+    }                                                                                                  \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+  }
+#define S4G_F2_TERM(SWAPPED, PA, PB)                                                                   \
+  if constexpr (SWAPPED) {                                                                             \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0][PB], af[0][PA], acc[0][0], 0, 0, 0);      \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0][PB], af[1][PA], acc[0][1], 0, 0, 0);      \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[1][PB], af[0][PA], acc[1][0], 0, 0, 0);      \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[1][PB], af[1][PA], acc[1][1], 0, 0, 0);      \
+  } else {                                                                                             \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][PA], bf[0][PB], acc[0][0], 0, 0, 0);      \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][PA], bf[1][PB], acc[0][1], 0, 0, 0);      \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][PA], bf[0][PB], acc[1][0], 0, 0, 0);      \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][PA], bf[1][PB], acc[1][1], 0, 0, 0);      \
+  }
+
+  // ---- phase 1: H = relu(bn(W A)), 128 channels = one strip, operands swapped
+  zero_acc();
+  prime_a();
+  {
+    const int n = wc * 64 + lane;   // channel whose scale / bias this lane stages for its wave
+    epi_s[lane] = inv_sa * p.w_inv_scale[n];
+    epi_s[64 + lane] = p.bias[n];
+  }
+  S4G_F2_STRIP(true, w1, w2)
+  float tmax = 0.f;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 sc4 = *reinterpret_cast<const float4*>(epi_s + nb * 32 + 8 * j + 4 * lh);
+      const float4 b4 = *reinterpret_cast<const float4*>(epi_s + 64 + nb * 32 + 8 * j + 4 * lh);
+      const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+      const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = __fmaf_rn(acc[nb][pb][4 * j + e], scv[e], bv[e]);
+          if (p.relu) x = fmaxf(x, 0.f);
+          acc[nb][pb][4 * j + e] = x;
+          tmax = fmaxf(tmax, fabsf(x));
+        }
+    }
+  {
+    const uint32_t wm = wave_max_u32(__float_as_uint(tmax));
+    if (lane == 0) scr[512 + wave] = __uint_as_float(wm);
+  }
+  __syncthreads();   // every wave is done with the old panel; the four maxima are visible
+  float hmax = fmaxf(fmaxf(scr[512], scr[513]), fmaxf(scr[514], scr[515]));
+  uint32_t exh = __float_as_uint(hmax) >> 23;
+  exh = exh < 15u ? 15u : (exh > 240u ? 240u : exh);
+  exh = __builtin_amdgcn_readfirstlane(exh);
+  const float sh = __uint_as_float((268u - exh) << 23);
+  const float inv_sh = __uint_as_float((exh - 14u) << 23);
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        const float4 v = make_float4(acc[nb][pb][4 * j], acc[nb][pb][4 * j + 1], acc[nb][pb][4 * j + 2],
+                                     acc[nb][pb][4 * j + 3]);
+        uint2 h, l;
+        split2_h<false>(v, sh, h, l);
+        uint16_t* dst = Ah + (wr * 64 + pb * 32 + li) * astr + wc * 64 + nb * 32 + 8 * j + 4 * lh;
+        *reinterpret_cast<uint2*>(dst) = h;
+        *reinterpret_cast<uint2*>(dst + aplane) = l;
+      }
+  __syncthreads();
+
+  // ---- phase 2: the strip loop on the new panel, max over the 64 rows of a centroid
+  GemmParams q = p;
+  q.Cout = p.Cout2;
+  q.relu = p.relu2;
+  zero_acc();
+  prime_a();
+  const char* wstrip = w2;
+  for (int strip = 0; strip < nstrip2; ++strip, wstrip += strip_stride) {
+    const int n = (strip * CW + wc) * 64 + lane;
+    const float e_sc = inv_sh * p.w_inv_scale2[n];
+    const float e_bias = p.bias2[n];
+    const char* wnext = strip + 1 < nstrip2 ? wstrip + strip_stride : wstrip;
+    S4G_F2_STRIP(false, wstrip, wnext)
+    const int n0 = (strip * CW + wc) * 64;
+    float omax = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const float sc = __shfl(e_sc, cb * 32 + li);
+      const float bias = __shfl(e_bias, cb * 32 + li);
+      float mx = -__builtin_inff(), mn = __builtin_inff();
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[rb][cb][r] * sc;
+          acc[rb][cb][r] = v;
+          mx = fmaxf(mx, v);
+          mn = fminf(mn, v);
+        }
+      const float hi = mx + bias, lo = mn + bias;
+      omax = fmaxf(omax, q.relu ? hi : fmaxf(fabsf(hi), fabsf(lo)));
+    }
+    if (p.out_amax) {
+      const uint32_t wm = wave_max_u32(__float_as_uint(fmaxf(omax, 0.f)));
+      if (lane == 0) atomicMax(p.out_amax + ((blockIdx.x * 4 + wave + strip) & 63), wm);
+    }
+    gemm_epilogue<EPI_MAX, 2>(q, acc, p.bias2, 0, p0, n0, wave, wr, 0, li, lh, smemf);
+    zero_acc();
+  }
+#undef S4G_F2_STRIP
+#undef S4G_F2_TERM
+}
+
+template <int LOADER>
+static int launch_gemm_f16x2_fused2(const GemmParams& p, hipStream_t st) {
+  constexpr int BM = 128, K = 128;
+  constexpr size_t lds = sizeof(uint16_t) * 2 * BM * (size_t)(K + 8) + sizeof(float) * (4 * 128 + 16);
+  static_assert(lds <= 80 * 1024, "two workgroups per CU");
+  static const hipError_t attr = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&mlp_gemm_f16x2_fused2_kernel<LOADER>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr != hipSuccess) return (int)attr;
+  const dim3 grid((unsigned)((p.P + BM - 1) / BM));
+  hipLaunchKernelGGL((mlp_gemm_f16x2_fused2_kernel<LOADER>), grid, dim3(256), lds, st, p);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
+
 template <int LOADER, int EPI, int RW, int KT>
 static int launch_gemm_f16x2_resident(const GemmParams& p, int groups, hipStream_t st) {
   constexpr int BM = 64 * RW;
@@ -1294,6 +1559,11 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   p.a_amax = d->a_amax; p.a_amax2 = d->a_amax2; p.a_amax_floor = d->a_amax_floor;
   p.out_amax = (uint32_t*)d->out_amax;
   p.Wfrag = (const uint16_t*)d->W_f16x2_frag;
+  p.Wfrag2 = (const uint16_t*)d->W2_f16x2_frag;
+  p.w_inv_scale2 = d->w2_inv_scale;
+  p.bias2 = d->bias2;
+  p.Cout2 = d->Cout2;
+  p.relu2 = d->relu2;
   p.mtiles = (d->P + GM_BM - 1) / GM_BM;
   p.ntiles = (d->Cout + GM_BN - 1) / GM_BN;
   hipStream_t st = (hipStream_t)stream;
@@ -1326,6 +1596,16 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
     return S4G_EINVAL;
   }
 
+  if (d->W2_f16x2_frag) {
+    // two fused layers: K = 128 -> 128 -> Cout2 with the max over 64 neighbours
+    if (!h2 || d->epilogue != S4G_GEMM_EPI_MAX || d->K != 64 || d->Kpad16 != 128 || d->Cout != 128 ||
+        d->Cout2 <= 0 || (d->Cout2 & 127) || d->groups != 1 || !d->W_f16x2_frag || !d->w2_inv_scale ||
+        !d->bias2 || (d->P & 63))
+      return S4G_EINVAL;
+    if (d->loader == S4G_GEMM_LOAD_GATHER_MLP1) return launch_gemm_f16x2_fused2<LOAD_GATHER_MLP1>(p, st);
+    if (d->loader == S4G_GEMM_LOAD_PLAIN) return launch_gemm_f16x2_fused2<LOAD_PLAIN>(p, st);
+    return S4G_EUNSUPPORTED;
+  }
 #define S4G_GEMM_CASE(L, E)                                            \
   if (d->loader == L && d->epilogue == E)                              \
     return h2 ? launch_gemm_f16x2<L, E>(p, d->groups, st)              \

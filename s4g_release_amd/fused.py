@@ -139,6 +139,8 @@ class FusedPointNet2:
             raise ValueError("precision must be 'f16x2', 'bf16x3', 'fp32' or 'bf16'")
         self.precision = precision
         self.dense_streams = max(1, int(os.environ.get("S4G_DENSE_STREAMS", "1")))
+        # S4G_GEMM_FUSE2=0: never fuse the last two layers of an SA level into one launch
+        self.fuse2 = os.environ.get("S4G_GEMM_FUSE2", "1") != "0"
         self.geo_streams = max(1, int(os.environ.get("S4G_GEO_STREAMS", "2")))
         p = next(net.parameters())
         if not p.is_cuda:
@@ -214,7 +216,7 @@ class FusedPointNet2:
         self._streams = None
 
     # ------------------------------------------------------------------ launches
-    def _gemm(self, name, layer, P, loader, epi, relu=True, **kw):
+    def _gemm(self, name, layer, P, loader, epi, relu=True, layer2=None, **kw):
         d = GemmDesc()
         d.loader, d.epilogue, d.groups, d.relu = loader, epi, layer.groups, int(relu)
         d.P, d.Cin, d.Kpad, d.Cout = P, layer.cin, layer.kpad, layer.cout
@@ -231,6 +233,12 @@ class FusedPointNet2:
             if v is not None:
                 setattr(d, k, v)
         flops = 2.0 * P * layer.cout * layer.cin * layer.groups
+        if layer2 is not None:   # second layer fused behind this one (intermediate stays in LDS)
+            d.W2_f16x2_frag = layer2.Wfrag.data_ptr()
+            d.w2_inv_scale, d.bias2 = layer2.w_inv_scale.data_ptr(), layer2.bias.data_ptr()
+            d.Cout2, d.relu2 = layer2.cout, 1
+            flops += 2.0 * P * layer2.cout * layer2.cin
+            name = "%s+%s" % (name, name[:-1] + str(int(name[-1]) + 1))
         with _F._timed("gemm[%s P=%d K=%d N=%dx%d]" % (name, P, layer.cin, layer.groups, layer.cout),
                        0, flops):
             rc = _cabi.lib().s4g_mlp_gemm_f32(ctypes.byref(d), _F._stream())
@@ -337,14 +345,25 @@ class FusedPointNet2:
             P = B * M * K
             layers = sa["layers"]
             x = x_amax = None
+            # the last two layers as ONE launch (K = 128 -> 128 -> Cout2, intermediate in LDS);
+            # the first of the pair then reads through the MLP1 or the plain loader
+            fuse2 = (self.precision == "f16x2" and self.fuse2 and K == 64 and
+                     layers[-2].kpad16 == 128 and layers[-2].cout == 128 and
+                     layers[-1].cin == 128 and layers[-1].kpad16 == 128 and
+                     layers[-1].cout % 128 == 0 and layers[-2].Wfrag is not None and
+                     layers[-1].Wfrag is not None and len(layers) >= 3)
             for l, layer in enumerate(layers):
                 if l == 0 and sa["mlp1"] is not None:
                     continue                      # folded into layer 1's loader
-                last = l == len(layers) - 1
+                if fuse2 and l == len(layers) - 1:
+                    continue                      # fused behind the previous layer's launch
+                last = l == len(layers) - 1 or (fuse2 and l == len(layers) - 2)
                 nrow = B * M if last else P
-                out = torch.empty((nrow, layer.cout), dtype=torch.float32, device=dev)
+                l2 = layers[-1] if (fuse2 and l == len(layers) - 2) else None
+                cout = l2.cout if l2 is not None else layer.cout
+                out = torch.empty((nrow, cout), dtype=torch.float32, device=dev)
                 out_amax = next(rows)
-                kw = dict(out=out, ldc=layer.cout, K=K, out_amax=out_amax)
+                kw = dict(out=out, ldc=cout, K=K, out_amax=out_amax, layer2=l2)
                 if l == 1 and sa["mlp1"] is not None:
                     kw.update(gidx=gidx, xyz=level_xyz[li], ctr=ctr, N=level_n[li], M=M,
                               mlp1_w=sa["mlp1"], a_amax_floor=sa["mlp1_bound"])
