@@ -252,12 +252,13 @@ typedef struct s4g_gemm_desc {
    * fits LDS) use the resident-A kernel, which streams W fragments straight into
    * the matrix-core operand registers. */
   const void *W_f16x2_frag;
-  /* ABI >= 3, optional: a SECOND layer fused behind this one (S4G_GEMM_F16X2, epilogue MAX,
-   * K == 64, Kpad16 == 128, Cout == 128, groups == 1, loader PLAIN or GATHER_MLP1): the
-   * launch computes out = max_K relu2(bias2 + W2 . relu(bias + W . A)) with the 128-channel
-   * intermediate kept in LDS (split with a per-tile power-of-two scale).  W2_f16x2_frag /
-   * w2_inv_scale / bias2 describe W2 (Cout2 x 128, Cout2 % 128 == 0) like W_f16x2_frag /
-   * w_inv_scale / bias describe W; out, ldc, c_coff, out_amax refer to the pooled output. */
+  /* ABI >= 3, optional: a SECOND layer fused behind this one (S4G_GEMM_F16X2, groups == 1,
+   * loader PLAIN or GATHER_MLP1, Kpad16 == Cout == C with C = 128 or 256, Cout2 % C == 0;
+   * epilogue MAX with K == 64, or STORE): the launch computes
+   *   out = epilogue(relu2(bias2 + W2 . relu(bias + W . A)))
+   * with the C-channel intermediate kept in LDS (split with a per-tile power-of-two scale).
+   * W2_f16x2_frag / w2_inv_scale / bias2 describe W2 (Cout2 x C) like W_f16x2_frag /
+   * w_inv_scale / bias describe W; out, ldc, c_coff, out_amax refer to the final output. */
   const void *W2_f16x2_frag;
   const float *w2_inv_scale;
   const float *bias2;

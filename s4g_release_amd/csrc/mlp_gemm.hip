@@ -1185,14 +1185,16 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
 // amax round trip through HBM (a per-tile scale is as exact as the per-tensor one: both
 // are powers of two undone in the epilogue).
 // ---------------------------------------------------------------------------
-template <int LOADER>
+template <int LOADER, int EPI2, int RW>
 __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const GemmParams p) {
-  constexpr int CW = 2, BM = 128, K = 128;
+  // RW = 2: 128 positions, 128-wide layers; RW = 1: 64 positions, 256-wide layers
+  constexpr int CW = 4 / RW, BM = 64 * RW, K = 64 * CW;
   constexpr int RPT = BM / 32, RS = 32;
   constexpr int astr = K + 8, aplane = BM * astr, KS = K >> 4;
   extern __shared__ __attribute__((aligned(16))) float smemf[];
   uint16_t* Ah = reinterpret_cast<uint16_t*>(smemf);   // [2][BM][K + 8]
   float* scr = reinterpret_cast<float*>(Ah + 2 * aplane);   // [4 waves][128] scale | bias, then 4 tile maxima
+  const int g = 0;
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -1386,48 +1388,83 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
     const float e_sc = inv_sh * p.w_inv_scale2[n];
     const float e_bias = p.bias2[n];
     const char* wnext = strip + 1 < nstrip2 ? wstrip + strip_stride : wstrip;
-    S4G_F2_STRIP(false, wstrip, wnext)
+    S4G_F2_STRIP(EPI2 == EPI_STORE, wstrip, wnext)
     const int n0 = (strip * CW + wc) * 64;
     float omax = 0.f;
+    if constexpr (EPI2 == EPI_STORE) {
+      // operands swapped: registers 4 j .. 4 j + 3 = channels n0 + 32 nb + 8 j + 4 lh + (0..3)
+      epi_s[lane] = e_sc;
+      epi_s[64 + lane] = e_bias;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      const float sc = __shfl(e_sc, cb * 32 + li);
-      const float bias = __shfl(e_bias, cb * 32 + li);
-      float mx = -__builtin_inff(), mn = __builtin_inff();
+      for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
+        for (int j = 0; j < 4; ++j) {
+          const int nn = n0 + nb * 32 + 8 * j + 4 * lh;
+          const float4 sc4 = *reinterpret_cast<const float4*>(epi_s + nb * 32 + 8 * j + 4 * lh);
+          const float4 b4 = *reinterpret_cast<const float4*>(epi_s + 64 + nb * 32 + 8 * j + 4 * lh);
+          const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+          const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = acc[rb][cb][r] * sc;
-          acc[rb][cb][r] = v;
-          mx = fmaxf(mx, v);
-          mn = fminf(mn, v);
+          for (int pb = 0; pb < 2; ++pb) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x = __fmaf_rn(acc[nb][pb][4 * j + e], scv[e], bv[e]);
+              if (q.relu) x = fmaxf(x, 0.f);
+              v[e] = x;
+              omax = fmaxf(omax, fabsf(x));
+            }
+            const int row = p0 + wr * 64 + pb * 32 + li;
+            if (row < p.P)
+              *reinterpret_cast<float4*>(p.out + (size_t)row * p.ldc + p.c_coff + nn) =
+                  make_float4(v[0], v[1], v[2], v[3]);
+          }
         }
-      const float hi = mx + bias, lo = mn + bias;
-      omax = fmaxf(omax, q.relu ? hi : fmaxf(fabsf(hi), fabsf(lo)));
+      if (p.out_amax) {
+        const uint32_t wm = wave_max_u32(__float_as_uint(omax));
+        if (lane == 0) atomicMax(p.out_amax + ((blockIdx.x * 4 + wave + strip) & 63), wm);
+      }
+    } else {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const float sc = __shfl(e_sc, cb * 32 + li);
+        const float bias = __shfl(e_bias, cb * 32 + li);
+        float mx = -__builtin_inff(), mn = __builtin_inff();
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[rb][cb][r] * sc;
+            acc[rb][cb][r] = v;
+            mx = fmaxf(mx, v);
+            mn = fminf(mn, v);
+          }
+        const float hi = mx + bias, lo = mn + bias;
+        omax = fmaxf(omax, q.relu ? hi : fmaxf(fabsf(hi), fabsf(lo)));
+      }
+      if (p.out_amax) {
+        const uint32_t wm = wave_max_u32(__float_as_uint(fmaxf(omax, 0.f)));
+        if (lane == 0) atomicMax(p.out_amax + ((blockIdx.x * 4 + wave + strip) & 63), wm);
+      }
+      gemm_epilogue<EPI_MAX, 2>(q, acc, p.bias2, g, p0, n0, wave, wr, 0, li, lh, smemf);
     }
-    if (p.out_amax) {
-      const uint32_t wm = wave_max_u32(__float_as_uint(fmaxf(omax, 0.f)));
-      if (lane == 0) atomicMax(p.out_amax + ((blockIdx.x * 4 + wave + strip) & 63), wm);
-    }
-    gemm_epilogue<EPI_MAX, 2>(q, acc, p.bias2, 0, p0, n0, wave, wr, 0, li, lh, smemf);
     zero_acc();
   }
 #undef S4G_F2_STRIP
 #undef S4G_F2_TERM
 }
 
-template <int LOADER>
+template <int LOADER, int EPI2, int RW>
 static int launch_gemm_f16x2_fused2(const GemmParams& p, hipStream_t st) {
-  constexpr int BM = 128, K = 128;
+  constexpr int BM = 64 * RW, K = 64 * (4 / RW);
   constexpr size_t lds = sizeof(uint16_t) * 2 * BM * (size_t)(K + 8) + sizeof(float) * (4 * 128 + 16);
   static_assert(lds <= 80 * 1024, "two workgroups per CU");
   static const hipError_t attr = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&mlp_gemm_f16x2_fused2_kernel<LOADER>),
+      reinterpret_cast<const void*>(&mlp_gemm_f16x2_fused2_kernel<LOADER, EPI2, RW>),
       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr != hipSuccess) return (int)attr;
   const dim3 grid((unsigned)((p.P + BM - 1) / BM));
-  hipLaunchKernelGGL((mlp_gemm_f16x2_fused2_kernel<LOADER>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((mlp_gemm_f16x2_fused2_kernel<LOADER, EPI2, RW>), grid, dim3(256), lds, st, p);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }
@@ -1597,13 +1634,24 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   }
 
   if (d->W2_f16x2_frag) {
-    // two fused layers: K = 128 -> 128 -> Cout2 with the max over 64 neighbours
-    if (!h2 || d->epilogue != S4G_GEMM_EPI_MAX || d->K != 64 || d->Kpad16 != 128 || d->Cout != 128 ||
-        d->Cout2 <= 0 || (d->Cout2 & 127) || d->groups != 1 || !d->W_f16x2_frag || !d->w2_inv_scale ||
-        !d->bias2 || (d->P & 63))
+    // two fused layers: K = C -> C -> Cout2 with C = 128 (128 positions per workgroup) or
+    // C = 256 (64 positions), epilogue MAX (K == 64 neighbours) or STORE
+    const bool c128 = d->Kpad16 == 128 && d->Cout == 128, c256 = d->Kpad16 == 256 && d->Cout == 256;
+    const bool store = d->epilogue == S4G_GEMM_EPI_STORE;
+    if (!h2 || (!store && (d->epilogue != S4G_GEMM_EPI_MAX || d->K != 64 || (d->P & 63))) ||
+        (!c128 && !c256) || d->Cout2 <= 0 || (d->Cout2 % d->Cout) || d->groups != 1 || !d->W_f16x2_frag ||
+        !d->w2_inv_scale || !d->bias2 ||
+        (store && (((d->ldc | d->c_coff) & 3) || ((uintptr_t)d->out & 15))))
       return S4G_EINVAL;
-    if (d->loader == S4G_GEMM_LOAD_GATHER_MLP1) return launch_gemm_f16x2_fused2<LOAD_GATHER_MLP1>(p, st);
-    if (d->loader == S4G_GEMM_LOAD_PLAIN) return launch_gemm_f16x2_fused2<LOAD_PLAIN>(p, st);
+#define S4G_FUSED2_CASE(L, E, R)                                    \
+  if (d->loader == L && (int)d->epilogue == (int)E && (c128 ? 2 : 1) == R) \
+    return launch_gemm_f16x2_fused2<L, E, R>(p, st);
+    S4G_FUSED2_CASE(LOAD_GATHER_MLP1, EPI_MAX, 2)
+    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_MAX, 2)
+    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_MAX, 1)
+    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_STORE, 1)
+    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_STORE, 2)
+#undef S4G_FUSED2_CASE
     return S4G_EUNSUPPORTED;
   }
 #define S4G_GEMM_CASE(L, E)                                            \

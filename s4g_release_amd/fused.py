@@ -215,6 +215,13 @@ class FusedPointNet2:
         self.sigmoid_from = sum(chans[:3])
         self._streams = None
 
+    def _fusable(self, l1, l2):
+        """Two consecutive layers one launch can take (mlp_gemm_f16x2_fused2_kernel)."""
+        c = l1.cout
+        return (self.precision == "f16x2" and self.fuse2 and c in (128, 256) and l1.groups == 1 and
+                l2.groups == 1 and l1.kpad16 == c and l2.cin == c and l2.kpad16 == c and
+                l2.cout % c == 0 and l1.Wfrag is not None and l2.Wfrag is not None)
+
     # ------------------------------------------------------------------ launches
     def _gemm(self, name, layer, P, loader, epi, relu=True, layer2=None, **kw):
         d = GemmDesc()
@@ -345,13 +352,9 @@ class FusedPointNet2:
             P = B * M * K
             layers = sa["layers"]
             x = x_amax = None
-            # the last two layers as ONE launch (K = 128 -> 128 -> Cout2, intermediate in LDS);
-            # the first of the pair then reads through the MLP1 or the plain loader
-            fuse2 = (self.precision == "f16x2" and self.fuse2 and K == 64 and
-                     layers[-2].kpad16 == 128 and layers[-2].cout == 128 and
-                     layers[-1].cin == 128 and layers[-1].kpad16 == 128 and
-                     layers[-1].cout % 128 == 0 and layers[-2].Wfrag is not None and
-                     layers[-1].Wfrag is not None and len(layers) >= 3)
+            # the last two layers as ONE launch (C -> C -> Cout2 with C = 128 or 256, intermediate
+            # in LDS); the first of the pair then reads through the MLP1 or the plain loader
+            fuse2 = K == 64 and len(layers) >= 3 and self._fusable(layers[-2], layers[-1])
             for l, layer in enumerate(layers):
                 if l == 0 and sa["mlp1"] is not None:
                     continue                      # folded into layer 1's loader
@@ -388,8 +391,13 @@ class FusedPointNet2:
             nidx, nw = geo["fp"][fi]
             P = B * n_dense
             x = x_amax = None
-            for l, layer in enumerate(fp["layers"]):
-                out = torch.empty((P, layer.cout), dtype=torch.float32, device=dev)
+            fl = fp["layers"]
+            fuse2 = len(fl) >= 3 and self._fusable(fl[-2], fl[-1])
+            for l, layer in enumerate(fl):
+                if fuse2 and l == len(fl) - 1:
+                    continue                      # fused behind the previous layer's launch
+                l2 = fl[-1] if (fuse2 and l == len(fl) - 2) else None
+                out = torch.empty((P, (l2 or layer).cout), dtype=torch.float32, device=dev)
                 out_amax = next(rows)
                 if l == 0:
                     c1 = 0 if dense_feat is None else dense_feat.shape[1]
@@ -400,8 +408,8 @@ class FusedPointNet2:
                                out_amax=out_amax)
                 else:
                     self._gemm("fp%d.%d" % (fi, l), layer, P, LOAD_PLAIN, EPI_STORE, out=out,
-                               ldc=layer.cout, A=x, lda=x.shape[1], a_amax=x_amax,
-                               out_amax=out_amax)
+                               ldc=out.shape[1], A=x, lda=x.shape[1], a_amax=x_amax,
+                               out_amax=out_amax, layer2=l2)
                 x, x_amax = out, out_amax
             sparse_feat, sparse_amax, n_sparse = x, x_amax, n_dense
 
