@@ -252,9 +252,10 @@ typedef struct s4g_gemm_desc {
    * fits LDS) use the resident-A kernel, which streams W fragments straight into
    * the matrix-core operand registers. */
   const void *W_f16x2_frag;
-  /* ABI >= 3, optional: a SECOND layer fused behind this one (S4G_GEMM_F16X2, groups == 1,
-   * loader PLAIN or GATHER_MLP1, Kpad16 == Cout == C with C = 128 or 256, Cout2 % C == 0;
-   * epilogue MAX with K == 64, or STORE): the launch computes
+  /* ABI >= 3, optional: a SECOND layer fused behind this one (S4G_GEMM_F16X2, loader PLAIN
+   * or GATHER_MLP1, Kpad16 == Cout == C with C = 128 or 256, Cout2 % 64 == 0; epilogue MAX
+   * with K == 64 and groups == 1, or STORE with any group count -- W2 / w2_inv_scale / bias2
+   * then hold `groups` blocks like their first-layer counterparts): the launch computes
    *   out = epilogue(relu2(bias2 + W2 . relu(bias + W . A)))
    * with the C-channel intermediate kept in LDS (split with a per-tile power-of-two scale).
    * W2_f16x2_frag / w2_inv_scale / bias2 describe W2 (Cout2 x C) like W_f16x2_frag /

@@ -1194,7 +1194,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
   extern __shared__ __attribute__((aligned(16))) float smemf[];
   uint16_t* Ah = reinterpret_cast<uint16_t*>(smemf);   // [2][BM][K + 8]
   float* scr = reinterpret_cast<float*>(Ah + 2 * aplane);   // [4 waves][128] scale | bias, then 4 tile maxima
-  const int g = 0;
+  const int g = blockIdx.y;
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -1216,9 +1216,14 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
   const uint32_t wf_lane = (uint32_t)lane * 16u;
   constexpr size_t cb_stride = (size_t)KS * 2048;               // bytes between n32 and n32 + 1
   constexpr size_t strip_stride = (size_t)CW * 2 * cb_stride;   // bytes between 128-channel strips
-  const char* __restrict__ w1 = reinterpret_cast<const char*>(p.Wfrag) + (size_t)(wc_u * 2) * cb_stride;
-  const char* __restrict__ w2 = reinterpret_cast<const char*>(p.Wfrag2) + (size_t)(wc_u * 2) * cb_stride;
-  const int nstrip2 = p.Cout2 / (64 * CW);
+  const char* __restrict__ w1 = reinterpret_cast<const char*>(p.Wfrag + (size_t)g * p.Cout * K * 2) +
+                                (size_t)(wc_u * 2) * cb_stride;
+  const char* __restrict__ w2 = reinterpret_cast<const char*>(p.Wfrag2 + (size_t)g * p.Cout2 * K * 2) +
+                                (size_t)(wc_u * 2) * cb_stride;
+  const int nstrip2 = (p.Cout2 + 64 * CW - 1) / (64 * CW);
+  // a wave whose 64 channels lie past Cout2 (last, partial strip) sits phase 2 out; its ring
+  // must not prefetch W2 fragments that do not exist
+  const bool active0 = wc_u * 64 < p.Cout2;
 
   uint4 ring[GR_RING][2][2];
 #pragma unroll
@@ -1232,7 +1237,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
 
   {  // prologue: the loader's panel -> two fp16 planes in LDS
     ALoader<LOADER, RPT, RS> ld;
-    ld.init(p, p0, 0, t);
+    ld.init(p, p0, g, t);
     const int chunk = t & 7, srow = t >> 3;
     constexpr int NKT = K / 32;
     float4 ra[NKT][RPT];
@@ -1326,10 +1331,10 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
   prime_a();
   {
     const int n = wc * 64 + lane;   // channel whose scale / bias this lane stages for its wave
-    epi_s[lane] = inv_sa * p.w_inv_scale[n];
-    epi_s[64 + lane] = p.bias[n];
+    epi_s[lane] = inv_sa * p.w_inv_scale[(size_t)g * p.b_gstride + n];
+    epi_s[64 + lane] = p.bias[(size_t)g * p.b_gstride + n];
   }
-  S4G_F2_STRIP(true, w1, w2)
+  S4G_F2_STRIP(true, w1, (active0 ? w2 : w1))
   float tmax = 0.f;
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
@@ -1383,11 +1388,13 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
   zero_acc();
   prime_a();
   const char* wstrip = w2;
+  const float* __restrict__ bg2 = p.bias2 + (size_t)g * p.Cout2;
   for (int strip = 0; strip < nstrip2; ++strip, wstrip += strip_stride) {
+    if ((strip * CW + wc_u) * 64 >= p.Cout2) break;
     const int n = (strip * CW + wc) * 64 + lane;
-    const float e_sc = inv_sh * p.w_inv_scale2[n];
-    const float e_bias = p.bias2[n];
-    const char* wnext = strip + 1 < nstrip2 ? wstrip + strip_stride : wstrip;
+    const float e_sc = inv_sh * p.w_inv_scale2[(size_t)g * p.Cout2 + n];
+    const float e_bias = bg2[n];
+    const char* wnext = ((strip + 1) * CW + wc_u) * 64 < p.Cout2 ? wstrip + strip_stride : wstrip;
     S4G_F2_STRIP(EPI2 == EPI_STORE, wstrip, wnext)
     const int n0 = (strip * CW + wc) * 64;
     float omax = 0.f;
@@ -1416,7 +1423,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
             }
             const int row = p0 + wr * 64 + pb * 32 + li;
             if (row < p.P)
-              *reinterpret_cast<float4*>(p.out + (size_t)row * p.ldc + p.c_coff + nn) =
+              *reinterpret_cast<float4*>(p.out + (size_t)row * p.ldc + p.c_coff + g * p.c_gcol + nn) =
                   make_float4(v[0], v[1], v[2], v[3]);
           }
         }
@@ -1446,7 +1453,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
         const uint32_t wm = wave_max_u32(__float_as_uint(fmaxf(omax, 0.f)));
         if (lane == 0) atomicMax(p.out_amax + ((blockIdx.x * 4 + wave + strip) & 63), wm);
       }
-      gemm_epilogue<EPI_MAX, 2>(q, acc, p.bias2, g, p0, n0, wave, wr, 0, li, lh, smemf);
+      gemm_epilogue<EPI_MAX, 2>(q, acc, bg2, g, p0, n0, wave, wr, 0, li, lh, smemf);
     }
     zero_acc();
   }
@@ -1455,7 +1462,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
 }
 
 template <int LOADER, int EPI2, int RW>
-static int launch_gemm_f16x2_fused2(const GemmParams& p, hipStream_t st) {
+static int launch_gemm_f16x2_fused2(const GemmParams& p, int groups, hipStream_t st) {
   constexpr int BM = 64 * RW, K = 64 * (4 / RW);
   constexpr size_t lds = sizeof(uint16_t) * 2 * BM * (size_t)(K + 8) + sizeof(float) * (4 * 128 + 16);
   static_assert(lds <= 80 * 1024, "two workgroups per CU");
@@ -1463,7 +1470,7 @@ static int launch_gemm_f16x2_fused2(const GemmParams& p, hipStream_t st) {
       reinterpret_cast<const void*>(&mlp_gemm_f16x2_fused2_kernel<LOADER, EPI2, RW>),
       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr != hipSuccess) return (int)attr;
-  const dim3 grid((unsigned)((p.P + BM - 1) / BM));
+  const dim3 grid((unsigned)((p.P + BM - 1) / BM), (unsigned)groups);
   hipLaunchKernelGGL((mlp_gemm_f16x2_fused2_kernel<LOADER, EPI2, RW>), grid, dim3(256), lds, st, p);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
@@ -1639,13 +1646,13 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
     const bool c128 = d->Kpad16 == 128 && d->Cout == 128, c256 = d->Kpad16 == 256 && d->Cout == 256;
     const bool store = d->epilogue == S4G_GEMM_EPI_STORE;
     if (!h2 || (!store && (d->epilogue != S4G_GEMM_EPI_MAX || d->K != 64 || (d->P & 63))) ||
-        (!c128 && !c256) || d->Cout2 <= 0 || (d->Cout2 % d->Cout) || d->groups != 1 || !d->W_f16x2_frag ||
+        (!c128 && !c256) || d->Cout2 <= 0 || (d->Cout2 & 63) || (!store && d->groups != 1) || !d->W_f16x2_frag ||
         !d->w2_inv_scale || !d->bias2 ||
-        (store && (((d->ldc | d->c_coff) & 3) || ((uintptr_t)d->out & 15))))
+        (store && (((d->ldc | d->c_coff | d->c_gcol) & 3) || ((uintptr_t)d->out & 15))))
       return S4G_EINVAL;
 #define S4G_FUSED2_CASE(L, E, R)                                    \
   if (d->loader == L && (int)d->epilogue == (int)E && (c128 ? 2 : 1) == R) \
-    return launch_gemm_f16x2_fused2<L, E, R>(p, st);
+    return launch_gemm_f16x2_fused2<L, E, R>(p, d->groups, st);
     S4G_FUSED2_CASE(LOAD_GATHER_MLP1, EPI_MAX, 2)
     S4G_FUSED2_CASE(LOAD_PLAIN, EPI_MAX, 2)
     S4G_FUSED2_CASE(LOAD_PLAIN, EPI_MAX, 1)

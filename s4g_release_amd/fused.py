@@ -218,9 +218,9 @@ class FusedPointNet2:
     def _fusable(self, l1, l2):
         """Two consecutive layers one launch can take (mlp_gemm_f16x2_fused2_kernel)."""
         c = l1.cout
-        return (self.precision == "f16x2" and self.fuse2 and c in (128, 256) and l1.groups == 1 and
-                l2.groups == 1 and l1.kpad16 == c and l2.cin == c and l2.kpad16 == c and
-                l2.cout % c == 0 and l1.Wfrag is not None and l2.Wfrag is not None)
+        return (self.precision == "f16x2" and self.fuse2 and c in (128, 256) and
+                l1.groups == l2.groups and l1.kpad16 == c and l2.cin == c and l2.kpad16 == c and
+                l2.cout % 64 == 0 and l1.Wfrag is not None and l2.Wfrag is not None)
 
     # ------------------------------------------------------------------ launches
     def _gemm(self, name, layer, P, loader, epi, relu=True, layer2=None, **kw):
@@ -244,7 +244,7 @@ class FusedPointNet2:
             d.W2_f16x2_frag = layer2.Wfrag.data_ptr()
             d.w2_inv_scale, d.bias2 = layer2.w_inv_scale.data_ptr(), layer2.bias.data_ptr()
             d.Cout2, d.relu2 = layer2.cout, 1
-            flops += 2.0 * P * layer2.cout * layer2.cin
+            flops += 2.0 * P * layer2.cout * layer2.cin * layer2.groups
             name = "%s+%s" % (name, name[:-1] + str(int(name[-1]) + 1))
         with _F._timed("gemm[%s P=%d K=%d N=%dx%d]" % (name, P, layer.cin, layer.groups, layer.cout),
                        0, flops):
@@ -354,7 +354,8 @@ class FusedPointNet2:
             x = x_amax = None
             # the last two layers as ONE launch (C -> C -> Cout2 with C = 128 or 256, intermediate
             # in LDS); the first of the pair then reads through the MLP1 or the plain loader
-            fuse2 = K == 64 and len(layers) >= 3 and self._fusable(layers[-2], layers[-1])
+            fuse2 = (K == 64 and len(layers) >= 3 and layers[-1].groups == 1 and
+                     self._fusable(layers[-2], layers[-1]))
             for l, layer in enumerate(layers):
                 if l == 0 and sa["mlp1"] is not None:
                     continue                      # folded into layer 1's loader
@@ -422,13 +423,20 @@ class FusedPointNet2:
         self._gemm("heads.0", l0, P, LOAD_PLAIN, EPI_STORE, out=h, ldc=l0.cout, A=x,
                    lda=x.shape[1], a_amax=x_amax, out_amax=h_amax)
         x, x_amax = h, h_amax
-        for l, layer in enumerate(self.head_layers[1:], start=1):
-            h = torch.empty((P, 4 * layer.cout), dtype=torch.float32, device=dev)
+        hl = self.head_layers
+        l = 1
+        while l < len(hl):
+            layer = hl[l]
+            # two consecutive grouped layers as one launch where the widths allow it
+            l2 = hl[l + 1] if (l + 1 < len(hl) and self._fusable(layer, hl[l + 1])) else None
+            cout = (l2 or layer).cout
+            h = torch.empty((P, layer.groups * cout), dtype=torch.float32, device=dev)
             h_amax = next(rows)
             self._gemm("heads.%d" % l, layer, P, LOAD_PLAIN, EPI_STORE, out=h,
-                       ldc=4 * layer.cout, c_gcol=layer.cout, A=x, lda=x.shape[1],
-                       a_gcol=layer.cin, a_amax=x_amax, out_amax=h_amax)
+                       ldc=layer.groups * cout, c_gcol=cout, A=x, lda=x.shape[1],
+                       a_gcol=layer.cin, a_amax=x_amax, out_amax=h_amax, layer2=l2)
             x, x_amax = h, h_amax
+            l += 2 if l2 is not None else 1
         names = ("score", "frame_R", "frame_t", "movable_logits")
         outs = [torch.empty((B, c, N0), dtype=torch.float32, device=dev)
                 for c in self.head_channels]
