@@ -229,6 +229,101 @@ def test_gemm_gather_mlp1(dev, C1, Cout, epi, prec, gemm_variant):
     assert (out.double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
 
 
+def _h2_second(W2):
+    """W2_f16x2_frag / w2_inv_scale of the layer fused behind (groups leading)."""
+    from s4g_release_amd.fused import fragment_order, split_f16x2
+    planes, inv = split_f16x2(W2.contiguous())
+    p4 = planes if planes.dim() == 4 else planes.unsqueeze(1)
+    return fragment_order(p4), inv
+
+
+@pytest.mark.parametrize("C,Cout2,epi,groups,P", [
+    (128, 256, 1, 1, 37 * 64),     # SA0 shape: plain loader, max over 64 rows
+    (128, 128, 1, 1, 3 * 64),      # odd number of centroids: half-empty last workgroup
+    (256, 512, 1, 1, 21 * 64),     # SA1 shape, 64 positions per workgroup
+    (256, 256, 0, 1, 1000),        # FP2 shape, store epilogue, ragged last tile
+    (128, 384, 0, 1, 777),         # 128-wide pair, store, three strips
+    (256, 128, 0, 4, 500),         # head layers 2 + 3: four groups, partial strip (waves 2, 3 sit out)
+    (256, 64, 0, 2, 130),          # quarter strip
+])
+def test_gemm_fused_layer_pair(dev, C, Cout2, epi, groups, P):
+    """Two layers, one launch (intermediate in LDS, per-tile scale): against fp64."""
+    g = torch.Generator(device="cpu").manual_seed(C + Cout2 + groups)
+    A = torch.randn(P, groups * C, generator=g).to(dev)
+    A[: P // 3] *= 1e-3                                   # tiles with very different magnitudes
+    W1 = (torch.randn(groups, C, C, generator=g) / C ** 0.5).to(dev)
+    b1 = torch.randn(groups, C, generator=g).to(dev)
+    W2 = (torch.randn(groups, Cout2, C, generator=g) / C ** 0.5).to(dev)
+    b2 = torch.randn(groups, Cout2, generator=g).to(dev)
+    K = 64
+    rows = P // K if epi == 1 else P
+    out = torch.full((rows, groups * Cout2), float("nan"), device=dev)
+    k16, w3 = _w3(W1)
+    h2 = _h2(W1, A)
+    frag2, inv2 = _h2_second(W2)
+    _run(dict(loader=0, epilogue=epi, groups=groups, relu=1, P=P, Cin=C, Kpad=C, Cout=C, W=W1, bias=b1,
+              w_gstride=C * C, b_gstride=C, A=A, lda=groups * C, a_gcol=C, K=K, out=out,
+              ldc=groups * Cout2, c_gcol=Cout2, precision=3, Kpad16=k16, W_bf16x3=w3,
+              W2_f16x2_frag=frag2, w2_inv_scale=inv2, bias2=b2, Cout2=Cout2, relu2=1, **h2), dev)
+    ref = []
+    for gi in range(groups):
+        h = (A[:, gi * C:(gi + 1) * C].double() @ W1[gi].double().t() + b1[gi].double()).clamp_min(0)
+        o = (h @ W2[gi].double().t() + b2[gi].double()).clamp_min(0)
+        ref.append(o)
+    ref = torch.cat(ref, dim=1)
+    if epi == 1:
+        ref = ref.view(rows, K, Cout2).max(dim=1)[0]
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    _check_out_amax(h2, out)
+
+
+def test_gemm_fused_layer_pair_mlp1_loader(dev):
+    """The SA0 launch: xyz gather + first layer in the loader, two contractions, max."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B, N, M, K, C, Cout2 = 2, 500, 23, 64, 128, 256
+    xyz = (torch.rand(B, 3, N, generator=g) * 0.2).to(dev)
+    cidx = torch.randint(0, N, (B, M), generator=g)
+    ctr = torch.stack([xyz[b][:, cidx[b]] for b in range(B)]).contiguous()
+    gidx = torch.randint(0, N, (B, M, K), generator=g).int().to(dev)
+    w1 = torch.randn(C, 4, generator=g).to(dev)
+    W = (torch.randn(C, C, generator=g) / C ** 0.5).to(dev)
+    b = torch.randn(C, generator=g).to(dev)
+    W2 = (torch.randn(Cout2, C, generator=g) / C ** 0.5).to(dev)
+    b2 = torch.randn(Cout2, generator=g).to(dev)
+    P = B * M * K
+    out = torch.full((B * M, Cout2), float("nan"), device=dev)
+    k16, w3 = _w3(W)
+    bound = float((w1[:, :3].abs().sum(1) * 0.4 + w1[:, 3].abs()).max())
+    h2 = _h2(W, floor=bound)
+    frag2, inv2 = _h2_second(W2)
+    _run(dict(loader=3, epilogue=1, groups=1, relu=1, P=P, Cin=C, Kpad=C, Cout=C, W=W, bias=b, gidx=gidx,
+              xyz=xyz, ctr=ctr, N=N, M=M, K=K, mlp1_w=w1, out=out, ldc=Cout2, precision=3, Kpad16=k16,
+              W_bf16x3=w3, W2_f16x2_frag=frag2, w2_inv_scale=inv2, bias2=b2, Cout2=Cout2, relu2=1,
+              **h2), dev)
+    rel = torch.stack([xyz[bi][:, gidx[bi].long()] - ctr[bi][:, :, None] for bi in range(B)])
+    rel = rel.permute(0, 2, 3, 1).reshape(P, 3).double()
+    A = (rel @ w1[:, :3].double().t() + w1[:, 3].double()).clamp_min(0)
+    h = (A @ W.double().t() + b.double()).clamp_min(0)
+    ref = (h @ W2.double().t() + b2.double()).clamp_min(0).view(B * M, K, Cout2).max(dim=1)[0]
+    assert (out.double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_fused_layer_pair_rejects_unsupported(dev):
+    from s4g_release_amd import _cabi
+    W1 = torch.randn(64, 64, device=dev)
+    k16, w3 = _w3(W1)
+    h2 = _h2(W1, torch.ones(1, device=dev))
+    frag2, inv2 = _h2_second(torch.randn(64, 64, device=dev))
+    A = torch.randn(64, 64, device=dev)
+    out = torch.empty(64, 64, device=dev)
+    with pytest.raises(RuntimeError):    # C = 64 is not a fused width
+        _run(dict(loader=0, epilogue=0, groups=1, relu=1, P=64, Cin=64, Kpad=64, Cout=64, W=W1,
+                  bias=torch.zeros(64, device=dev), A=A, lda=64, out=out, ldc=64, precision=3, Kpad16=k16,
+                  W_bf16x3=w3, W2_f16x2_frag=frag2, w2_inv_scale=inv2, bias2=torch.zeros(64, device=dev),
+                  Cout2=64, relu2=1, **h2), dev)
+
+
 @pytest.mark.parametrize("prec", PRECISIONS)
 def test_gemm_interp_store(dev, prec):
     g = torch.Generator(device="cpu").manual_seed(5)
@@ -494,3 +589,22 @@ def test_fused_equals_modules_random_configs(dev, seed):
         for k in a:
             scale = max(1.0, float(a[k].abs().max()))
             assert (a[k] - b[k]).abs().max().item() < TOL * scale, (k, precision, cfg)
+
+
+def test_fused_layer_pairs_match_layer_by_layer(dev, monkeypatch):
+    """The default (pairs fused into single launches) against S4G_GEMM_FUSE2=0 on the bench
+    architecture: same network outputs to fp32 round-off."""
+    from s4g_release_amd import synth
+    from s4g_release_amd.fused import FusedPointNet2
+    from s4g_release_amd.model import S4GConfig, build_pointnet2_cls, randomize_bn_
+    torch.manual_seed(11)
+    net = build_pointnet2_cls(S4GConfig())
+    randomize_bn_(net, 12)
+    net = net.to(dev).eval()
+    pts = torch.from_numpy(synth.make_batch([0, 1], 25600)).to(dev)
+    a = FusedPointNet2(net)({"scene_points": pts})
+    monkeypatch.setenv("S4G_GEMM_FUSE2", "0")
+    b = FusedPointNet2(net)({"scene_points": pts})
+    for k in a:
+        scale = max(1.0, b[k].abs().max().item())
+        assert (a[k] - b[k]).abs().max().item() < 2e-5 * scale, k
