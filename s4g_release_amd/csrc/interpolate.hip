@@ -254,6 +254,57 @@ __global__ __launch_bounds__(256) void group_points_tile_kernel(
   }
 }
 
+// Channels-last interpolate + add + bias + ReLU for the fast path's FP levels, where the
+// first shared-MLP layer is applied BEFORE the interpolation (it is linear, the weights
+// sum the same three rows): out[p][c] = act(y[p][c] + bias[c] + sum_k w[p][k] * s[b*N2 + idx[p][k]][c]).
+// y (the skip features' share of the layer) may be NULL.  A lane owns 4 channels of a row
+// (one 16-byte gather per neighbour); the wave maximum of |out| goes to a 64-slot row
+// (the f16x2 contraction that consumes `out` derives its scale from it).
+constexpr int IA_ROWS = 8;   // rows per lane group per workgroup pass
+
+__global__ __launch_bounds__(256) void interp_add_cl_kernel(
+    const float* __restrict__ y, const float* __restrict__ sp, const int* __restrict__ nidx,
+    const float* __restrict__ nw, const float* __restrict__ bias, int64_t P, int N1, int N2, int C,
+    int relu, float* __restrict__ out, uint32_t* __restrict__ out_amax) {
+  const int lpr = C >> 2;                       // lanes per row
+  const int rpb = 256 / lpr;                    // rows per block pass (C <= 1024)
+  const int c4 = (threadIdx.x % lpr) * 4;
+  const int rl = threadIdx.x / lpr;
+  const bool lane_ok = rl < rpb;
+  const float4 bb = *reinterpret_cast<const float4*>(bias + c4);
+  float tmax = 0.f;
+  for (int it = 0; it < IA_ROWS; ++it) {
+    const int64_t p = ((int64_t)blockIdx.x * IA_ROWS + it) * rpb + rl;
+    if (!lane_ok || p >= P) continue;
+    const int b = (int)(p / N1);
+    const int i0 = nidx[p * 3], i1 = nidx[p * 3 + 1], i2 = nidx[p * 3 + 2];
+    const float w0 = nw[p * 3], w1 = nw[p * 3 + 1], w2 = nw[p * 3 + 2];
+    const float* __restrict__ base = sp + (size_t)b * N2 * C + c4;
+    const float4 a = *reinterpret_cast<const float4*>(base + (size_t)i0 * C);
+    const float4 bq = *reinterpret_cast<const float4*>(base + (size_t)i1 * C);
+    const float4 c = *reinterpret_cast<const float4*>(base + (size_t)i2 * C);
+    float4 v = y ? *reinterpret_cast<const float4*>(y + (size_t)p * C + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w}, cv[4] = {c.x, c.y, c.z, c.w};
+    const float bi[4] = {bb.x, bb.y, bb.z, bb.w};
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float acc = __fmul_rn(av[e], w0);
+      acc = __fadd_rn(acc, __fmul_rn(bv[e], w1));
+      acc = __fadd_rn(acc, __fmul_rn(cv[e], w2));
+      float x = __fadd_rn(__fadd_rn(o[e], acc), bi[e]);
+      if (relu) x = fmaxf(x, 0.f);
+      o[e] = x;
+      tmax = fmaxf(tmax, fabsf(x));
+    }
+    *reinterpret_cast<float4*>(out + (size_t)p * C + c4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  if (out_amax) {
+    const uint32_t wm = wave_max_u32(__float_as_uint(tmax));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_amax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63), wm);
+  }
+}
+
 __global__ __launch_bounds__(IP_THREADS) void three_interpolate_backward_kernel(
     const float* __restrict__ gout, const int64_t* __restrict__ idx,
     const float* __restrict__ w, int C, int N2, int N1,
@@ -397,6 +448,28 @@ extern "C" int s4g_group_points_ws_f32(const float* feat_bcn, const int64_t* idx
   const dim3 tgrid((unsigned)((nslices + 7) / 8 * 8) * (unsigned)tiles_x);
   hipLaunchKernelGGL(s4g::group_points_tile_kernel, tgrid, dim3(256), 0, st, featT, idx_bmk, (int)C,
                      (int)N, MK, out_bcmk, (int)tiles_x, (int)tiles_y, nslices);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
+
+extern "C" int s4g_interp_add_cl_f32(const float* y_pc, const float* sparse_rc, const int32_t* nidx_p3,
+                                     const float* nw_p3, const float* bias_c, int64_t B, int64_t N1,
+                                     int64_t N2, int64_t C, int relu, float* out_pc, float* out_amax64,
+                                     s4g_stream_t stream) {
+  if (B < 0 || N1 < 0 || N2 <= 0 || C <= 0 || (C & 3) || C > 1024 || (1024 % C) != 0 ||
+      N2 >= (1ll << 31) || N1 >= (1ll << 31))
+    return S4G_EINVAL;
+  if (B == 0 || N1 == 0) return S4G_OK;
+  if (!sparse_rc || !nidx_p3 || !nw_p3 || !bias_c || !out_pc) return S4G_EINVAL;
+  if (((uintptr_t)sparse_rc | (uintptr_t)out_pc | (uintptr_t)bias_c | (uintptr_t)y_pc) & 15) return S4G_EINVAL;
+  const int64_t P = B * N1;
+  const int rpb = 256 / (int)(C / 4);
+  const int64_t per_block = (int64_t)rpb * s4g::IA_ROWS;
+  const int64_t blocks = (P + per_block - 1) / per_block;
+  if (blocks >= (1ll << 31)) return S4G_EINVAL;
+  hipLaunchKernelGGL(s4g::interp_add_cl_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     y_pc, sparse_rc, nidx_p3, nw_p3, bias_c, P, (int)N1, (int)N2, (int)C, relu, out_pc,
+                     reinterpret_cast<uint32_t*>(out_amax64));
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }

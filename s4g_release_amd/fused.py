@@ -141,6 +141,9 @@ class FusedPointNet2:
         self.dense_streams = max(1, int(os.environ.get("S4G_DENSE_STREAMS", "1")))
         # S4G_GEMM_FUSE2=0: never fuse the last two layers of an SA level into one launch
         self.fuse2 = os.environ.get("S4G_GEMM_FUSE2", "1") != "0"
+        # S4G_FP_LINEAR_FIRST=0: interpolate first, like the reference (fused into the
+        # contraction's loader); default: first FP layer before the interpolation
+        self.fp_linear_first = os.environ.get("S4G_FP_LINEAR_FIRST", "1") != "0"
         self.geo_streams = max(1, int(os.environ.get("S4G_GEO_STREAMS", "2")))
         p = next(net.parameters())
         if not p.is_cuda:
@@ -400,7 +403,36 @@ class FusedPointNet2:
                 l2 = fl[-1] if (fuse2 and l == len(fl) - 2) else None
                 out = torch.empty((P, (l2 or layer).cout), dtype=torch.float32, device=dev)
                 out_amax = next(rows)
-                if l == 0:
+                if l == 0 and self.fp_linear_first and layer.cout % 4 == 0 and 1024 % layer.cout == 0:
+                    # the layer is linear: apply it to the sparse features (and to the skip
+                    # features) first, interpolate the narrow result afterwards -- the big
+                    # tensor's contraction shrinks from K = C2 + C1 to K = C1 (or vanishes)
+                    c2 = sparse_feat.shape[1]
+                    c1 = 0 if dense_feat is None else dense_feat.shape[1]
+                    sp = fp.get("split")
+                    if sp is None or sp[2] != c2:
+                        w = layer.W[:, :layer.cin]
+                        zero = torch.zeros_like(layer.bias)
+                        la = _Layer(_pad_k(w[:, :c2].contiguous()), zero, c2)
+                        lb = _Layer(_pad_k(w[:, c2:].contiguous()), zero, c1) if c1 > 0 else None
+                        sp = fp["split"] = (la, lb, c2)
+                    la, lb, _ = sp
+                    s_out = torch.empty((B * n_sparse, layer.cout), dtype=torch.float32, device=dev)
+                    self._gemm("fp%d.0s" % fi, la, B * n_sparse, LOAD_PLAIN, EPI_STORE, relu=False,
+                               out=s_out, ldc=layer.cout, A=sparse_feat, lda=c2, a_amax=sparse_amax)
+                    y = None
+                    if lb is not None:
+                        y = torch.empty((P, layer.cout), dtype=torch.float32, device=dev)
+                        self._gemm("fp%d.0d" % fi, lb, P, LOAD_PLAIN, EPI_STORE, relu=False, out=y,
+                                   ldc=layer.cout, A=dense_feat, lda=c1, a_amax=dense_amax)
+                    with _F._timed("interp_add[P=%d,C=%d]" % (P, layer.cout),
+                                   P * layer.cout * (8 if y is not None else 4) + P * 24):
+                        rc = _cabi.lib().s4g_interp_add_cl_f32(
+                            None if y is None else y.data_ptr(), s_out.data_ptr(), nidx.data_ptr(),
+                            nw.data_ptr(), layer.bias.data_ptr(), B, n_dense, n_sparse, layer.cout, 1,
+                            out.data_ptr(), out_amax.data_ptr(), _F._stream())
+                    _cabi.check(rc, "interp_add_cl")
+                elif l == 0:
                     c1 = 0 if dense_feat is None else dense_feat.shape[1]
                     self._gemm("fp%d.%d" % (fi, l), layer, P, LOAD_INTERP, EPI_STORE, out=out,
                                ldc=layer.cout, nidx=nidx, nw=nw, sparse=sparse_feat,
