@@ -177,6 +177,12 @@ int s4g_interp_weights_f32(const float *d2_bn3, int64_t B, int64_t N1,
  *         S4G_GEMM_LOAD_GATHER_MLP1  first xyz-only SA layer folded into the loader:
  *                                A row p = relu(W1 . (xyz[b,:,gidx[p]] - ctr[b,:,m]) + b1),
  *                                mlp1_w = Cin x (wx, wy, wz, bias) fp32
+ *         S4G_GEMM_LOAD_GATHER_ADD  first SA layer of a level WITH features, applied to the
+ *                                features before the grouping (it is linear; feat = F =
+ *                                W_feat . features, (B*N, Cf = Cin) channels-last):
+ *                                A row p = relu(F[b*N + gidx[p]] + W_xyz . (xyz - ctr) + b1),
+ *                                mlp1_w = Cin x (wx, wy, wz, bias); a_amax bounds |F| and
+ *                                a_amax_floor the xyz + bias part (the two are ADDED)
  * epilogue S4G_GEMM_EPI_STORE   out[p*ldc + c_coff + g*c_gcol + n]
  *          S4G_GEMM_EPI_MAX     out[(p/K)*ldc + c_coff + n] = max over the K
  *                               consecutive rows of a group (K in 16,32,64)
@@ -190,6 +196,7 @@ int s4g_interp_weights_f32(const float *d2_bn3, int64_t B, int64_t N1,
 #define S4G_GEMM_LOAD_GATHER 1
 #define S4G_GEMM_LOAD_INTERP 2
 #define S4G_GEMM_LOAD_GATHER_MLP1 3
+#define S4G_GEMM_LOAD_GATHER_ADD 4
 #define S4G_GEMM_EPI_STORE 0
 #define S4G_GEMM_EPI_MAX 1
 #define S4G_GEMM_EPI_CHANNEL_FIRST 2

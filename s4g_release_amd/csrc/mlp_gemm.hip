@@ -45,7 +45,7 @@ constexpr int GM_BK = 32;
 constexpr int GM_LDS = 36;  // padded row stride (floats)
 constexpr int GM_THREADS = 256;
 
-enum { LOAD_PLAIN = 0, LOAD_GATHER = 1, LOAD_INTERP = 2, LOAD_GATHER_MLP1 = 3 };
+enum { LOAD_PLAIN = 0, LOAD_GATHER = 1, LOAD_INTERP = 2, LOAD_GATHER_MLP1 = 3, LOAD_GATHER_ADD = 4 };
 enum { EPI_STORE = 0, EPI_MAX = 1, EPI_CHANNEL_FIRST = 2 };
 
 struct GemmParams {
@@ -136,6 +136,19 @@ struct ALoader {
         rel[s][0] = __fsub_rn(x[j], c[m]);
         rel[s][1] = __fsub_rn(x[p.N + j], c[p.M + m]);
         rel[s][2] = __fsub_rn(x[2 * p.N + j], c[2 * p.M + m]);
+      } else if constexpr (LOADER == LOAD_GATHER_ADD) {
+        // first SA layer applied to the level's features BEFORE the grouping (it is linear):
+        // A[p][k] = relu(F[b*N + j][k] + w1[k] . (xyz_j - ctr_m, 1))
+        const int MK = p.M * p.K;
+        const int b = pp / MK;
+        const int m = (pp - b * MK) / p.K;
+        const int j = p.gidx[pp];
+        src0[s] = p.feat + ((size_t)b * p.N + j) * p.Cf;
+        const float* x = p.xyz + (size_t)b * 3 * p.N;
+        const float* c = p.ctr + (size_t)b * 3 * p.M;
+        rel[s][0] = __fsub_rn(x[j], c[m]);
+        rel[s][1] = __fsub_rn(x[p.N + j], c[p.M + m]);
+        rel[s][2] = __fsub_rn(x[2 * p.N + j], c[2 * p.M + m]);
       } else if constexpr (LOADER == LOAD_GATHER) {
         const int MK = p.M * p.K;
         const int b = pp / MK;
@@ -177,6 +190,19 @@ struct ALoader {
         const float4 w = p.mlp1[k0 + e];
         const float v = __fmaf_rn(w.z, rel[s][2], __fmaf_rn(w.y, rel[s][1], __fmaf_rn(w.x, rel[s][0], w.w)));
         rp[e] = fmaxf(v, 0.f);
+      }
+      return r;
+    } else if constexpr (LOADER == LOAD_GATHER_ADD) {
+      if (k0 >= p.Cin) return f4zero();
+      const float4 f = *reinterpret_cast<const float4*>(src0[s] + k0);
+      const float fv[4] = {f.x, f.y, f.z, f.w};
+      float4 r;
+      float* rp = reinterpret_cast<float*>(&r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float4 w = p.mlp1[k0 + e];
+        const float v = __fmaf_rn(w.z, rel[s][2], __fmaf_rn(w.y, rel[s][1], __fmaf_rn(w.x, rel[s][0], w.w)));
+        rp[e] = fmaxf(__fadd_rn(fv[e], v), 0.f);
       }
       return r;
     } else if constexpr (LOADER == LOAD_GATHER) {
@@ -748,7 +774,8 @@ __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP) ? 2 : 3) v
 
   // activation scale: the power of two that puts the tensor maximum in [2^14, 2^15)
   float amax = p.a_amax_floor;
-  if (p.a_amax) amax = fmaxf(amax, amax_slots(p.a_amax, lane));
+  if (p.a_amax) amax = LOADER == LOAD_GATHER_ADD ? amax + amax_slots(p.a_amax, lane)   // |F + xyz part|
+                                                 : fmaxf(amax, amax_slots(p.a_amax, lane));
   if (p.a_amax2) amax = fmaxf(amax, amax_slots(p.a_amax2, lane));
   uint32_t ex = __float_as_uint(amax) >> 23;
   ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
@@ -950,7 +977,8 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
   const float* __restrict__ wsc = p.w_inv_scale + (size_t)g * p.b_gstride;
 
   float amax = p.a_amax_floor;
-  if (p.a_amax) amax = fmaxf(amax, amax_slots(p.a_amax, lane));
+  if (p.a_amax) amax = LOADER == LOAD_GATHER_ADD ? amax + amax_slots(p.a_amax, lane)   // |F + xyz part|
+                                                 : fmaxf(amax, amax_slots(p.a_amax, lane));
   if (p.a_amax2) amax = fmaxf(amax, amax_slots(p.a_amax2, lane));
   uint32_t ex = __float_as_uint(amax) >> 23;
   ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
@@ -1202,7 +1230,8 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
   const int p0 = blockIdx.x * BM;
 
   float amax = p.a_amax_floor;
-  if (p.a_amax) amax = fmaxf(amax, amax_slots(p.a_amax, lane));
+  if (p.a_amax) amax = LOADER == LOAD_GATHER_ADD ? amax + amax_slots(p.a_amax, lane)   // |F + xyz part|
+                                                 : fmaxf(amax, amax_slots(p.a_amax, lane));
   if (p.a_amax2) amax = fmaxf(amax, amax_slots(p.a_amax2, lane));
   uint32_t ex = __float_as_uint(amax) >> 23;
   ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
@@ -1517,7 +1546,8 @@ static int launch_gemm_f16x2(const GemmParams& p, int groups, hipStream_t st) {
   // the INTERP / GATHER loaders hold too much per-row state for the wide tile's
   // 128 accumulator registers (they would spill)
   const bool wide = force ? force == 4
-                          : p.Cout > 128 && (LOADER == LOAD_PLAIN || LOADER == LOAD_GATHER_MLP1);
+                          : p.Cout > 128 && (LOADER == LOAD_PLAIN || LOADER == LOAD_GATHER_MLP1 ||
+                                             LOADER == LOAD_GATHER_ADD);
   if (wide) return launch_gemm_f16x2_cfg<LOADER, EPI, 4>(p, groups, st);
   return launch_gemm_f16x2_cfg<LOADER, EPI, 2>(p, groups, st);
 }
@@ -1623,6 +1653,11 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
     if (!d->gidx || !d->xyz || !d->ctr || !d->mlp1_w || (d->Cin & 3) || d->K <= 0 || d->M <= 0 ||
         d->N <= 0 || d->groups != 1 || ((uintptr_t)d->mlp1_w & 15))
       return S4G_EINVAL;
+  } else if (d->loader == S4G_GEMM_LOAD_GATHER_ADD) {
+    if (!d->gidx || !d->xyz || !d->ctr || !d->mlp1_w || !d->feat || (d->Cin & 3) || d->Cf != d->Cin ||
+        d->K <= 0 || d->M <= 0 || d->N <= 0 || d->groups != 1 || ((uintptr_t)d->mlp1_w & 15) ||
+        ((uintptr_t)d->feat & 15))
+      return S4G_EINVAL;
   } else if (d->loader == S4G_GEMM_LOAD_INTERP) {
     if (!d->nidx || !d->nw || !d->sparse || (d->C2 & 3) || (d->C1 & 3) ||
         (d->C1 > 0 && !d->dense) || d->N1 <= 0 || d->N2 <= 0 || d->groups != 1)
@@ -1654,6 +1689,8 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   if (d->loader == L && (int)d->epilogue == (int)E && (c128 ? 2 : 1) == R) \
     return launch_gemm_f16x2_fused2<L, E, R>(p, d->groups, st);
     S4G_FUSED2_CASE(LOAD_GATHER_MLP1, EPI_MAX, 2)
+    S4G_FUSED2_CASE(LOAD_GATHER_ADD, EPI_MAX, 2)
+    S4G_FUSED2_CASE(LOAD_GATHER_ADD, EPI_MAX, 1)
     S4G_FUSED2_CASE(LOAD_PLAIN, EPI_MAX, 2)
     S4G_FUSED2_CASE(LOAD_PLAIN, EPI_MAX, 1)
     S4G_FUSED2_CASE(LOAD_PLAIN, EPI_STORE, 1)
@@ -1674,6 +1711,8 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   S4G_GEMM_CASE(LOAD_INTERP, EPI_STORE)
   S4G_GEMM_CASE(LOAD_GATHER_MLP1, EPI_STORE)
   S4G_GEMM_CASE(LOAD_GATHER_MLP1, EPI_MAX)
+  S4G_GEMM_CASE(LOAD_GATHER_ADD, EPI_STORE)
+  S4G_GEMM_CASE(LOAD_GATHER_ADD, EPI_MAX)
 #undef S4G_GEMM_CASE
   return S4G_EUNSUPPORTED;
 }

@@ -34,7 +34,7 @@ _i32 = ctypes.c_int32
 _fp = ctypes.c_void_p
 GemmDesc = _cabi.GemmDesc
 
-LOAD_PLAIN, LOAD_GATHER, LOAD_INTERP, LOAD_GATHER_MLP1 = 0, 1, 2, 3
+LOAD_PLAIN, LOAD_GATHER, LOAD_INTERP, LOAD_GATHER_MLP1, LOAD_GATHER_ADD = 0, 1, 2, 3, 4
 EPI_STORE, EPI_MAX, EPI_CF = 0, 1, 2
 
 
@@ -175,12 +175,25 @@ class FusedPointNet2:
                     cin = w.shape[1]
                 layers.append(_Layer(_pad_k(w), b, cin))
             radius = float(sa.grouper.radius)
+            pre = None
+            if (sa.in_channels > 0 and sa.in_channels % 4 == 0 and len(sa.mlp) > 1 and
+                    layers[0].cout % 4 == 0 and os.environ.get("S4G_SA_LINEAR_FIRST", "1") != "0"):
+                # a level WITH input features: its first layer is linear, so the feature part is
+                # applied once per POINT (N rows) instead of once per (centroid, neighbour) pair
+                # (M*K rows, every point ~K*M/N times); the xyz part + bias + ReLU move into the
+                # next layer's loader
+                w0 = layers[0].W[:, :layers[0].cin]                 # K order [feat, xyz]
+                cf = sa.in_channels
+                la = _Layer(_pad_k(w0[:, :cf].contiguous()), torch.zeros_like(layers[0].bias), cf)
+                w1 = torch.cat([w0[:, cf:cf + 3], layers[0].bias[:, None]], dim=1).contiguous()
+                bound = float((w1[:, :3].abs().sum(dim=1) * radius + w1[:, 3].abs()).max())
+                pre = dict(la=la, w1=w1, bound=bound)
             # |relu(w . rel + b)| <= (|wx|+|wy|+|wz|) r + |b| for neighbours inside the ball
             mlp1_bound = 0.0 if mlp1 is None else float(
                 (mlp1[:, :3].abs().sum(dim=1) * radius + mlp1[:, 3].abs()).max())
             self.sa.append(dict(M=sa.num_centroids, radius=radius,
                                 K=int(sa.grouper.num_neighbours), layers=layers,
-                                cf=sa.in_channels, mlp1=mlp1, mlp1_bound=mlp1_bound))
+                                cf=sa.in_channels, mlp1=mlp1, mlp1_bound=mlp1_bound, pre=pre))
         self.fp = []
         for fp in net.fp_modules:
             if fp.interpolator is None:
@@ -342,7 +355,7 @@ class FusedPointNet2:
         dev = xyz.device
         level_xyz, level_n = geo["level_xyz"], geo["level_n"]
         n_launch = sum(len(sa["layers"]) for sa in self.sa) + \
-            sum(len(fp["layers"]) for fp in self.fp) + len(self.head_layers) + 1
+            sum(len(fp["layers"]) for fp in self.fp) + len(self.head_layers) + 1 + len(self.sa)
         amax = torch.zeros((n_launch, 64), dtype=torch.float32, device=dev)
         rows = iter(amax.unbind(0))
         level_feat = [(None, None)]                  # (tensor, amax row)
@@ -359,8 +372,16 @@ class FusedPointNet2:
             # in LDS); the first of the pair then reads through the MLP1 or the plain loader
             fuse2 = (K == 64 and len(layers) >= 3 and layers[-1].groups == 1 and
                      self._fusable(layers[-2], layers[-1]))
+            pre = sa["pre"] if self.precision == "f16x2" else None
+            if pre is not None:
+                # F = W_feat . features, one row per point of the level
+                fpre = torch.empty((B * level_n[li], layers[0].cout), dtype=torch.float32, device=dev)
+                fpre_amax = next(rows)
+                self._gemm("sa%d.0f" % li, pre["la"], B * level_n[li], LOAD_PLAIN, EPI_STORE, relu=False,
+                           out=fpre, ldc=layers[0].cout, A=feat, lda=feat.shape[1], a_amax=feat_amax,
+                           out_amax=fpre_amax)
             for l, layer in enumerate(layers):
-                if l == 0 and sa["mlp1"] is not None:
+                if l == 0 and (sa["mlp1"] is not None or pre is not None):
                     continue                      # folded into layer 1's loader
                 if fuse2 and l == len(layers) - 1:
                     continue                      # fused behind the previous layer's launch
@@ -375,6 +396,11 @@ class FusedPointNet2:
                     kw.update(gidx=gidx, xyz=level_xyz[li], ctr=ctr, N=level_n[li], M=M,
                               mlp1_w=sa["mlp1"], a_amax_floor=sa["mlp1_bound"])
                     loader = LOAD_GATHER_MLP1
+                elif l == 1 and pre is not None:
+                    kw.update(gidx=gidx, feat=fpre, Cf=layers[0].cout, xyz=level_xyz[li], ctr=ctr,
+                              N=level_n[li], M=M, mlp1_w=pre["w1"], a_amax=fpre_amax,
+                              a_amax_floor=pre["bound"])
+                    loader = LOAD_GATHER_ADD
                 elif l == 0:
                     kw.update(gidx=gidx, feat=feat, xyz=level_xyz[li], ctr=ctr, Cf=sa["cf"],
                               N=level_n[li], M=M, a_amax=feat_amax, a_amax_floor=sa["radius"])
