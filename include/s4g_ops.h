@@ -138,7 +138,7 @@ int s4g_three_interpolate_ws_f32(const float *feat_bcn2, const int64_t *idx_bn3,
 /* Fast path, FP levels: the first shared-MLP layer is linear, so it is applied to the sparse
  * features BEFORE the interpolation (and to the skip features separately); this call then
  * forms out[p][c] = act(y[p][c] + bias[c] + sum_k nw[p][k] * sparse[b*N2 + nidx[p][k]][c]) on
- * channels-last tensors (y may be NULL; C % 4 == 0, C divides 1024) and leaves max|out| in
+ * channels-last tensors (y may be NULL; C % 4 == 0, C <= 1024) and leaves max|out| in
  * out_amax64 (64 uint32 slots, zeroed by the caller; may be NULL).  No reference counterpart:
  * modules.py:122-128 interpolates first; the two orders agree to fp32 round-off. */
 int s4g_interp_add_cl_f32(const float *y_pc, const float *sparse_rc, const int32_t *nidx_p3,

@@ -456,7 +456,7 @@ extern "C" int s4g_interp_add_cl_f32(const float* y_pc, const float* sparse_rc, 
                                      const float* nw_p3, const float* bias_c, int64_t B, int64_t N1,
                                      int64_t N2, int64_t C, int relu, float* out_pc, float* out_amax64,
                                      s4g_stream_t stream) {
-  if (B < 0 || N1 < 0 || N2 <= 0 || C <= 0 || (C & 3) || C > 1024 || (1024 % C) != 0 ||
+  if (B < 0 || N1 < 0 || N2 <= 0 || C <= 0 || (C & 3) || C > 1024 ||
       N2 >= (1ll << 31) || N1 >= (1ll << 31))
     return S4G_EINVAL;
   if (B == 0 || N1 == 0) return S4G_OK;

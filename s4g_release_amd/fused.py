@@ -429,7 +429,7 @@ class FusedPointNet2:
                 l2 = fl[-1] if (fuse2 and l == len(fl) - 2) else None
                 out = torch.empty((P, (l2 or layer).cout), dtype=torch.float32, device=dev)
                 out_amax = next(rows)
-                if l == 0 and self.fp_linear_first and layer.cout % 4 == 0 and 1024 % layer.cout == 0:
+                if l == 0 and self.fp_linear_first and layer.cout % 4 == 0 and layer.cout <= 1024:
                     # the layer is linear: apply it to the sparse features (and to the skip
                     # features) first, interpolate the narrow result afterwards -- the big
                     # tensor's contraction shrinks from K = C2 + C1 to K = C1 (or vanishes)

@@ -324,6 +324,73 @@ def test_gemm_fused_layer_pair_rejects_unsupported(dev):
                   Cout2=64, relu2=1, **h2), dev)
 
 
+@pytest.mark.parametrize("Cin,Cout,epi,K", [(256, 256, 0, 64), (64, 160, 1, 32), (512, 512, 0, 64),
+                                            (128, 128, 1, 16)])
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_gemm_gather_add_loader(dev, Cin, Cout, epi, K, prec):
+    """First SA layer applied per point before the grouping: the loader gathers that row, adds
+    the xyz part + bias and applies the ReLU (A = relu(F[idx] + W_xyz . (xyz - ctr) + b))."""
+    g = torch.Generator(device="cpu").manual_seed(Cin + Cout + K)
+    B, N, M = 2, 300, 19
+    xyz = (torch.rand(B, 3, N, generator=g) * 0.2).to(dev)
+    cidx = torch.randint(0, N, (B, M), generator=g)
+    ctr = torch.stack([xyz[b][:, cidx[b]] for b in range(B)]).contiguous()
+    gidx = torch.randint(0, N, (B, M, K), generator=g).int().to(dev)
+    F = torch.randn(B * N, Cin, generator=g).to(dev)
+    w1 = torch.randn(Cin, 4, generator=g).to(dev)
+    W = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    P = B * M * K
+    rows = B * M if epi == 1 else P
+    out = torch.full((rows, Cout), float("nan"), device=dev)
+    Wp = _padk(W)
+    k16, w3 = _w3(W)
+    bound = float((w1[:, :3].abs().sum(1) * 0.4 + w1[:, 3].abs()).max())
+    h2 = _h2(W, F, floor=bound)
+    _run(dict(loader=4, epilogue=epi, groups=1, relu=1, P=P, Cin=Cin, Kpad=Wp.shape[1], Cout=Cout, W=Wp,
+              bias=b, gidx=gidx, feat=F, Cf=Cin, xyz=xyz, ctr=ctr, N=N, M=M, K=K, mlp1_w=w1, out=out,
+              ldc=Cout, precision=prec, Kpad16=k16, W_bf16x3=w3, **h2), dev)
+    rel = torch.stack([xyz[bi][:, gidx[bi].long()] - ctr[bi][:, :, None] for bi in range(B)])
+    rel = rel.permute(0, 2, 3, 1).reshape(P, 3).double()
+    rows_f = torch.cat([F.view(B, N, Cin)[bi][gidx[bi].long().reshape(-1)] for bi in range(B)]).double()
+    A = (rows_f + rel @ w1[:, :3].double().t() + w1[:, 3].double()).clamp_min(0)
+    ref = (A @ W.double().t() + b.double()).clamp_min(0)
+    if epi == 1:
+        ref = ref.view(B * M, K, Cout).max(dim=1)[0]
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("C,with_y,relu", [(256, True, 1), (512, False, 1), (36, True, 0), (1024, True, 1)])
+def test_interp_add_channels_last(dev, C, with_y, relu):
+    """out = act(y + bias + sum_k w_k * sparse[idx_k]) on channels-last tensors + its amax row."""
+    from s4g_release_amd import _cabi
+    g = torch.Generator(device="cpu").manual_seed(C)
+    B, N1, N2 = 3, 777, 50
+    sp = torch.randn(B * N2, C, generator=g).to(dev)
+    y = torch.randn(B * N1, C, generator=g).to(dev) if with_y else None
+    bias = torch.randn(C, generator=g).to(dev)
+    nidx = torch.randint(0, N2, (B, N1, 3), generator=g).int().to(dev)
+    nw = torch.rand(B, N1, 3, generator=g).to(dev)
+    out = torch.full((B * N1, C), float("nan"), device=dev)
+    amax = torch.zeros(64, device=dev)
+    rc = _cabi.lib().s4g_interp_add_cl_f32(None if y is None else y.data_ptr(), sp.data_ptr(),
+                                           nidx.data_ptr(), nw.data_ptr(), bias.data_ptr(), B, N1, N2, C,
+                                           relu, out.data_ptr(), amax.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream)
+    _cabi.check(rc, "interp_add")
+    torch.cuda.synchronize()
+    rows = torch.stack([sp.view(B, N2, C)[bi][nidx[bi].long()] for bi in range(B)])     # (B,N1,3,C)
+    ref = (rows.double() * nw.double()[..., None]).sum(dim=2).view(B * N1, C) + bias.double()
+    if y is not None:
+        ref = ref + y.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    assert (out.double() - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    assert amax.view(torch.int32).max().item() > 0
+    assert amax.max().item() >= out.abs().max().item()
+
+
 @pytest.mark.parametrize("prec", PRECISIONS)
 def test_gemm_interp_store(dev, prec):
     g = torch.Generator(device="cpu").manual_seed(5)
