@@ -280,6 +280,12 @@ typedef struct s4g_gemm_desc {
   const float *w2_inv_scale;
   const float *bias2;
   int32_t Cout2, relu2;
+  /* optional THIRD layer (then Cout2 == C: layer 2's output stays in LDS as well and the
+   * epilogue / out / ldc / out_amax describe layer 3, Cout3 % 64 == 0). */
+  const void *W3_f16x2_frag;
+  const float *w3_inv_scale;
+  const float *bias3;
+  int32_t Cout3, relu3;
 } s4g_gemm_desc_t;
 
 int s4g_mlp_gemm_f32(const s4g_gemm_desc_t *desc, s4g_stream_t stream);

@@ -40,6 +40,7 @@ class GemmDesc(ctypes.Structure):
         ("W_f16x2", _vp), ("w_inv_scale", _vp), ("a_amax", _vp), ("a_amax2", _vp),
         ("a_amax_floor", _f32), ("out_amax", _vp), ("W_f16x2_frag", _vp),
         ("W2_f16x2_frag", _vp), ("w2_inv_scale", _vp), ("bias2", _vp), ("Cout2", _i32), ("relu2", _i32),
+        ("W3_f16x2_frag", _vp), ("w3_inv_scale", _vp), ("bias3", _vp), ("Cout3", _i32), ("relu3", _i32),
     ]
 
 

@@ -101,6 +101,11 @@ struct GemmParams {
   const float* w_inv_scale2;
   const float* bias2;
   int Cout2, relu2;
+  // optional third layer of the chain (then layer 2 is as wide as layer 1 and also stays in LDS)
+  const uint16_t* Wfrag3;
+  const float* w_inv_scale3;
+  const float* bias3;
+  int Cout3, relu3;
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -1247,12 +1252,20 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
   constexpr size_t strip_stride = (size_t)CW * 2 * cb_stride;   // bytes between 128-channel strips
   const char* __restrict__ w1 = reinterpret_cast<const char*>(p.Wfrag + (size_t)g * p.Cout * K * 2) +
                                 (size_t)(wc_u * 2) * cb_stride;
-  const char* __restrict__ w2 = reinterpret_cast<const char*>(p.Wfrag2 + (size_t)g * p.Cout2 * K * 2) +
-                                (size_t)(wc_u * 2) * cb_stride;
-  const int nstrip2 = (p.Cout2 + 64 * CW - 1) / (64 * CW);
-  // a wave whose 64 channels lie past Cout2 (last, partial strip) sits phase 2 out; its ring
-  // must not prefetch W2 fragments that do not exist
-  const bool active0 = wc_u * 64 < p.Cout2;
+  // chain: layer 1 -> [layer 2 when a third layer follows] -> final layer (2 or 3)
+  const bool tri = p.Wfrag3 != nullptr;
+  const char* __restrict__ wmid = reinterpret_cast<const char*>(p.Wfrag2 + (size_t)g * p.Cout2 * K * 2) +
+                                  (size_t)(wc_u * 2) * cb_stride;
+  const int CoutF = tri ? p.Cout3 : p.Cout2;
+  const float* __restrict__ scF = (tri ? p.w_inv_scale3 : p.w_inv_scale2) + (size_t)g * CoutF;
+  const float* __restrict__ bgF = (tri ? p.bias3 : p.bias2) + (size_t)g * CoutF;
+  const char* __restrict__ w2 = tri ? reinterpret_cast<const char*>(p.Wfrag3 + (size_t)g * CoutF * K * 2) +
+                                          (size_t)(wc_u * 2) * cb_stride
+                                    : wmid;
+  const int nstrip2 = (CoutF + 64 * CW - 1) / (64 * CW);
+  // a wave whose 64 channels lie past the final Cout (last, partial strip) sits the final phase
+  // out; its ring must not prefetch fragments that do not exist
+  const bool active0 = wc_u * 64 < CoutF;
 
   uint4 ring[GR_RING][2][2];
 #pragma unroll
@@ -1355,15 +1368,23 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][PA], bf[1][PB], acc[1][1], 0, 0, 0);      \
   }
 
-  // ---- phase 1: H = relu(bn(W A)), 128 channels = one strip, operands swapped
+  // ---- panel phases: H = relu(bn(W A)), C channels = one strip, operands swapped
+  const char* wcur = w1;
+  const float* __restrict__ scp = p.w_inv_scale + (size_t)g * p.b_gstride;
+  const float* __restrict__ bp = p.bias + (size_t)g * p.b_gstride;
+  int relu_ph = p.relu;
+  float inv_in = inv_sa, inv_sh = 1.f;
+  const int npanel = tri ? 2 : 1;
+  for (int ph = 0; ph < npanel; ++ph) {
+  const char* wnxt = ph + 1 < npanel ? wmid : (active0 ? w2 : wcur);
   zero_acc();
   prime_a();
   {
     const int n = wc * 64 + lane;   // channel whose scale / bias this lane stages for its wave
-    epi_s[lane] = inv_sa * p.w_inv_scale[(size_t)g * p.b_gstride + n];
-    epi_s[64 + lane] = p.bias[(size_t)g * p.b_gstride + n];
+    epi_s[lane] = inv_in * scp[n];
+    epi_s[64 + lane] = bp[n];
   }
-  S4G_F2_STRIP(true, w1, (active0 ? w2 : w1))
+  S4G_F2_STRIP(true, wcur, wnxt)
   float tmax = 0.f;
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
@@ -1378,7 +1399,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float x = __fmaf_rn(acc[nb][pb][4 * j + e], scv[e], bv[e]);
-          if (p.relu) x = fmaxf(x, 0.f);
+          if (relu_ph) x = fmaxf(x, 0.f);
           acc[nb][pb][4 * j + e] = x;
           tmax = fmaxf(tmax, fabsf(x));
         }
@@ -1393,7 +1414,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
   exh = exh < 15u ? 15u : (exh > 240u ? 240u : exh);
   exh = __builtin_amdgcn_readfirstlane(exh);
   const float sh = __uint_as_float((268u - exh) << 23);
-  const float inv_sh = __uint_as_float((exh - 14u) << 23);
+  inv_sh = __uint_as_float((exh - 14u) << 23);
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -1409,21 +1430,28 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
         *reinterpret_cast<uint2*>(dst + aplane) = l;
       }
   __syncthreads();
+  // the next panel phase (three-layer chains) reads this panel through layer 2's weights
+  inv_in = inv_sh;
+  wcur = wmid;
+  scp = p.w_inv_scale2 + (size_t)g * p.Cout2;
+  bp = p.bias2 + (size_t)g * p.Cout2;
+  relu_ph = p.relu2;
+  }
 
   // ---- phase 2: the strip loop on the new panel, max over the 64 rows of a centroid
   GemmParams q = p;
-  q.Cout = p.Cout2;
-  q.relu = p.relu2;
+  q.Cout = CoutF;
+  q.relu = tri ? p.relu3 : p.relu2;
   zero_acc();
   prime_a();
   const char* wstrip = w2;
-  const float* __restrict__ bg2 = p.bias2 + (size_t)g * p.Cout2;
+  const float* __restrict__ bg2 = bgF;
   for (int strip = 0; strip < nstrip2; ++strip, wstrip += strip_stride) {
-    if ((strip * CW + wc_u) * 64 >= p.Cout2) break;
+    if ((strip * CW + wc_u) * 64 >= CoutF) break;
     const int n = (strip * CW + wc) * 64 + lane;
-    const float e_sc = inv_sh * p.w_inv_scale2[(size_t)g * p.Cout2 + n];
+    const float e_sc = inv_sh * scF[n];
     const float e_bias = bg2[n];
-    const char* wnext = ((strip + 1) * CW + wc_u) * 64 < p.Cout2 ? wstrip + strip_stride : wstrip;
+    const char* wnext = ((strip + 1) * CW + wc_u) * 64 < CoutF ? wstrip + strip_stride : wstrip;
     S4G_F2_STRIP(EPI2 == EPI_STORE, wstrip, wnext)
     const int n0 = (strip * CW + wc) * 64;
     float omax = 0.f;
@@ -1638,6 +1666,11 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   p.bias2 = d->bias2;
   p.Cout2 = d->Cout2;
   p.relu2 = d->relu2;
+  p.Wfrag3 = (const uint16_t*)d->W3_f16x2_frag;
+  p.w_inv_scale3 = d->w3_inv_scale;
+  p.bias3 = d->bias3;
+  p.Cout3 = d->Cout3;
+  p.relu3 = d->relu3;
   p.mtiles = (d->P + GM_BM - 1) / GM_BM;
   p.ntiles = (d->Cout + GM_BN - 1) / GM_BN;
   hipStream_t st = (hipStream_t)stream;
@@ -1682,6 +1715,8 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
     const bool store = d->epilogue == S4G_GEMM_EPI_STORE;
     if (!h2 || (!store && (d->epilogue != S4G_GEMM_EPI_MAX || d->K != 64 || (d->P & 63))) ||
         (!c128 && !c256) || d->Cout2 <= 0 || (d->Cout2 & 63) || (!store && d->groups != 1) || !d->W_f16x2_frag ||
+        (d->W3_f16x2_frag && (d->Cout2 != d->Cout || d->Cout3 <= 0 || (d->Cout3 & 63) || !d->w3_inv_scale ||
+                              !d->bias3)) ||
         !d->w2_inv_scale || !d->bias2 ||
         (store && (((d->ldc | d->c_coff | d->c_gcol) & 3) || ((uintptr_t)d->out & 15))))
       return S4G_EINVAL;

@@ -141,6 +141,7 @@ class FusedPointNet2:
         self.dense_streams = max(1, int(os.environ.get("S4G_DENSE_STREAMS", "1")))
         # S4G_GEMM_FUSE2=0: never fuse the last two layers of an SA level into one launch
         self.fuse2 = os.environ.get("S4G_GEMM_FUSE2", "1") != "0"
+        self.fuse3 = os.environ.get("S4G_GEMM_FUSE3", "1") != "0"   # + first head layer
         # S4G_FP_LINEAR_FIRST=0: interpolate first, like the reference (fused into the
         # contraction's loader); default: first FP layer before the interpolation
         self.fp_linear_first = os.environ.get("S4G_FP_LINEAR_FIRST", "1") != "0"
@@ -239,7 +240,7 @@ class FusedPointNet2:
                 l2.cout % 64 == 0 and l1.Wfrag is not None and l2.Wfrag is not None)
 
     # ------------------------------------------------------------------ launches
-    def _gemm(self, name, layer, P, loader, epi, relu=True, layer2=None, **kw):
+    def _gemm(self, name, layer, P, loader, epi, relu=True, layer2=None, layer3=None, **kw):
         d = GemmDesc()
         d.loader, d.epilogue, d.groups, d.relu = loader, epi, layer.groups, int(relu)
         d.P, d.Cin, d.Kpad, d.Cout = P, layer.cin, layer.kpad, layer.cout
@@ -262,6 +263,12 @@ class FusedPointNet2:
             d.Cout2, d.relu2 = layer2.cout, 1
             flops += 2.0 * P * layer2.cout * layer2.cin * layer2.groups
             name = "%s+%s" % (name, name[:-1] + str(int(name[-1]) + 1))
+        if layer3 is not None:   # ... and a third one (layer 2's output stays in LDS too)
+            d.W3_f16x2_frag = layer3.Wfrag.data_ptr()
+            d.w3_inv_scale, d.bias3 = layer3.w_inv_scale.data_ptr(), layer3.bias.data_ptr()
+            d.Cout3, d.relu3 = layer3.cout, 1
+            flops += 2.0 * P * layer3.cout * layer3.cin * layer3.groups
+            name += "+heads.0"
         with _F._timed("gemm[%s P=%d K=%d N=%dx%d]" % (name, P, layer.cin, layer.groups, layer.cout),
                        0, flops):
             rc = _cabi.lib().s4g_mlp_gemm_f32(ctypes.byref(d), _F._stream())
@@ -416,6 +423,7 @@ class FusedPointNet2:
 
         cur.wait_event(geo["done"])               # the 3-NN searches of the FP path
         (sparse_feat, sparse_amax), n_sparse = level_feat[-1], level_n[-1]
+        heads0_fused = False
         for fi, fp in enumerate(self.fp):
             (dense_feat, dense_amax), n_dense = level_feat[-2 - fi], level_n[-2 - fi]
             nidx, nw = geo["fp"][fi]
@@ -423,11 +431,18 @@ class FusedPointNet2:
             x = x_amax = None
             fl = fp["layers"]
             fuse2 = len(fl) >= 3 and self._fusable(fl[-2], fl[-1])
+            # last FP level: the first head layer (shared input, groups == 1) rides along as a
+            # third layer, so the per-point features never go through HBM before the heads
+            h0 = self.head_layers[0]
+            fuse3 = (fuse2 and fi == len(self.fp) - 1 and self.fuse3 and fl[-1].cout == fl[-2].cout and
+                     h0.groups == 1 and h0.cin == fl[-1].cout and h0.kpad16 == fl[-1].cout and
+                     h0.cout % 64 == 0 and h0.Wfrag is not None)
             for l, layer in enumerate(fl):
                 if fuse2 and l == len(fl) - 1:
                     continue                      # fused behind the previous layer's launch
                 l2 = fl[-1] if (fuse2 and l == len(fl) - 2) else None
-                out = torch.empty((P, (l2 or layer).cout), dtype=torch.float32, device=dev)
+                l3 = h0 if (fuse3 and l2 is not None) else None
+                out = torch.empty((P, (l3 or l2 or layer).cout), dtype=torch.float32, device=dev)
                 out_amax = next(rows)
                 if l == 0 and self.fp_linear_first and layer.cout % 4 == 0 and layer.cout <= 1024:
                     # the layer is linear: apply it to the sparse features (and to the skip
@@ -468,7 +483,8 @@ class FusedPointNet2:
                 else:
                     self._gemm("fp%d.%d" % (fi, l), layer, P, LOAD_PLAIN, EPI_STORE, out=out,
                                ldc=out.shape[1], A=x, lda=x.shape[1], a_amax=x_amax,
-                               out_amax=out_amax, layer2=l2)
+                               out_amax=out_amax, layer2=l2, layer3=l3)
+                    heads0_fused = l3 is not None
                 x, x_amax = out, out_amax
             sparse_feat, sparse_amax, n_sparse = x, x_amax, n_dense
 
@@ -476,11 +492,12 @@ class FusedPointNet2:
         P = B * N0
         x, x_amax = sparse_feat, sparse_amax
         l0 = self.head_layers[0]
-        h = torch.empty((P, l0.cout), dtype=torch.float32, device=dev)
-        h_amax = next(rows)
-        self._gemm("heads.0", l0, P, LOAD_PLAIN, EPI_STORE, out=h, ldc=l0.cout, A=x,
-                   lda=x.shape[1], a_amax=x_amax, out_amax=h_amax)
-        x, x_amax = h, h_amax
+        if not heads0_fused:
+            h = torch.empty((P, l0.cout), dtype=torch.float32, device=dev)
+            h_amax = next(rows)
+            self._gemm("heads.0", l0, P, LOAD_PLAIN, EPI_STORE, out=h, ldc=l0.cout, A=x,
+                       lda=x.shape[1], a_amax=x_amax, out_amax=h_amax)
+            x, x_amax = h, h_amax
         hl = self.head_layers
         l = 1
         while l < len(hl):
