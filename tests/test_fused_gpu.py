@@ -278,6 +278,34 @@ def test_gemm_fused_layer_pair(dev, C, Cout2, epi, groups, P):
     _check_out_amax(h2, out)
 
 
+@pytest.mark.parametrize("C,Cout3,epi,P", [(256, 2048, 0, 700), (128, 320, 0, 300), (256, 512, 1, 5 * 64)])
+def test_gemm_fused_three_layer_chain(dev, C, Cout3, epi, P):
+    """Three layers, one launch: two intermediates stay in LDS (C -> C -> C -> Cout3)."""
+    g = torch.Generator(device="cpu").manual_seed(C + Cout3)
+    A = torch.randn(P, C, generator=g).to(dev)
+    Ws = [(torch.randn(n, C, generator=g) / C ** 0.5).to(dev) for n in (C, C, Cout3)]
+    bs = [torch.randn(n, generator=g).to(dev) for n in (C, C, Cout3)]
+    K = 64
+    rows = P // K if epi == 1 else P
+    out = torch.full((rows, Cout3), float("nan"), device=dev)
+    k16, w3 = _w3(Ws[0])
+    h2 = _h2(Ws[0], A)
+    f2, i2 = _h2_second(Ws[1])
+    f3, i3 = _h2_second(Ws[2])
+    _run(dict(loader=0, epilogue=epi, groups=1, relu=1, P=P, Cin=C, Kpad=C, Cout=C, W=Ws[0], bias=bs[0],
+              A=A, lda=C, K=K, out=out, ldc=Cout3, precision=3, Kpad16=k16, W_bf16x3=w3,
+              W2_f16x2_frag=f2, w2_inv_scale=i2, bias2=bs[1], Cout2=C, relu2=1,
+              W3_f16x2_frag=f3, w3_inv_scale=i3, bias3=bs[2], Cout3=Cout3, relu3=1, **h2), dev)
+    ref = A.double()
+    for W, b in zip(Ws, bs):
+        ref = (ref @ W.double().t() + b.double()).clamp_min(0)
+    if epi == 1:
+        ref = ref.view(rows, K, Cout3).max(dim=1)[0]
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() < 4e-5 * max(1.0, ref.abs().max().item())
+    _check_out_amax(h2, out)
+
+
 def test_gemm_fused_layer_pair_mlp1_loader(dev):
     """The SA0 launch: xyz gather + first layer in the loader, two contractions, max."""
     g = torch.Generator(device="cpu").manual_seed(5)
@@ -659,8 +687,9 @@ def test_fused_equals_modules_random_configs(dev, seed):
 
 
 def test_fused_layer_pairs_match_layer_by_layer(dev, monkeypatch):
-    """The default (pairs fused into single launches) against S4G_GEMM_FUSE2=0 on the bench
-    architecture: same network outputs to fp32 round-off."""
+    """The default (layer chains fused into single launches, first SA / FP layers applied
+    before the grouping / interpolation) against the layer-by-layer, reference-order form
+    on the bench architecture: same network outputs to fp32 round-off."""
     from s4g_release_amd import synth
     from s4g_release_amd.fused import FusedPointNet2
     from s4g_release_amd.model import S4GConfig, build_pointnet2_cls, randomize_bn_
@@ -671,6 +700,8 @@ def test_fused_layer_pairs_match_layer_by_layer(dev, monkeypatch):
     pts = torch.from_numpy(synth.make_batch([0, 1], 25600)).to(dev)
     a = FusedPointNet2(net)({"scene_points": pts})
     monkeypatch.setenv("S4G_GEMM_FUSE2", "0")
+    monkeypatch.setenv("S4G_SA_LINEAR_FIRST", "0")
+    monkeypatch.setenv("S4G_FP_LINEAR_FIRST", "0")
     b = FusedPointNet2(net)({"scene_points": pts})
     for k in a:
         scale = max(1.0, b[k].abs().max().item())
