@@ -35,6 +35,8 @@
 
 #include "s4g_common.h"
 
+#include <type_traits>
+
 namespace s4g {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1218,7 +1220,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
 // amax round trip through HBM (a per-tile scale is as exact as the per-tensor one: both
 // are powers of two undone in the epilogue).
 // ---------------------------------------------------------------------------
-template <int LOADER, int EPI2, int RW>
+template <int LOADER, int EPI2, int RW, int KC>
 __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const GemmParams p) {
   // RW = 2: 128 positions, 128-wide layers; RW = 1: 64 positions, 256-wide layers
   constexpr int CW = 4 / RW, BM = 64 * RW, K = 64 * CW;
@@ -1250,8 +1252,12 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
   const uint32_t wf_lane = (uint32_t)lane * 16u;
   constexpr size_t cb_stride = (size_t)KS * 2048;               // bytes between n32 and n32 + 1
   constexpr size_t strip_stride = (size_t)CW * 2 * cb_stride;   // bytes between 128-channel strips
-  const char* __restrict__ w1 = reinterpret_cast<const char*>(p.Wfrag + (size_t)g * p.Cout * K * 2) +
-                                (size_t)(wc_u * 2) * cb_stride;
+  // layer 1 may contract over kchunks * K inputs: its panel is loaded K columns at a time and
+  // the accumulators run through all chunks before the first epilogue
+  constexpr int kchunks = KC;   // Kpad16 / K
+  const size_t cbs1 = (size_t)kchunks * cb_stride;              // layer 1's bytes between n32 blocks
+  const char* __restrict__ w1 = reinterpret_cast<const char*>(p.Wfrag + (size_t)g * p.Cout * p.Kpad16 * 2) +
+                                (size_t)(wc_u * 2) * cbs1;
   // chain: layer 1 -> [layer 2 when a third layer follows] -> final layer (2 or 3)
   const bool tri = p.Wfrag3 != nullptr;
   const char* __restrict__ wmid = reinterpret_cast<const char*>(p.Wfrag2 + (size_t)g * p.Cout2 * K * 2) +
@@ -1275,29 +1281,40 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl)
         ring[d][cb][pl] = *reinterpret_cast<const uint4*>(
-            w1 + ((size_t)cb * cb_stride + (size_t)(d * 2 + pl) * 1024) + wf_lane);
+            w1 + ((size_t)cb * cbs1 + (size_t)(d * 2 + pl) * 1024) + wf_lane);
 
-  {  // prologue: the loader's panel -> two fp16 planes in LDS
-    ALoader<LOADER, RPT, RS> ld;
-    ld.init(p, p0, g, t);
+  // (the loader's per-row state stays live through the first layer only when that layer is
+  // more than one panel deep: KC > 1)
+  ALoader<LOADER, RPT, RS> ld;
+  ld.init(p, p0, g, t);
+  // columns [kc * K, kc * K + K) of the loader's rows -> two fp16 planes.  DEPTH K-tiles of
+  // loads are in flight at a time: the whole panel in the prologue (one round trip), two
+  // tiles for the later chunks of a deep first layer (accumulators and ring are live then)
+  auto load_panel = [&](int kc, auto depth_tag) {
+    constexpr int DEPTH = decltype(depth_tag)::value;
     const int chunk = t & 7, srow = t >> 3;
     constexpr int NKT = K / 32;
-    float4 ra[NKT][RPT];
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+    for (int kt0 = 0; kt0 < NKT; kt0 += DEPTH) {
+      float4 ra[DEPTH][RPT];
 #pragma unroll
-      for (int s = 0; s < RPT; ++s) ra[kt][s] = ld.load(p, s, kt * 32 + chunk * 4, t);
+      for (int kt = 0; kt < DEPTH; ++kt)
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+        for (int s = 0; s < RPT; ++s) ra[kt][s] = ld.load(p, s, kc * K + (kt0 + kt) * 32 + chunk * 4, t);
 #pragma unroll
-      for (int s = 0; s < RPT; ++s) {
-        uint2 h, l;
-        split2_h<false>(ra[kt][s], sa, h, l);
-        uint16_t* dst = Ah + (srow + RS * s) * astr + kt * 32 + chunk * 4;
-        *reinterpret_cast<uint2*>(dst) = h;
-        *reinterpret_cast<uint2*>(dst + aplane) = l;
-      }
-  }
+      for (int kt = 0; kt < DEPTH; ++kt)
+#pragma unroll
+        for (int s = 0; s < RPT; ++s) {
+          uint2 h, l;
+          split2_h<false>(ra[kt][s], sa, h, l);
+          uint16_t* dst = Ah + (srow + RS * s) * astr + (kt0 + kt) * 32 + chunk * 4;
+          *reinterpret_cast<uint2*>(dst) = h;
+          *reinterpret_cast<uint2*>(dst + aplane) = l;
+        }
+      if (DEPTH < NKT) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  load_panel(0, std::integral_constant<int, K / 32>{});
   __syncthreads();
 
   const uint16_t* a_lane = Ah + (wr * 64 + li) * astr + 8 * lh;
@@ -1323,7 +1340,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
 
   // one 128-deep strip: 8 steps of 12 MFMAs; W fragments through the ring, refilled RING
   // steps ahead from this strip (wcur) or the next one (wnext)
-#define S4G_F2_STRIP(SWAPPED, wcur, wnext)                                                             \
+#define S4G_F2_STRIP(SWAPPED, wcur, cbs_cur, wnext, cbs_next)                                                             \
   _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                  \
     const int d = ks % GR_RING;                                                                        \
     const int ksn = ks + 1 == KS ? 0 : ks + 1;                                                         \
@@ -1338,10 +1355,11 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
     {                                                                                                  \
       const int kr = ks + GR_RING;                                                                     \
       const char* src = kr < KS ? (wcur) : (wnext);                                                    \
+      const size_t cbs = kr < KS ? (cbs_cur) : (cbs_next);                                             \
       const int kk = kr < KS ? kr : kr - KS;                                                           \
       _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) \
         ring[d][cb][pl] = *reinterpret_cast<const uint4*>(                                             \
-            src + ((size_t)cb * cb_stride + (size_t)(kk * 2 + pl) * 1024) + wf_lane);                  \
+            src + ((size_t)cb * cbs + (size_t)(kk * 2 + pl) * 1024) + wf_lane);                        \
     }                                                                                                  \
     S4G_F2_TERM(SWAPPED, 0, 1)                                                                         \
     S4G_F2_TERM(SWAPPED, 1, 0)                                                                         \
@@ -1384,7 +1402,24 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
     epi_s[lane] = inv_in * scp[n];
     epi_s[64 + lane] = bp[n];
   }
-  S4G_F2_STRIP(true, wcur, wnxt)
+  if (KC > 1 && ph == 0) {
+    // layer 1: every K-column chunk of the loader's rows through the same accumulators
+    for (int kc = 0; kc < kchunks; ++kc) {
+      if (kc > 0) {
+        __syncthreads();      // everybody is done reading the previous chunk's panel
+        load_panel(kc, std::integral_constant<int, 2>{});
+        __syncthreads();
+        prime_a();
+      }
+      const char* wc1 = w1 + (size_t)kc * cb_stride;           // this chunk's 16 steps of each n32 block
+      const bool lastc = kc + 1 == kchunks;
+      const char* wn1 = lastc ? wnxt : wc1 + cb_stride;
+      const size_t cbsn = lastc ? cb_stride : cbs1;
+      S4G_F2_STRIP(true, wc1, cbs1, wn1, cbsn)
+    }
+  } else {
+    S4G_F2_STRIP(true, wcur, cb_stride, wnxt, cb_stride)
+  }
   float tmax = 0.f;
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
@@ -1452,7 +1487,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
     const float e_sc = inv_sh * scF[n];
     const float e_bias = bg2[n];
     const char* wnext = ((strip + 1) * CW + wc_u) * 64 < CoutF ? wstrip + strip_stride : wstrip;
-    S4G_F2_STRIP(EPI2 == EPI_STORE, wstrip, wnext)
+    S4G_F2_STRIP(EPI2 == EPI_STORE, wstrip, cb_stride, wnext, cb_stride)
     const int n0 = (strip * CW + wc) * 64;
     float omax = 0.f;
     if constexpr (EPI2 == EPI_STORE) {
@@ -1518,17 +1553,17 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
 #undef S4G_F2_TERM
 }
 
-template <int LOADER, int EPI2, int RW>
+template <int LOADER, int EPI2, int RW, int KC>
 static int launch_gemm_f16x2_fused2(const GemmParams& p, int groups, hipStream_t st) {
   constexpr int BM = 64 * RW, K = 64 * (4 / RW);
   constexpr size_t lds = sizeof(uint16_t) * 2 * BM * (size_t)(K + 8) + sizeof(float) * (4 * 128 + 16);
   static_assert(lds <= 80 * 1024, "two workgroups per CU");
   static const hipError_t attr = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&mlp_gemm_f16x2_fused2_kernel<LOADER, EPI2, RW>),
+      reinterpret_cast<const void*>(&mlp_gemm_f16x2_fused2_kernel<LOADER, EPI2, RW, KC>),
       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr != hipSuccess) return (int)attr;
   const dim3 grid((unsigned)((p.P + BM - 1) / BM), (unsigned)groups);
-  hipLaunchKernelGGL((mlp_gemm_f16x2_fused2_kernel<LOADER, EPI2, RW>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((mlp_gemm_f16x2_fused2_kernel<LOADER, EPI2, RW, KC>), grid, dim3(256), lds, st, p);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }
@@ -1711,7 +1746,9 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   if (d->W2_f16x2_frag) {
     // two fused layers: K = C -> C -> Cout2 with C = 128 (128 positions per workgroup) or
     // C = 256 (64 positions), epilogue MAX (K == 64 neighbours) or STORE
-    const bool c128 = d->Kpad16 == 128 && d->Cout == 128, c256 = d->Kpad16 == 256 && d->Cout == 256;
+    // layer 1 may be one or two panels deep (Kpad16 = C or 2 C)
+    const bool c128 = d->Cout == 128 && d->Kpad16 == 128,
+               c256 = d->Cout == 256 && (d->Kpad16 == 256 || d->Kpad16 == 512);
     const bool store = d->epilogue == S4G_GEMM_EPI_STORE;
     if (!h2 || (!store && (d->epilogue != S4G_GEMM_EPI_MAX || d->K != 64 || (d->P & 63))) ||
         (!c128 && !c256) || d->Cout2 <= 0 || (d->Cout2 & 63) || (!store && d->groups != 1) || !d->W_f16x2_frag ||
@@ -1720,16 +1757,18 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
         !d->w2_inv_scale || !d->bias2 ||
         (store && (((d->ldc | d->c_coff | d->c_gcol) & 3) || ((uintptr_t)d->out & 15))))
       return S4G_EINVAL;
-#define S4G_FUSED2_CASE(L, E, R)                                    \
-  if (d->loader == L && (int)d->epilogue == (int)E && (c128 ? 2 : 1) == R) \
-    return launch_gemm_f16x2_fused2<L, E, R>(p, d->groups, st);
-    S4G_FUSED2_CASE(LOAD_GATHER_MLP1, EPI_MAX, 2)
-    S4G_FUSED2_CASE(LOAD_GATHER_ADD, EPI_MAX, 2)
-    S4G_FUSED2_CASE(LOAD_GATHER_ADD, EPI_MAX, 1)
-    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_MAX, 2)
-    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_MAX, 1)
-    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_STORE, 1)
-    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_STORE, 2)
+#define S4G_FUSED2_CASE(L, E, R, KCH)                                                        \
+  if (d->loader == L && (int)d->epilogue == (int)E && (c128 ? 2 : 1) == R &&                  \
+      d->Kpad16 / d->Cout == KCH)                                                             \
+    return launch_gemm_f16x2_fused2<L, E, R, KCH>(p, d->groups, st);
+    S4G_FUSED2_CASE(LOAD_GATHER_MLP1, EPI_MAX, 2, 1)
+    S4G_FUSED2_CASE(LOAD_GATHER_ADD, EPI_MAX, 2, 1)
+    S4G_FUSED2_CASE(LOAD_GATHER_ADD, EPI_MAX, 1, 1)
+    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_MAX, 2, 1)
+    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_MAX, 1, 1)
+    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_STORE, 1, 1)
+    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_STORE, 2, 1)
+    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_STORE, 1, 2)     // first layer two panels deep (512 -> 256 -> ...)
 #undef S4G_FUSED2_CASE
     return S4G_EUNSUPPORTED;
   }

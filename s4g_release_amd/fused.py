@@ -232,15 +232,18 @@ class FusedPointNet2:
         self.sigmoid_from = sum(chans[:3])
         self._streams = None
 
-    def _fusable(self, l1, l2):
-        """Two consecutive layers one launch can take (mlp_gemm_f16x2_fused2_kernel)."""
+    def _fusable(self, l1, l2, deep_first=False):
+        """Two consecutive layers one launch can take (mlp_gemm_f16x2_fused2_kernel);
+        deep_first: the first layer may contract over 2 C inputs (plain loader, store epilogue)."""
         c = l1.cout
+        k1_ok = l1.kpad16 == c or (deep_first and c == 256 and l1.kpad16 == 512 and self.fuse3)
         return (self.precision == "f16x2" and self.fuse2 and c in (128, 256) and
-                l1.groups == l2.groups and l1.kpad16 == c and l2.cin == c and l2.kpad16 == c and
+                l1.groups == l2.groups and k1_ok and l2.cin == c and l2.kpad16 == c and
                 l2.cout % 64 == 0 and l1.Wfrag is not None and l2.Wfrag is not None)
 
     # ------------------------------------------------------------------ launches
-    def _gemm(self, name, layer, P, loader, epi, relu=True, layer2=None, layer3=None, **kw):
+    def _gemm(self, name, layer, P, loader, epi, relu=True, layer2=None, layer3=None, name3="heads.0",
+              **kw):
         d = GemmDesc()
         d.loader, d.epilogue, d.groups, d.relu = loader, epi, layer.groups, int(relu)
         d.P, d.Cin, d.Kpad, d.Cout = P, layer.cin, layer.kpad, layer.cout
@@ -268,7 +271,7 @@ class FusedPointNet2:
             d.w3_inv_scale, d.bias3 = layer3.w_inv_scale.data_ptr(), layer3.bias.data_ptr()
             d.Cout3, d.relu3 = layer3.cout, 1
             flops += 2.0 * P * layer3.cout * layer3.cin * layer3.groups
-            name += "+heads.0"
+            name += "+" + name3
         with _F._timed("gemm[%s P=%d K=%d N=%dx%d]" % (name, P, layer.cin, layer.groups, layer.cout),
                        0, flops):
             rc = _cabi.lib().s4g_mlp_gemm_f32(ctypes.byref(d), _F._stream())
@@ -502,16 +505,23 @@ class FusedPointNet2:
         l = 1
         while l < len(hl):
             layer = hl[l]
-            # two consecutive grouped layers as one launch where the widths allow it
-            l2 = hl[l + 1] if (l + 1 < len(hl) and self._fusable(layer, hl[l + 1])) else None
-            cout = (l2 or layer).cout
+            # two or three consecutive grouped layers as one launch where the widths allow it
+            l2 = hl[l + 1] if (l + 1 < len(hl) and self._fusable(layer, hl[l + 1], deep_first=True)) else None
+            l3 = None
+            if (l2 is not None and self.fuse3 and l + 2 < len(hl) and l2.cout == layer.cout and
+                    self._fusable(l2, hl[l + 2])):
+                l3 = hl[l + 2]
+            if l2 is not None and l3 is None and layer.kpad16 != layer.cout:
+                l2 = None                # a deep first layer only as part of a three-layer chain
+            cout = (l3 or l2 or layer).cout
             h = torch.empty((P, layer.groups * cout), dtype=torch.float32, device=dev)
             h_amax = next(rows)
             self._gemm("heads.%d" % l, layer, P, LOAD_PLAIN, EPI_STORE, out=h,
                        ldc=layer.groups * cout, c_gcol=cout, A=x, lda=x.shape[1],
-                       a_gcol=layer.cin, a_amax=x_amax, out_amax=h_amax, layer2=l2)
+                       a_gcol=layer.cin, a_amax=x_amax, out_amax=h_amax, layer2=l2, layer3=l3,
+                       name3="heads.%d" % (l + 2))
             x, x_amax = h, h_amax
-            l += 2 if l2 is not None else 1
+            l += 3 if l3 is not None else (2 if l2 is not None else 1)
         names = ("score", "frame_R", "frame_t", "movable_logits")
         outs = [torch.empty((B, c, N0), dtype=torch.float32, device=dev)
                 for c in self.head_channels]

@@ -306,6 +306,37 @@ def test_gemm_fused_three_layer_chain(dev, C, Cout3, epi, P):
     _check_out_amax(h2, out)
 
 
+@pytest.mark.parametrize("groups,P,Cout3", [(4, 333, 128), (1, 1000, 256)])
+def test_gemm_fused_chain_deep_first_layer(dev, groups, P, Cout3):
+    """Head layers 1 + 2 + 3: the first layer contracts over 2 C = 512 inputs (two panel
+    loads through the same accumulators), then two more layers; four column groups."""
+    C, K1 = 256, 512
+    g = torch.Generator(device="cpu").manual_seed(groups + P)
+    A = torch.randn(P, groups * K1, generator=g).to(dev)
+    W1 = (torch.randn(groups, C, K1, generator=g) / K1 ** 0.5).to(dev)
+    W2 = (torch.randn(groups, C, C, generator=g) / C ** 0.5).to(dev)
+    W3 = (torch.randn(groups, Cout3, C, generator=g) / C ** 0.5).to(dev)
+    b1, b2, b3 = (torch.randn(groups, n, generator=g).to(dev) for n in (C, C, Cout3))
+    out = torch.full((P, groups * Cout3), float("nan"), device=dev)
+    k16, w3 = _w3(W1)
+    h2 = _h2(W1, A)
+    f2, i2 = _h2_second(W2)
+    f3, i3 = _h2_second(W3)
+    _run(dict(loader=0, epilogue=0, groups=groups, relu=1, P=P, Cin=K1, Kpad=K1, Cout=C, W=W1, bias=b1,
+              w_gstride=C * K1, b_gstride=C, A=A, lda=groups * K1, a_gcol=K1, out=out,
+              ldc=groups * Cout3, c_gcol=Cout3, precision=3, Kpad16=k16, W_bf16x3=w3,
+              W2_f16x2_frag=f2, w2_inv_scale=i2, bias2=b2, Cout2=C, relu2=1,
+              W3_f16x2_frag=f3, w3_inv_scale=i3, bias3=b3, Cout3=Cout3, relu3=1, **h2), dev)
+    ref = []
+    for gi in range(groups):
+        h = (A[:, gi * K1:(gi + 1) * K1].double() @ W1[gi].double().t() + b1[gi].double()).clamp_min(0)
+        h = (h @ W2[gi].double().t() + b2[gi].double()).clamp_min(0)
+        ref.append((h @ W3[gi].double().t() + b3[gi].double()).clamp_min(0))
+    ref = torch.cat(ref, dim=1)
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() < 4e-5 * max(1.0, ref.abs().max().item())
+
+
 def test_gemm_fused_layer_pair_mlp1_loader(dev):
     """The SA0 launch: xyz gather + first layer in the loader, two contractions, max."""
     g = torch.Generator(device="cpu").manual_seed(5)
