@@ -1762,6 +1762,7 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
       d->Kpad16 / d->Cout == KCH)                                                             \
     return launch_gemm_f16x2_fused2<L, E, R, KCH>(p, d->groups, st);
     S4G_FUSED2_CASE(LOAD_GATHER_MLP1, EPI_MAX, 2, 1)
+    S4G_FUSED2_CASE(LOAD_GATHER_MLP1, EPI_MAX, 1, 1)
     S4G_FUSED2_CASE(LOAD_GATHER_ADD, EPI_MAX, 2, 1)
     S4G_FUSED2_CASE(LOAD_GATHER_ADD, EPI_MAX, 1, 1)
     S4G_FUSED2_CASE(LOAD_PLAIN, EPI_MAX, 2, 1)

@@ -717,6 +717,44 @@ def test_fused_equals_modules_random_configs(dev, seed):
             assert (a[k] - b[k]).abs().max().item() < TOL * scale, (k, precision, cfg)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_fused_equals_modules_chain_widths(dev, seed):
+    """Random architectures whose widths are 128 / 256 (so the two- and three-layer chain
+    launches, the deep first head layer and both linear-first restructurings all engage) on
+    odd cloud sizes (ragged last tiles): fast path == reference-shaped modules path."""
+    from s4g_release_amd import synth
+    from s4g_release_amd.fused import FusedPointNet2
+    from s4g_release_amd.model import PointNet2, randomize_bn_
+    rng = np.random.default_rng(500 + seed)
+    n_pts = int(rng.integers(1500, 2600)) | 1
+    m1 = int(rng.integers(300, 500)) | 1
+    m2 = int(rng.integers(64, 140)) | 1
+    m3 = int(rng.integers(12, 30))
+    w = lambda: int(rng.choice([128, 256]))      # noqa: E731
+    c0, c1 = w(), w()
+    sa = ((c0, c0, c0 * int(rng.choice([1, 2]))), (c1, c1, c1 * int(rng.choice([1, 2]))), (64, 96, 160))
+    f2 = w()
+    fp = ((192, 160), (f2 * 2, f2 * 2), (f2, f2, f2))
+    h = 256
+    cfg = dict(score_classes=3, num_centroids=(m1, m2, m3), radius=(0.05, 0.12, 0.4),
+               num_neighbours=(64, 64, int(rng.choice([16, 32]))), sa_channels=sa, fp_channels=fp,
+               num_fp_neighbours=(3, 3, 3), seg_channels=(2 * h, h, h, int(rng.choice([64, 128]))),
+               num_removal_directions=5, dropout_prob=0.5)
+    if f2 != h:
+        cfg["fp_channels"] = ((192, 160), (f2 * 2, f2 * 2), (h, h, h))
+    torch.manual_seed(seed)
+    net = randomize_bn_(PointNet2(**cfg), seed + 70).to(dev).eval()
+    variant = ["tabletop-v1", "dup-heavy", "uniform-box"][seed % 3]
+    pts = torch.from_numpy(synth.make_batch([seed, seed + 3][: 1 + seed % 2], n_pts, variant=variant)).to(dev)
+    with torch.no_grad():
+        a = net({"scene_points": pts})
+    fused = FusedPointNet2(net)
+    b = fused({"scene_points": pts})
+    for k in a:
+        scale = max(1.0, float(a[k].abs().max()))
+        assert (a[k] - b[k]).abs().max().item() < TOL * scale, (k, cfg)
+
+
 def test_fused_layer_pairs_match_layer_by_layer(dev, monkeypatch):
     """The default (layer chains fused into single launches, first SA / FP layers applied
     before the grouping / interpolation) against the layer-by-layer, reference-order form
