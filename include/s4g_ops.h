@@ -183,6 +183,11 @@ int s4g_interp_weights_f32(const float *d2_bn3, int64_t B, int64_t N1,
  *                                A row p = relu(F[b*N + gidx[p]] + W_xyz . (xyz - ctr) + b1),
  *                                mlp1_w = Cin x (wx, wy, wz, bias); a_amax bounds |F| and
  *                                a_amax_floor the xyz + bias part (the two are ADDED)
+ *         S4G_GEMM_LOAD_INTERP_ADD  first FP layer applied before the interpolation (linear):
+ *                                A row p = relu(dense[p] + loader_bias + sum_k nw[p,k] *
+ *                                sparse[b*N2 + nidx[p,k]]), sparse = W_a . sparse features and
+ *                                dense = W_b . skip features (or NULL), both (rows, C2 = Cin);
+ *                                a_amax / a_amax2 / a_amax_floor bound the three terms (ADDED)
  * epilogue S4G_GEMM_EPI_STORE   out[p*ldc + c_coff + g*c_gcol + n]
  *          S4G_GEMM_EPI_MAX     out[(p/K)*ldc + c_coff + n] = max over the K
  *                               consecutive rows of a group (K in 16,32,64)
@@ -197,6 +202,7 @@ int s4g_interp_weights_f32(const float *d2_bn3, int64_t B, int64_t N1,
 #define S4G_GEMM_LOAD_INTERP 2
 #define S4G_GEMM_LOAD_GATHER_MLP1 3
 #define S4G_GEMM_LOAD_GATHER_ADD 4
+#define S4G_GEMM_LOAD_INTERP_ADD 5
 #define S4G_GEMM_EPI_STORE 0
 #define S4G_GEMM_EPI_MAX 1
 #define S4G_GEMM_EPI_CHANNEL_FIRST 2
@@ -288,6 +294,7 @@ typedef struct s4g_gemm_desc {
   const float *w3_inv_scale;
   const float *bias3;
   int32_t Cout3, relu3;
+  const float *loader_bias; /* S4G_GEMM_LOAD_INTERP_ADD: Cin floats */
 } s4g_gemm_desc_t;
 
 int s4g_mlp_gemm_f32(const s4g_gemm_desc_t *desc, s4g_stream_t stream);

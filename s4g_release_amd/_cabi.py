@@ -41,6 +41,7 @@ class GemmDesc(ctypes.Structure):
         ("a_amax_floor", _f32), ("out_amax", _vp), ("W_f16x2_frag", _vp),
         ("W2_f16x2_frag", _vp), ("w2_inv_scale", _vp), ("bias2", _vp), ("Cout2", _i32), ("relu2", _i32),
         ("W3_f16x2_frag", _vp), ("w3_inv_scale", _vp), ("bias3", _vp), ("Cout3", _i32), ("relu3", _i32),
+        ("loader_bias", _vp),
     ]
 
 

@@ -47,7 +47,8 @@ constexpr int GM_BK = 32;
 constexpr int GM_LDS = 36;  // padded row stride (floats)
 constexpr int GM_THREADS = 256;
 
-enum { LOAD_PLAIN = 0, LOAD_GATHER = 1, LOAD_INTERP = 2, LOAD_GATHER_MLP1 = 3, LOAD_GATHER_ADD = 4 };
+enum { LOAD_PLAIN = 0, LOAD_GATHER = 1, LOAD_INTERP = 2, LOAD_GATHER_MLP1 = 3, LOAD_GATHER_ADD = 4,
+       LOAD_INTERP_ADD = 5 };
 enum { EPI_STORE = 0, EPI_MAX = 1, EPI_CHANNEL_FIRST = 2 };
 
 struct GemmParams {
@@ -98,6 +99,7 @@ struct GemmParams {
   float a_amax_floor;
   uint32_t* out_amax;          // 64 slots or NULL
   const uint16_t* Wfrag;       // f16x2 planes in MFMA-fragment order (resident-A kernel) or NULL
+  const float* lbias;          // INTERP_ADD loader: bias of the layer whose output the loader forms
   // fused second layer (mlp_gemm_f16x2_fused2_kernel): out = max_K relu(bn(W2 relu(bn(W A))))
   const uint16_t* Wfrag2;
   const float* w_inv_scale2;
@@ -170,7 +172,7 @@ struct ALoader {
           rel[s][1] = __fsub_rn(x[p.N + j], c[p.M + m]);
           rel[s][2] = __fsub_rn(x[2 * p.N + j], c[2 * p.M + m]);
         }
-      } else {
+      } else {   // INTERP, INTERP_ADD
         const int b = pp / p.N1;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -210,6 +212,27 @@ struct ALoader {
         const float4 w = p.mlp1[k0 + e];
         const float v = __fmaf_rn(w.z, rel[s][2], __fmaf_rn(w.y, rel[s][1], __fmaf_rn(w.x, rel[s][0], w.w)));
         rp[e] = fmaxf(__fadd_rn(fv[e], v), 0.f);
+      }
+      return r;
+    } else if constexpr (LOADER == LOAD_INTERP_ADD) {
+      // first FP layer applied before the interpolation: A = relu(y + bias + sum_k w_k S[idx_k])
+      if (k0 >= p.Cin) return f4zero();
+      const float4 a = *reinterpret_cast<const float4*>(p.sparse + (size_t)i3[s][0] * p.C2 + k0);
+      const float4 b = *reinterpret_cast<const float4*>(p.sparse + (size_t)i3[s][1] * p.C2 + k0);
+      const float4 c = *reinterpret_cast<const float4*>(p.sparse + (size_t)i3[s][2] * p.C2 + k0);
+      const float4 bb = *reinterpret_cast<const float4*>(p.lbias + k0);
+      float4 y = f4zero();
+      if (p.dense) y = *reinterpret_cast<const float4*>(p.dense + drow[s] * p.C2 + k0);
+      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, cv[4] = {c.x, c.y, c.z, c.w};
+      const float yv[4] = {y.x, y.y, y.z, y.w}, bi[4] = {bb.x, bb.y, bb.z, bb.w};
+      float4 r;
+      float* rp = reinterpret_cast<float*>(&r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float acc = __fmul_rn(av[e], w3[s][0]);
+        acc = __fadd_rn(acc, __fmul_rn(bv[e], w3[s][1]));
+        acc = __fadd_rn(acc, __fmul_rn(cv[e], w3[s][2]));
+        rp[e] = fmaxf(__fadd_rn(__fadd_rn(yv[e], acc), bi[e]), 0.f);   // same order as interp_add_cl_kernel
       }
       return r;
     } else if constexpr (LOADER == LOAD_GATHER) {
@@ -554,7 +577,7 @@ __device__ __forceinline__ void split3_frag(const float4 lo, const float4 hi, bf
 }
 
 template <int LOADER, int EPI, int NS, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, (NS == 1 && WAVES == 4 && LOADER != LOAD_INTERP) ? 3 : (NS == 1 ? WAVES / 2 : 1)) void mlp_gemm_bf16x3_kernel(const GemmParams p) {
+__global__ __launch_bounds__(64 * WAVES, (NS == 1 && WAVES == 4 && LOADER != LOAD_INTERP && LOADER != LOAD_INTERP_ADD) ? 3 : (NS == 1 ? WAVES / 2 : 1)) void mlp_gemm_bf16x3_kernel(const GemmParams p) {
   constexpr int THREADS = 64 * WAVES;
   constexpr int WC = WAVES / 2;          // column strips (wave grid is 2 x WC)
   constexpr int NCB = 4 / WC;            // 32-wide column blocks per wave
@@ -752,7 +775,7 @@ __device__ __forceinline__ float amax_slots(const float* __restrict__ slots, int
 // LDS and L1 traffic per MFMA and twice the matrix work per barrier; used when
 // Cout > 128.
 template <int LOADER, int EPI, int NCB>
-__global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP) ? 2 : 3) void mlp_gemm_f16x2_kernel(
+__global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP || LOADER == LOAD_INTERP_ADD) ? 2 : 3) void mlp_gemm_f16x2_kernel(
     const GemmParams p) {
   constexpr int BN = 64 * NCB;
   constexpr int RPT = 4, RS = 32, WPT = BN / 64, WRS = 64, BK = 32;
@@ -781,9 +804,9 @@ __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP) ? 2 : 3) v
 
   // activation scale: the power of two that puts the tensor maximum in [2^14, 2^15)
   float amax = p.a_amax_floor;
-  if (p.a_amax) amax = LOADER == LOAD_GATHER_ADD ? amax + amax_slots(p.a_amax, lane)   // |F + xyz part|
-                                                 : fmaxf(amax, amax_slots(p.a_amax, lane));
-  if (p.a_amax2) amax = fmaxf(amax, amax_slots(p.a_amax2, lane));
+  constexpr bool ADD_BOUNDS = LOADER == LOAD_GATHER_ADD || LOADER == LOAD_INTERP_ADD;   // the loader SUMS its inputs
+  if (p.a_amax) amax = ADD_BOUNDS ? amax + amax_slots(p.a_amax, lane) : fmaxf(amax, amax_slots(p.a_amax, lane));
+  if (p.a_amax2) amax = ADD_BOUNDS ? amax + amax_slots(p.a_amax2, lane) : fmaxf(amax, amax_slots(p.a_amax2, lane));
   uint32_t ex = __float_as_uint(amax) >> 23;
   ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
   ex = __builtin_amdgcn_readfirstlane(ex);
@@ -984,9 +1007,9 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
   const float* __restrict__ wsc = p.w_inv_scale + (size_t)g * p.b_gstride;
 
   float amax = p.a_amax_floor;
-  if (p.a_amax) amax = LOADER == LOAD_GATHER_ADD ? amax + amax_slots(p.a_amax, lane)   // |F + xyz part|
-                                                 : fmaxf(amax, amax_slots(p.a_amax, lane));
-  if (p.a_amax2) amax = fmaxf(amax, amax_slots(p.a_amax2, lane));
+  constexpr bool ADD_BOUNDS = LOADER == LOAD_GATHER_ADD || LOADER == LOAD_INTERP_ADD;   // the loader SUMS its inputs
+  if (p.a_amax) amax = ADD_BOUNDS ? amax + amax_slots(p.a_amax, lane) : fmaxf(amax, amax_slots(p.a_amax, lane));
+  if (p.a_amax2) amax = ADD_BOUNDS ? amax + amax_slots(p.a_amax2, lane) : fmaxf(amax, amax_slots(p.a_amax2, lane));
   uint32_t ex = __float_as_uint(amax) >> 23;
   ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
   ex = __builtin_amdgcn_readfirstlane(ex);
@@ -1237,9 +1260,9 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
   const int p0 = blockIdx.x * BM;
 
   float amax = p.a_amax_floor;
-  if (p.a_amax) amax = LOADER == LOAD_GATHER_ADD ? amax + amax_slots(p.a_amax, lane)   // |F + xyz part|
-                                                 : fmaxf(amax, amax_slots(p.a_amax, lane));
-  if (p.a_amax2) amax = fmaxf(amax, amax_slots(p.a_amax2, lane));
+  constexpr bool ADD_BOUNDS = LOADER == LOAD_GATHER_ADD || LOADER == LOAD_INTERP_ADD;   // the loader SUMS its inputs
+  if (p.a_amax) amax = ADD_BOUNDS ? amax + amax_slots(p.a_amax, lane) : fmaxf(amax, amax_slots(p.a_amax, lane));
+  if (p.a_amax2) amax = ADD_BOUNDS ? amax + amax_slots(p.a_amax2, lane) : fmaxf(amax, amax_slots(p.a_amax2, lane));
   uint32_t ex = __float_as_uint(amax) >> 23;
   ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
   ex = __builtin_amdgcn_readfirstlane(ex);
@@ -1592,7 +1615,7 @@ static int launch_gemm_f16x2(const GemmParams& p, int groups, hipStream_t st) {
   const char* rmode = getenv("S4G_GEMM_RESIDENT");
   const bool no_resident = rmode && rmode[0] == '0';
   const bool any_resident = rmode && rmode[0] == '1';
-  if constexpr (EPI != EPI_CHANNEL_FIRST && LOADER != LOAD_INTERP) {
+  if constexpr (EPI != EPI_CHANNEL_FIRST && LOADER != LOAD_INTERP && LOADER != LOAD_INTERP_ADD) {
     // resident-A kernel: short contractions whose A panel fits LDS twice per CU
     const bool vec_ok = ((p.ldc | p.c_coff | p.c_gcol) & 3) == 0 &&
                         ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
@@ -1696,6 +1719,7 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   p.a_amax = d->a_amax; p.a_amax2 = d->a_amax2; p.a_amax_floor = d->a_amax_floor;
   p.out_amax = (uint32_t*)d->out_amax;
   p.Wfrag = (const uint16_t*)d->W_f16x2_frag;
+  p.lbias = d->loader_bias;
   p.Wfrag2 = (const uint16_t*)d->W2_f16x2_frag;
   p.w_inv_scale2 = d->w2_inv_scale;
   p.bias2 = d->bias2;
@@ -1725,6 +1749,11 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
     if (!d->gidx || !d->xyz || !d->ctr || !d->mlp1_w || !d->feat || (d->Cin & 3) || d->Cf != d->Cin ||
         d->K <= 0 || d->M <= 0 || d->N <= 0 || d->groups != 1 || ((uintptr_t)d->mlp1_w & 15) ||
         ((uintptr_t)d->feat & 15))
+      return S4G_EINVAL;
+  } else if (d->loader == S4G_GEMM_LOAD_INTERP_ADD) {
+    if (!d->nidx || !d->nw || !d->sparse || !d->loader_bias || (d->Cin & 3) || d->C2 != d->Cin ||
+        d->N1 <= 0 || d->N2 <= 0 || d->groups != 1 ||
+        (((uintptr_t)d->sparse | (uintptr_t)d->dense | (uintptr_t)d->loader_bias) & 15))
       return S4G_EINVAL;
   } else if (d->loader == S4G_GEMM_LOAD_INTERP) {
     if (!d->nidx || !d->nw || !d->sparse || (d->C2 & 3) || (d->C1 & 3) ||
@@ -1770,6 +1799,8 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
     S4G_FUSED2_CASE(LOAD_PLAIN, EPI_STORE, 1, 1)
     S4G_FUSED2_CASE(LOAD_PLAIN, EPI_STORE, 2, 1)
     S4G_FUSED2_CASE(LOAD_PLAIN, EPI_STORE, 1, 2)     // first layer two panels deep (512 -> 256 -> ...)
+    S4G_FUSED2_CASE(LOAD_INTERP_ADD, EPI_STORE, 1, 1)
+    S4G_FUSED2_CASE(LOAD_INTERP_ADD, EPI_STORE, 2, 1)
 #undef S4G_FUSED2_CASE
     return S4G_EUNSUPPORTED;
   }
@@ -1788,6 +1819,7 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   S4G_GEMM_CASE(LOAD_GATHER_MLP1, EPI_MAX)
   S4G_GEMM_CASE(LOAD_GATHER_ADD, EPI_STORE)
   S4G_GEMM_CASE(LOAD_GATHER_ADD, EPI_MAX)
+  S4G_GEMM_CASE(LOAD_INTERP_ADD, EPI_STORE)
 #undef S4G_GEMM_CASE
   return S4G_EUNSUPPORTED;
 }

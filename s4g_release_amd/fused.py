@@ -34,7 +34,7 @@ _i32 = ctypes.c_int32
 _fp = ctypes.c_void_p
 GemmDesc = _cabi.GemmDesc
 
-LOAD_PLAIN, LOAD_GATHER, LOAD_INTERP, LOAD_GATHER_MLP1, LOAD_GATHER_ADD = 0, 1, 2, 3, 4
+LOAD_PLAIN, LOAD_GATHER, LOAD_INTERP, LOAD_GATHER_MLP1, LOAD_GATHER_ADD, LOAD_INTERP_ADD = 0, 1, 2, 3, 4, 5
 EPI_STORE, EPI_MAX, EPI_CF = 0, 1, 2
 
 
@@ -145,6 +145,12 @@ class FusedPointNet2:
         # S4G_FP_LINEAR_FIRST=0: interpolate first, like the reference (fused into the
         # contraction's loader); default: first FP layer before the interpolation
         self.fp_linear_first = os.environ.get("S4G_FP_LINEAR_FIRST", "1") != "0"
+        # FP levels whose interpolate + add + ReLU happens in the next launch's loader:
+        # S4G_FP_LOADER_ADD = "auto" (default: where that launch is a fused chain, whose panel is
+        # loaded once -- the tiled kernel would repeat the gathers per column tile: measured
+        # 0.41 ms against 0.14 + 0.18 ms at FP level 1), "none", or a comma list of levels
+        v = os.environ.get("S4G_FP_LOADER_ADD", "auto")
+        self.fp_loader_add = v if v in ("auto", "none") else set(int(t) for t in v.split(",") if t)
         self.geo_streams = max(1, int(os.environ.get("S4G_GEO_STREAMS", "2")))
         p = next(net.parameters())
         if not p.is_cuda:
@@ -203,7 +209,8 @@ class FusedPointNet2:
             for blk in fp.mlp:
                 w, b = fold_conv_bn(blk)
                 layers.append(_Layer(_pad_k(w), b, w.shape[1]))
-            self.fp.append(dict(layers=layers, eps=float(fp.interpolator._eps)))
+            self.fp.append(dict(layers=layers, eps=float(fp.interpolator._eps),
+                                bias0_max=float(layers[0].bias.abs().max())))
         # heads: order score, R, t, movable (PointNet2_tcls.py:126-140)
         heads = [(net.mlp_seg, net.seg_logit), (net.mlp_R, net.R_logit), (net.mlp_t, net.t_logit),
                  (net.mlp_movable, net.movable_logit[0])]
@@ -365,7 +372,7 @@ class FusedPointNet2:
         dev = xyz.device
         level_xyz, level_n = geo["level_xyz"], geo["level_n"]
         n_launch = sum(len(sa["layers"]) for sa in self.sa) + \
-            sum(len(fp["layers"]) for fp in self.fp) + len(self.head_layers) + 1 + len(self.sa)
+            sum(len(fp["layers"]) for fp in self.fp) + len(self.head_layers) + 1 + len(self.sa) + 2 * len(self.fp)
         amax = torch.zeros((n_launch, 64), dtype=torch.float32, device=dev)
         rows = iter(amax.unbind(0))
         level_feat = [(None, None)]                  # (tensor, amax row)
@@ -433,6 +440,7 @@ class FusedPointNet2:
             P = B * n_dense
             x = x_amax = None
             fl = fp["layers"]
+            pending = None
             fuse2 = len(fl) >= 3 and self._fusable(fl[-2], fl[-1])
             # last FP level: the first head layer (shared input, groups == 1) rides along as a
             # third layer, so the per-point features never go through HBM before the heads
@@ -462,13 +470,29 @@ class FusedPointNet2:
                         sp = fp["split"] = (la, lb, c2)
                     la, lb, _ = sp
                     s_out = torch.empty((B * n_sparse, layer.cout), dtype=torch.float32, device=dev)
+                    # the sum is formed by the NEXT launch's loader where that is faster
+                    # (S4G_FP_LOADER_ADD = list of FP levels), else by interp_add_cl_kernel
+                    if self.fp_loader_add == "auto":
+                        in_loader = fuse2 and len(fl) == 3
+                    else:
+                        in_loader = self.fp_loader_add != "none" and fi in self.fp_loader_add
+                    in_loader = in_loader and self.precision == "f16x2" and len(fl) >= 2
+                    s_amax = next(rows) if in_loader else None
                     self._gemm("fp%d.0s" % fi, la, B * n_sparse, LOAD_PLAIN, EPI_STORE, relu=False,
-                               out=s_out, ldc=layer.cout, A=sparse_feat, lda=c2, a_amax=sparse_amax)
-                    y = None
+                               out=s_out, ldc=layer.cout, A=sparse_feat, lda=c2, a_amax=sparse_amax,
+                               out_amax=s_amax)
+                    y = y_amax = None
                     if lb is not None:
                         y = torch.empty((P, layer.cout), dtype=torch.float32, device=dev)
+                        y_amax = next(rows) if in_loader else None
                         self._gemm("fp%d.0d" % fi, lb, P, LOAD_PLAIN, EPI_STORE, relu=False, out=y,
-                                   ldc=layer.cout, A=dense_feat, lda=c1, a_amax=dense_amax)
+                                   ldc=layer.cout, A=dense_feat, lda=c1, a_amax=dense_amax,
+                                   out_amax=y_amax)
+                    if in_loader:
+                        pending = dict(sparse=s_out, dense=y, C2=layer.cout, N2=n_sparse, N1=n_dense,
+                                       nidx=nidx, nw=nw, loader_bias=layer.bias, a_amax=s_amax,
+                                       a_amax2=y_amax, a_amax_floor=fp["bias0_max"])
+                        continue
                     with _F._timed("interp_add[P=%d,C=%d]" % (P, layer.cout),
                                    P * layer.cout * (8 if y is not None else 4) + P * 24):
                         rc = _cabi.lib().s4g_interp_add_cl_f32(
@@ -483,6 +507,11 @@ class FusedPointNet2:
                                dense=dense_feat, C2=sparse_feat.shape[1], C1=c1, N2=n_sparse,
                                N1=n_dense, a_amax=sparse_amax, a_amax2=dense_amax,
                                out_amax=out_amax)
+                elif pending is not None:
+                    self._gemm("fp%d.%d" % (fi, l), layer, P, LOAD_INTERP_ADD, EPI_STORE, out=out,
+                               ldc=out.shape[1], out_amax=out_amax, layer2=l2, layer3=l3, **pending)
+                    heads0_fused = l3 is not None
+                    pending = None
                 else:
                     self._gemm("fp%d.%d" % (fi, l), layer, P, LOAD_PLAIN, EPI_STORE, out=out,
                                ldc=out.shape[1], A=x, lda=x.shape[1], a_amax=x_amax,

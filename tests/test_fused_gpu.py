@@ -420,6 +420,47 @@ def test_gemm_gather_add_loader(dev, Cin, Cout, epi, K, prec):
     assert (out.double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("C,Cout,with_y,chain", [(256, 256, False, True), (128, 128, True, True),
+                                                   (64, 96, True, False), (512, 512, False, False)])
+def test_gemm_interp_add_loader(dev, C, Cout, with_y, chain):
+    """Interpolate + add + bias + ReLU formed by the loader of the next launch (tiled kernel
+    or fused chain): A = relu(y + b0 + sum_k w_k S[idx_k]), then one or two more layers."""
+    g = torch.Generator(device="cpu").manual_seed(C + Cout)
+    B, N1, N2 = 2, 333, 40
+    P = B * N1
+    S = torch.randn(B * N2, C, generator=g).to(dev)
+    y = torch.randn(P, C, generator=g).to(dev) if with_y else None
+    b0 = torch.randn(C, generator=g).to(dev)
+    nidx = torch.randint(0, N2, (B, N1, 3), generator=g).int().to(dev)
+    nw = torch.rand(B, N1, 3, generator=g)
+    nw = (nw / nw.sum(dim=2, keepdim=True)).to(dev)
+    W = (torch.randn(Cout, C, generator=g) / C ** 0.5).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    W2 = (torch.randn(Cout, Cout, generator=g) / Cout ** 0.5).to(dev)
+    b2 = torch.randn(Cout, generator=g).to(dev)
+    out = torch.full((P, Cout), float("nan"), device=dev)
+    Wp = _padk(W)
+    k16, w3 = _w3(W)
+    h2 = _h2(W, S, y, floor=float(b0.abs().max()))
+    kw = dict(loader=5, epilogue=0, groups=1, relu=1, P=P, Cin=C, Kpad=Wp.shape[1], Cout=Cout, W=Wp, bias=b,
+              nidx=nidx, nw=nw, sparse=S, dense=y, C2=C, N2=N2, N1=N1, loader_bias=b0, out=out, ldc=Cout,
+              precision=3, Kpad16=k16, W_bf16x3=w3, **h2)
+    if chain:
+        f2, i2 = _h2_second(W2)
+        kw.update(W2_f16x2_frag=f2, w2_inv_scale=i2, bias2=b2, Cout2=Cout, relu2=1)
+    _run({k: v for k, v in kw.items() if v is not None}, dev)
+    rows = torch.stack([S.view(B, N2, C)[bi][nidx[bi].long()] for bi in range(B)]).double()   # (B,N1,3,C)
+    A = (rows * nw.double()[..., None]).sum(dim=2).view(P, C) + b0.double()
+    if y is not None:
+        A = A + y.double()
+    A = A.clamp_min(0)
+    ref = (A @ W.double().t() + b.double()).clamp_min(0)
+    if chain:
+        ref = (ref @ W2.double().t() + b2.double()).clamp_min(0)
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() < 4e-5 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("C,with_y,relu", [(256, True, 1), (512, False, 1), (36, True, 0), (1024, True, 1)])
 def test_interp_add_channels_last(dev, C, with_y, relu):
     """out = act(y + bias + sum_k w_k * sparse[idx_k]) on channels-last tensors + its amax row."""
