@@ -37,6 +37,9 @@
 extern "C" {
 #endif
 
+/* 1: operators; 2: f16x2 contraction fields, crop / voxel / outlier / grid 3-NN / _ws entry points;
+ * 3: fused layer chains (W2 / W3 fields), GATHER_ADD / INTERP_ADD loaders, s4g_interp_add_cl_f32,
+ *    s4g_group_points_ws_f32, device-side cell choice of s4g_three_nn_grid_f32 (cell < 0). */
 #define S4G_ABI_VERSION 3
 
 #define S4G_OK 0
