@@ -278,7 +278,7 @@ typedef struct s4g_gemm_desc {
    * the matrix-core operand registers. */
   const void *W_f16x2_frag;
   /* ABI >= 3, optional: a SECOND layer fused behind this one (S4G_GEMM_F16X2, loader PLAIN
-   * GATHER_MLP1 or GATHER_ADD, Kpad16 == Cout == C with C = 128 or 256 -- for the plain
+   * GATHER_MLP1, GATHER_ADD or INTERP_ADD, Kpad16 == Cout == C with C = 128, 256 or 512 -- for the plain
    * loader + STORE also Kpad16 == 2 C == 512: the first layer then runs through two panel loads
    * --, Cout2 % 64 == 0; epilogue MAX
    * with K == 64 and groups == 1, or STORE with any group count -- W2 / w2_inv_scale / bias2

@@ -1244,14 +1244,16 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
 // are powers of two undone in the epilogue).
 // ---------------------------------------------------------------------------
 template <int LOADER, int EPI2, int RW, int KC>
-__global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const GemmParams p) {
-  // RW = 2: 128 positions, 128-wide layers; RW = 1: 64 positions, 256-wide layers
-  constexpr int CW = 4 / RW, BM = 64 * RW, K = 64 * CW;
-  constexpr int RPT = BM / 32, RS = 32;
+__global__ __launch_bounds__(RW == 8 ? 512 : 256, 2) void mlp_gemm_f16x2_fused2_kernel(const GemmParams p) {
+  // RW = 2: 128 positions, 128-wide layers, 4 waves; RW = 1: 64 positions, 256-wide layers, 4 waves;
+  // RW = 8: 64 positions, 512-wide layers, EIGHT waves (one workgroup per CU: its 133 KB panel)
+  constexpr int CW = RW == 8 ? 8 : 4 / RW, RWN = RW == 8 ? 1 : RW;
+  constexpr int BM = 64 * RWN, K = 64 * CW, NW = RWN * CW;
+  constexpr int RS = 8 * NW, RPT = BM / RS;   // loader: 8 lanes per row, RS rows per pass
   constexpr int astr = K + 8, aplane = BM * astr, KS = K >> 4;
   extern __shared__ __attribute__((aligned(16))) float smemf[];
   uint16_t* Ah = reinterpret_cast<uint16_t*>(smemf);   // [2][BM][K + 8]
-  float* scr = reinterpret_cast<float*>(Ah + 2 * aplane);   // [4 waves][128] scale | bias, then 4 tile maxima
+  float* scr = reinterpret_cast<float*>(Ah + 2 * aplane);   // [NW waves][128] scale | bias, then NW tile maxima
   const int g = blockIdx.y;
 
   const int t = threadIdx.x;
@@ -1464,10 +1466,12 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
     }
   {
     const uint32_t wm = wave_max_u32(__float_as_uint(tmax));
-    if (lane == 0) scr[512 + wave] = __uint_as_float(wm);
+    if (lane == 0) scr[NW * 128 + wave] = __uint_as_float(wm);
   }
   __syncthreads();   // every wave is done with the old panel; the four maxima are visible
-  float hmax = fmaxf(fmaxf(scr[512], scr[513]), fmaxf(scr[514], scr[515]));
+  float hmax = scr[NW * 128];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) hmax = fmaxf(hmax, scr[NW * 128 + w]);
   uint32_t exh = __float_as_uint(hmax) >> 23;
   exh = exh < 15u ? 15u : (exh > 240u ? 240u : exh);
   exh = __builtin_amdgcn_readfirstlane(exh);
@@ -1578,15 +1582,16 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_fused2_kernel(const Gem
 
 template <int LOADER, int EPI2, int RW, int KC>
 static int launch_gemm_f16x2_fused2(const GemmParams& p, int groups, hipStream_t st) {
-  constexpr int BM = 64 * RW, K = 64 * (4 / RW);
-  constexpr size_t lds = sizeof(uint16_t) * 2 * BM * (size_t)(K + 8) + sizeof(float) * (4 * 128 + 16);
-  static_assert(lds <= 80 * 1024, "two workgroups per CU");
+  constexpr int CW = RW == 8 ? 8 : 4 / RW, RWN = RW == 8 ? 1 : RW;
+  constexpr int BM = 64 * RWN, K = 64 * CW, NW = RWN * CW;
+  constexpr size_t lds = sizeof(uint16_t) * 2 * BM * (size_t)(K + 8) + sizeof(float) * (NW * 128 + 16);
+  static_assert(lds <= (RW == 8 ? 160 : 80) * 1024, "two workgroups per CU (one for the 8-wave form)");
   static const hipError_t attr = hipFuncSetAttribute(
       reinterpret_cast<const void*>(&mlp_gemm_f16x2_fused2_kernel<LOADER, EPI2, RW, KC>),
       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr != hipSuccess) return (int)attr;
   const dim3 grid((unsigned)((p.P + BM - 1) / BM), (unsigned)groups);
-  hipLaunchKernelGGL((mlp_gemm_f16x2_fused2_kernel<LOADER, EPI2, RW, KC>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((mlp_gemm_f16x2_fused2_kernel<LOADER, EPI2, RW, KC>), grid, dim3(64 * NW), lds, st, p);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }
@@ -1777,17 +1782,18 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
     // C = 256 (64 positions), epilogue MAX (K == 64 neighbours) or STORE
     // layer 1 may be one or two panels deep (Kpad16 = C or 2 C)
     const bool c128 = d->Cout == 128 && d->Kpad16 == 128,
-               c256 = d->Cout == 256 && (d->Kpad16 == 256 || d->Kpad16 == 512);
+               c256 = d->Cout == 256 && (d->Kpad16 == 256 || d->Kpad16 == 512),
+               c512 = d->Cout == 512 && d->Kpad16 == 512;
     const bool store = d->epilogue == S4G_GEMM_EPI_STORE;
     if (!h2 || (!store && (d->epilogue != S4G_GEMM_EPI_MAX || d->K != 64 || (d->P & 63))) ||
-        (!c128 && !c256) || d->Cout2 <= 0 || (d->Cout2 & 63) || (!store && d->groups != 1) || !d->W_f16x2_frag ||
+        (!c128 && !c256 && !c512) || d->Cout2 <= 0 || (d->Cout2 & 63) || (!store && d->groups != 1) || !d->W_f16x2_frag ||
         (d->W3_f16x2_frag && (d->Cout2 != d->Cout || d->Cout3 <= 0 || (d->Cout3 & 63) || !d->w3_inv_scale ||
                               !d->bias3)) ||
         !d->w2_inv_scale || !d->bias2 ||
         (store && (((d->ldc | d->c_coff | d->c_gcol) & 3) || ((uintptr_t)d->out & 15))))
       return S4G_EINVAL;
 #define S4G_FUSED2_CASE(L, E, R, KCH)                                                        \
-  if (d->loader == L && (int)d->epilogue == (int)E && (c128 ? 2 : 1) == R &&                  \
+  if (d->loader == L && (int)d->epilogue == (int)E && (c128 ? 2 : (c256 ? 1 : 8)) == R &&     \
       d->Kpad16 / d->Cout == KCH)                                                             \
     return launch_gemm_f16x2_fused2<L, E, R, KCH>(p, d->groups, st);
     S4G_FUSED2_CASE(LOAD_GATHER_MLP1, EPI_MAX, 2, 1)
@@ -1800,6 +1806,9 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
     S4G_FUSED2_CASE(LOAD_PLAIN, EPI_STORE, 2, 1)
     S4G_FUSED2_CASE(LOAD_PLAIN, EPI_STORE, 1, 2)     // first layer two panels deep (512 -> 256 -> ...)
     S4G_FUSED2_CASE(LOAD_INTERP_ADD, EPI_STORE, 1, 1)
+    S4G_FUSED2_CASE(LOAD_GATHER_ADD, EPI_MAX, 8, 1)   // 512-wide pairs: eight waves, one workgroup per CU
+    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_MAX, 8, 1)
+    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_STORE, 8, 1)
     S4G_FUSED2_CASE(LOAD_INTERP_ADD, EPI_STORE, 2, 1)
 #undef S4G_FUSED2_CASE
     return S4G_EUNSUPPORTED;

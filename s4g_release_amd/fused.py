@@ -244,7 +244,8 @@ class FusedPointNet2:
         deep_first: the first layer may contract over 2 C inputs (plain loader, store epilogue)."""
         c = l1.cout
         k1_ok = l1.kpad16 == c or (deep_first and c == 256 and l1.kpad16 == 512 and self.fuse3)
-        return (self.precision == "f16x2" and self.fuse2 and c in (128, 256) and
+        wide_ok = c == 512 and os.environ.get("S4G_GEMM_FUSE512", "1") != "0"   # 8-wave form
+        return (self.precision == "f16x2" and self.fuse2 and (c in (128, 256) or wide_ok) and
                 l1.groups == l2.groups and k1_ok and l2.cin == c and l2.kpad16 == c and
                 l2.cout % 64 == 0 and l1.Wfrag is not None and l2.Wfrag is not None)
 

@@ -245,6 +245,8 @@ def _h2_second(W2):
     (128, 384, 0, 1, 777),         # 128-wide pair, store, three strips
     (256, 128, 0, 4, 500),         # head layers 2 + 3: four groups, partial strip (waves 2, 3 sit out)
     (256, 64, 0, 2, 130),          # quarter strip
+    (512, 1024, 1, 1, 9 * 64),     # SA2 shape: eight-wave workgroup, 512-wide panel
+    (512, 512, 0, 1, 333),         # 512-wide pair, store, ragged
 ])
 def test_gemm_fused_layer_pair(dev, C, Cout2, epi, groups, P):
     """Two layers, one launch (intermediate in LDS, per-tile scale): against fp64."""
