@@ -243,8 +243,11 @@ def main():
         elif getattr(runner, "precision", "fp32") == "f16x2":
             # three fp16 MFMA products per fp32-equivalent product: price the flops the
             # matrix cores actually execute against the dense fp16 peak (= the bf16 one).
-            roofline_dense = {"kernel": "mlp_gemm_f16x2_kernel (v_mfma_f32_32x32x16_f16, 3 products "
-                                        "per fp32-equivalent product), all launches of one step",
+            roofline_dense = {"kernel": "mlp_gemm_f16x2_kernel + mlp_gemm_f16x2_fused2_kernel (fused layer "
+                                        "chains) (v_mfma_f32_32x32x16_f16, 3 products per "
+                                        "fp32-equivalent product), all contraction launches of one step; "
+                                        "flops = those executed after moving the linear first SA / FP "
+                                        "layers in front of the grouping / interpolation",
                               "bound": "mfma", "achieved": round(3 * dense_tf, 1),
                               "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
                               "frac": round(3 * dense_tf / BF16_MFMA_PEAK_TF, 4),
