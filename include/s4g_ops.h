@@ -302,6 +302,11 @@ typedef struct s4g_gemm_desc {
 
 int s4g_mlp_gemm_f32(const s4g_gemm_desc_t *desc, s4g_stream_t stream);
 
+/* 1 when s4g_mlp_gemm_f32 has a fused-chain form (W2_f16x2_frag set) for this first-layer
+ * loader, final epilogue, chain width C (= Cout = Cout2 of a three-layer chain) and first-layer
+ * depth Kpad16; callers decide with it which layers to hand over as one launch. */
+int s4g_gemm_chain_supported(int loader, int epilogue, int C, int Kpad16);
+
 /* int32-index variants used by the fast path (same kernels and semantics as
  * s4g_ball_query_f32 / s4g_three_nn_f32; the int64 API tensors are an
  * interface requirement of the reference, not of the hardware).

@@ -57,6 +57,7 @@ SIGNATURES = {
                                              _sz, _int, _vp]),
     "s4g_three_nn_grid_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _sz, _int, _vp]),
     "s4g_group_points_xyz_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "s4g_gemm_chain_supported": (_int, [_int, _int, _int, _int]),
     "s4g_interp_add_cl_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp]),
     "s4g_group_points_ws_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "s4g_three_interpolate_ws_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _int, _vp]),

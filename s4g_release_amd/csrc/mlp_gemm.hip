@@ -1688,6 +1688,37 @@ static int launch_gemm(const GemmParams& p, int groups, hipStream_t st) {
 
 }  // namespace s4g
 
+// Instantiations of the fused chain kernel: (first layer's loader, final epilogue, RW code
+// (2: C = 128, 1: C = 256, 8: C = 512), panels the first layer is deep).  The dispatch and
+// s4g_gemm_chain_supported are generated from this one list.
+#define S4G_FUSED2_LIST(X)                                                                       \
+  X(LOAD_GATHER_MLP1, EPI_MAX, 2, 1)                                                             \
+  X(LOAD_GATHER_MLP1, EPI_MAX, 1, 1)                                                             \
+  X(LOAD_GATHER_ADD, EPI_MAX, 2, 1)                                                              \
+  X(LOAD_GATHER_ADD, EPI_MAX, 1, 1)                                                              \
+  X(LOAD_GATHER_ADD, EPI_MAX, 8, 1)   /* 512-wide pairs: eight waves, one workgroup per CU */    \
+  X(LOAD_PLAIN, EPI_MAX, 2, 1)                                                                   \
+  X(LOAD_PLAIN, EPI_MAX, 1, 1)                                                                   \
+  X(LOAD_PLAIN, EPI_MAX, 8, 1)                                                                   \
+  X(LOAD_PLAIN, EPI_STORE, 2, 1)                                                                 \
+  X(LOAD_PLAIN, EPI_STORE, 1, 1)                                                                 \
+  X(LOAD_PLAIN, EPI_STORE, 1, 2)      /* first layer two panels deep (512 -> 256 -> ...) */      \
+  X(LOAD_PLAIN, EPI_STORE, 8, 1)                                                                 \
+  X(LOAD_INTERP_ADD, EPI_STORE, 2, 1)                                                            \
+  X(LOAD_INTERP_ADD, EPI_STORE, 1, 1)
+
+extern "C" int s4g_gemm_chain_supported(int loader, int epilogue, int C, int Kpad16) {
+  using namespace s4g;
+  const int r = C == 128 ? 2 : (C == 256 ? 1 : (C == 512 ? 8 : 0));
+  if (r == 0 || Kpad16 <= 0 || Kpad16 % C) return 0;
+  const int kc = Kpad16 / C;
+#define S4G_FUSED2_Q(L, E, R, KCH) \
+  if (loader == L && epilogue == (int)E && r == R && kc == KCH) return 1;
+  S4G_FUSED2_LIST(S4G_FUSED2_Q)
+#undef S4G_FUSED2_Q
+  return 0;
+}
+
 extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   using namespace s4g;
   if (!d || d->P < 0 || d->Cout <= 0 || d->groups <= 0 || !d->bias) return S4G_EINVAL;
@@ -1800,20 +1831,7 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   if (d->loader == L && (int)d->epilogue == (int)E && (c128 ? 2 : (c256 ? 1 : 8)) == R &&     \
       d->Kpad16 / d->Cout == KCH)                                                             \
     return launch_gemm_f16x2_fused2<L, E, R, KCH>(p, d->groups, st);
-    S4G_FUSED2_CASE(LOAD_GATHER_MLP1, EPI_MAX, 2, 1)
-    S4G_FUSED2_CASE(LOAD_GATHER_MLP1, EPI_MAX, 1, 1)
-    S4G_FUSED2_CASE(LOAD_GATHER_ADD, EPI_MAX, 2, 1)
-    S4G_FUSED2_CASE(LOAD_GATHER_ADD, EPI_MAX, 1, 1)
-    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_MAX, 2, 1)
-    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_MAX, 1, 1)
-    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_STORE, 1, 1)
-    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_STORE, 2, 1)
-    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_STORE, 1, 2)     // first layer two panels deep (512 -> 256 -> ...)
-    S4G_FUSED2_CASE(LOAD_INTERP_ADD, EPI_STORE, 1, 1)
-    S4G_FUSED2_CASE(LOAD_GATHER_ADD, EPI_MAX, 8, 1)   // 512-wide pairs: eight waves, one workgroup per CU
-    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_MAX, 8, 1)
-    S4G_FUSED2_CASE(LOAD_PLAIN, EPI_STORE, 8, 1)
-    S4G_FUSED2_CASE(LOAD_INTERP_ADD, EPI_STORE, 2, 1)
+    S4G_FUSED2_LIST(S4G_FUSED2_CASE)
 #undef S4G_FUSED2_CASE
     return S4G_EUNSUPPORTED;
   }

@@ -239,15 +239,20 @@ class FusedPointNet2:
         self.sigmoid_from = sum(chans[:3])
         self._streams = None
 
-    def _fusable(self, l1, l2, deep_first=False):
-        """Two consecutive layers one launch can take (mlp_gemm_f16x2_fused2_kernel);
-        deep_first: the first layer may contract over 2 C inputs (plain loader, store epilogue)."""
+    def _fusable(self, l1, l2, loader=LOAD_PLAIN, epi=EPI_STORE):
+        """Two consecutive layers one launch can take: widths that chain (C -> C -> Cout2) and a
+        fused form of the contraction for this loader / epilogue / first-layer depth (the
+        library is asked: s4g_gemm_chain_supported)."""
         c = l1.cout
-        k1_ok = l1.kpad16 == c or (deep_first and c == 256 and l1.kpad16 == 512 and self.fuse3)
-        wide_ok = c == 512 and os.environ.get("S4G_GEMM_FUSE512", "1") != "0"   # 8-wave form
-        return (self.precision == "f16x2" and self.fuse2 and (c in (128, 256) or wide_ok) and
-                l1.groups == l2.groups and k1_ok and l2.cin == c and l2.kpad16 == c and
-                l2.cout % 64 == 0 and l1.Wfrag is not None and l2.Wfrag is not None)
+        if not (self.precision == "f16x2" and self.fuse2 and l1.groups == l2.groups and
+                l2.cin == c and l2.kpad16 == c and l2.cout % 64 == 0 and
+                l1.Wfrag is not None and l2.Wfrag is not None):
+            return False
+        if c == 512 and os.environ.get("S4G_GEMM_FUSE512", "1") == "0":
+            return False
+        if l1.kpad16 != c and not self.fuse3:
+            return False
+        return bool(_cabi.lib().s4g_gemm_chain_supported(loader, epi, c, l1.kpad16))
 
     # ------------------------------------------------------------------ launches
     def _gemm(self, name, layer, P, loader, epi, relu=True, layer2=None, layer3=None, name3="heads.0",
@@ -388,9 +393,12 @@ class FusedPointNet2:
             x = x_amax = None
             # the last two layers as ONE launch (C -> C -> Cout2 with C = 128 or 256, intermediate
             # in LDS); the first of the pair then reads through the MLP1 or the plain loader
-            fuse2 = (K == 64 and len(layers) >= 3 and layers[-1].groups == 1 and
-                     self._fusable(layers[-2], layers[-1]))
             pre = sa["pre"] if self.precision == "f16x2" else None
+            lp = len(layers) - 2                  # first layer of the candidate pair
+            first_loader = (LOAD_GATHER_MLP1 if (lp == 1 and sa["mlp1"] is not None) else
+                            LOAD_GATHER_ADD if (lp == 1 and pre is not None) else LOAD_PLAIN)
+            fuse2 = (K == 64 and len(layers) >= 3 and layers[-1].groups == 1 and
+                     self._fusable(layers[-2], layers[-1], first_loader, EPI_MAX))
             if pre is not None:
                 # F = W_feat . features, one row per point of the level
                 fpre = torch.empty((B * level_n[li], layers[0].cout), dtype=torch.float32, device=dev)
@@ -474,10 +482,13 @@ class FusedPointNet2:
                     # the sum is formed by the NEXT launch's loader where that is faster
                     # (S4G_FP_LOADER_ADD = list of FP levels), else by interp_add_cl_kernel
                     if self.fp_loader_add == "auto":
-                        in_loader = fuse2 and len(fl) == 3
+                        in_loader = (fuse2 and len(fl) == 3 and
+                                     self._fusable(fl[-2], fl[-1], LOAD_INTERP_ADD, EPI_STORE))
                     else:
                         in_loader = self.fp_loader_add != "none" and fi in self.fp_loader_add
                     in_loader = in_loader and self.precision == "f16x2" and len(fl) >= 2
+                    if in_loader and fuse2 and not self._fusable(fl[-2], fl[-1], LOAD_INTERP_ADD, EPI_STORE):
+                        in_loader = False
                     s_amax = next(rows) if in_loader else None
                     self._gemm("fp%d.0s" % fi, la, B * n_sparse, LOAD_PLAIN, EPI_STORE, relu=False,
                                out=s_out, ldc=layer.cout, A=sparse_feat, lda=c2, a_amax=sparse_amax,
@@ -536,7 +547,7 @@ class FusedPointNet2:
         while l < len(hl):
             layer = hl[l]
             # two or three consecutive grouped layers as one launch where the widths allow it
-            l2 = hl[l + 1] if (l + 1 < len(hl) and self._fusable(layer, hl[l + 1], deep_first=True)) else None
+            l2 = hl[l + 1] if (l + 1 < len(hl) and self._fusable(layer, hl[l + 1])) else None
             l3 = None
             if (l2 is not None and self.fuse3 and l + 2 < len(hl) and l2.cout == layer.cout and
                     self._fusable(l2, hl[l + 2])):

@@ -370,6 +370,33 @@ def test_gemm_fused_layer_pair_mlp1_loader(dev):
     assert (out.double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
 
 
+def test_gemm_chain_supported_query_matches_dispatch(dev):
+    """s4g_gemm_chain_supported answers exactly what s4g_mlp_gemm_f32 accepts."""
+    from s4g_release_amd import _cabi
+    lib = _cabi.lib()
+    assert lib.s4g_gemm_chain_supported(0, 0, 256, 512) == 1      # plain, store, deep first layer
+    assert lib.s4g_gemm_chain_supported(3, 1, 256, 256) == 1      # MLP1 loader, 256 wide
+    assert lib.s4g_gemm_chain_supported(4, 1, 512, 512) == 1      # eight-wave form
+    assert lib.s4g_gemm_chain_supported(5, 0, 256, 256) == 1
+    assert lib.s4g_gemm_chain_supported(1, 1, 256, 256) == 0      # plain GATHER loader: never fused
+    assert lib.s4g_gemm_chain_supported(0, 0, 64, 64) == 0
+    assert lib.s4g_gemm_chain_supported(0, 1, 256, 512) == 0      # deep first layer only with STORE
+    assert lib.s4g_gemm_chain_supported(0, 0, 512, 1024) == 0
+    for loader, epi, C, k16, P in [(0, 0, 128, 128, 200), (0, 1, 512, 512, 128), (0, 0, 256, 512, 70)]:
+        g = torch.Generator(device="cpu").manual_seed(C)
+        A = torch.randn(P, k16, generator=g).to(dev)
+        W1 = (torch.randn(C, k16, generator=g) / k16 ** 0.5).to(dev)
+        W2 = (torch.randn(C, C, generator=g) / C ** 0.5).to(dev)
+        b = torch.zeros(C, device=dev)
+        out = torch.empty((P // 64 if epi else P, C), device=dev)
+        kk, w3 = _w3(W1)
+        h2 = _h2(W1, A)
+        f2, i2 = _h2_second(W2)
+        _run(dict(loader=loader, epilogue=epi, groups=1, relu=1, P=P, Cin=k16, Kpad=k16, Cout=C, W=W1,
+                  bias=b, A=A, lda=k16, K=64, out=out, ldc=C, precision=3, Kpad16=kk, W_bf16x3=w3,
+                  W2_f16x2_frag=f2, w2_inv_scale=i2, bias2=b, Cout2=C, relu2=1, **h2), dev)
+
+
 def test_gemm_fused_layer_pair_rejects_unsupported(dev):
     from s4g_release_amd import _cabi
     W1 = torch.randn(64, 64, device=dev)
