@@ -11,20 +11,33 @@ data-path collective) and the per-point outputs are all-gathered over RCCL.
 The timed region is bracketed by barrier + synchronize on both sides and the
 slowest rank's time is used.  Rank 0 prints ONE JSON line.
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment
+launches itself: the parent starts `python -m torch.distributed.run ... bench.py`
+as a child process BEFORE importing torch or touching a GPU, relays rank 0's
+JSON line and returns the child's exit code (reference's only multi-device site:
+`grasp_proposal_test.py:52-53`).  A WORLD_SIZE that disagrees with --gpus is an error.
+
 Extra objects on the line:
   roofline      the dominant kernel of a step: the MFMA shared-MLP contraction (all its
                 launches), HIP-event durations from the timed region, flops the matrix
-                cores execute against the dense peak, PMC traffic from profiles/
+                cores execute against the dense peak, PMC traffic from profiles/ (only
+                when it was measured on the same sources and arguments, else null)
   roofline_ball_query_group_points
                 the HBM-bound operator pair the north star names, at SA1 size, through
                 the operator API on the same batch (+ the fused single-pass entry point)
+  step_ms       per-step completion intervals: median / p10 / p90 / pipeline fill
+  latency       one batch alone (no pipelining) and the one-scene (B = 1) figures
+  io            H2D of the clouds / D2H of the outputs, measured apart (never in `value`)
   kernels       every native launch: mean ms, algorithmic bytes / flops, GB/s / TFLOP/s
   cpu_baseline  the CPU oracle forward (oracle/pn2_forward.py) on ONE scene,
                 rank 0 at N == 1 only -- a reported baseline, not the target
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,11 +47,12 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3      # fp32-in MFMA = fp32 vector peak
-BF16_MFMA_PEAK_TF = 2500.0     # dense bf16 MFMA (no sparsity)
-GFLOP_PER_SCENE = 203.48       # SURVEY.md Appendix B (BN folded, 2*MAC)
+BF16_MFMA_PEAK_TF = 2500.0     # dense bf16 / fp16 MFMA (no sparsity)
+GFLOP_PER_SCENE = 203.48       # SURVEY.md Appendix B (BN folded, 2*MAC), N = 25 600
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -47,6 +61,8 @@ def parse():
     ap.add_argument("--points", type=int, default=25600)
     ap.add_argument("--impl", default="auto", choices=["auto", "fused", "modules"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the latency / io / operator-pair probes after the timed region")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="batches kept in flight besides the one being collected")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -54,12 +70,105 @@ def parse():
     ap.add_argument("--variant", default="tabletop-v1")
     ap.add_argument("--precision", default=None, choices=["f16x2", "bf16x3", "fp32", "bf16"],
                     help="contraction arithmetic of the fast path (default f16x2 = fp32-class); "
-                         "'bf16' is the reduced-precision roofline configuration, not the headline")
-    return ap.parse_args()
+                         "'bf16' is the reduced-precision roofline configuration (configs[4]), "
+                         "not the headline")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_command(args, argv):
+    """The child command of a self-launched multi-GPU run (one process per GPU)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
+            str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+            os.path.join(ROOT, "bench.py")] + list(argv)
+
+
+def maybe_spawn(args, argv, environ=None, run=subprocess.run, out=None, err=None):
+    """`python bench.py --gpus N` (N > 1) without torchrun: start the N ranks as a CHILD process
+    (never an exec; nothing in this process has touched the GPU yet), relay rank 0's JSON line.
+    Returns the exit code to leave with, or None when this process is itself a rank."""
+    environ = os.environ if environ is None else environ
+    out = sys.stdout if out is None else out
+    err = sys.stderr if err is None else err
+    if "WORLD_SIZE" in environ:
+        world = int(environ["WORLD_SIZE"])
+        if world != args.gpus:
+            print("bench.py: WORLD_SIZE=%d disagrees with --gpus %d" % (world, args.gpus), file=err)
+            return 2
+        return None
+    if args.gpus <= 1:
+        return None
+    env = dict(environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    proc = run(spawn_command(args, argv), env=env, cwd=ROOT, stdout=subprocess.PIPE,
+               stderr=subprocess.PIPE, text=True)
+    lines = [l for l in (proc.stdout or "").splitlines() if l.strip().startswith("{")]
+    rest = [l for l in (proc.stdout or "").splitlines() if not l.strip().startswith("{")]
+    if rest:
+        print("\n".join(rest), file=err)
+    if proc.stderr:
+        print(proc.stderr[-8000:], file=err)
+    if proc.returncode == 0 and len(lines) != 1:
+        print("bench.py: expected one JSON line from rank 0, got %d" % len(lines), file=err)
+        return 1
+    for l in lines[-1:]:
+        print(l, file=out)
+    return proc.returncode
+
+
+def source_stamp():
+    """Hash of the sources the measured kernels are built from; PMC traffic figures in
+    profiles/ are attached only when they were collected on the same sources."""
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, "s4g_release_amd")
+    files = sorted(os.path.join(pkg, "csrc", f) for f in os.listdir(os.path.join(pkg, "csrc"))
+                   if f.endswith((".hip", ".h")))
+    files += [os.path.join(pkg, "fused.py"), os.path.join(pkg, "functions.py")]
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(key):
+    """(bytes, source, None) of `key` in profiles/r02_traffic.json when its stamp matches this
+    tree, else (None, None, reason)."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            tr = json.load(f).get(key)
+    except (OSError, ValueError):
+        return None, None, "no PMC summary for this build in profiles/"
+    if not tr:
+        return None, None, "no PMC pass was collected for %s" % key
+    if tr.get("source_stamp") != source_stamp():
+        return None, None, ("PMC pass in %s was collected on other sources (stamp %s)"
+                            % (os.path.basename(TRAFFIC_FILE), tr.get("source_stamp")))
+    return tr["traffic_bytes"], tr["source"], None
+
+
+def percentile(xs, q):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    pos = (len(xs) - 1) * q
+    lo = int(pos)
+    hi = min(lo + 1, len(xs) - 1)
+    return xs[lo] + (xs[hi] - xs[lo]) * (pos - lo)
 
 
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    rc = maybe_spawn(args, argv)          # before torch / HIP are imported
+    if rc is not None:
+        sys.exit(rc)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -69,12 +178,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print("WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run"
-                  % (world, args.gpus), file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -106,10 +209,12 @@ def main():
     else:
         runner = net
         impl = "modules"
+    precision = getattr(runner, "precision", "library")
 
     B = args.batch
     scene_ids = [rank * B + i for i in range(B)]
-    pts = torch.from_numpy(synth.make_batch(scene_ids, args.points, variant=args.variant)).to(dev)
+    pts_host = torch.from_numpy(synth.make_batch(scene_ids, args.points, variant=args.variant))
+    pts = pts_host.to(dev)
     batch = {"scene_points": pts}
     heads = ("score", "frame_R", "frame_t", "movable_logits")
 
@@ -120,25 +225,34 @@ def main():
             return sdist.all_gather_outputs(pred)   # one RCCL all-gather of (B,21,N)
         return pred
 
-    def run_steps(n):
-        """n forward passes over the batch.  Pipelined mode keeps ONE batch in
-        flight: batch i+1 is submitted (its FPS chain starts on the geometry
-        stream) before batch i's outputs are collected; every batch is complete
-        when the trailing fence returns."""
+    def run_steps(n, data=batch, pipe=pipelined, marks=None):
+        """n forward passes over the batch.  Pipelined mode keeps up to `--in-flight`
+        batches submitted besides the one being collected: batch i+1's FPS chain
+        starts on the geometry stream before batch i's outputs are collected; every
+        batch is complete when the trailing fence returns.  `marks` collects one HIP
+        event per completed step (recorded on the collecting stream)."""
+        def mark():
+            if marks is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append(ev)
         if n <= 0:
             return
         with torch.no_grad():
-            if not pipelined:
+            if not pipe:
                 for _ in range(n):
-                    finish(runner(batch))
+                    finish(runner(data))
+                    mark()
                 return
             pending = []
             for _ in range(n):
-                pending.append(runner.submit(batch))
+                pending.append(runner.submit(data))
                 if len(pending) > args.in_flight:
                     finish(pending.pop(0).result())
+                    mark()
             while pending:
                 finish(pending.pop(0).result())
+                mark()
 
     run_steps(args.warmup)
 
@@ -150,8 +264,11 @@ def main():
 
     F.OpTimer.reset(enabled=True)
     fence()
+    marks = []
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    run_steps(args.steps, marks=marks)
     fence()
     elapsed = time.perf_counter() - t0
     F.OpTimer.enabled = False
@@ -169,100 +286,133 @@ def main():
     value = scenes / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
+    # per-step completion intervals (HIP events on the collecting stream): the first
+    # one contains the pipeline fill (the first batch's geometry runs in front of its
+    # own contractions), the rest is the steady state
+    stamps = [ev0.elapsed_time(m) for m in marks]
+    deltas = [b - a for a, b in zip([0.0] + stamps[:-1], stamps)]
+    steady = deltas[1:] if len(deltas) > 1 else deltas
+    step_ms = {"median": round(percentile(steady, 0.5), 3), "p10": round(percentile(steady, 0.1), 3),
+               "p90": round(percentile(steady, 0.9), 3), "first_step_incl_pipeline_fill": round(deltas[0], 3),
+               "pipeline_fill": round(max(0.0, deltas[0] - percentile(steady, 0.5)), 3) if len(deltas) > 1 else None,
+               "n": len(steady), "source": "HIP events after each collected batch"}
+
     kernels = {}
     gemm_ms = gemm_flops = 0.0
+    gemm_launches = 0
     for name, (n, ms, nbytes, flops) in sorted(F.OpTimer.summary().items()):
         if flops > 0:
             kernels[name] = {"launches": n, "ms": round(ms, 5), "GFLOP": round(flops / 1e9, 3),
                              "TFLOPs": round(flops / ms / 1e9, 2) if ms > 0 else None}
             gemm_ms += ms * n / args.steps
             gemm_flops += flops * n / args.steps
+            gemm_launches += n
         else:
             kernels[name] = {"launches": n, "ms": round(ms, 5), "bytes": int(nbytes),
                              "GBps": round(nbytes / ms / 1e6, 2) if ms > 0 else None}
 
-    # north-star roofline: the operator pair ball_query + group_points(xyz) at SA1
-    # size on this step's batch, through the public operator API (int64 indices),
-    # HIP events around each launch on the launch stream.
     N, M, K = args.points, cfg.num_centroids[0], cfg.num_neighbours[0]
-    with torch.no_grad():
-        ctr = F.gather_points(pts, F.farthest_point_sample(pts, M))
-        for rep in range(2 + 10):
-            if rep == 2:
-                torch.cuda.synchronize()
-                F.OpTimer.reset(enabled=True)
-            gidx, _ = F.ball_query(pts, ctr, cfg.radius[0], K)
-            F.group_points(pts, gidx)
-            F.query_and_group(pts, ctr, cfg.radius[0], K)
-        torch.cuda.synchronize()
-        F.OpTimer.enabled = False
-    probe = F.OpTimer.summary()
-    bq = probe["ball_query[N=%d,M=%d,K=%d]" % (N, M, K)]
-    gp = probe["group_points[C=3,N=%d,M=%d,K=%d]" % (N, M, K)]
-    nbytes = bq[2] + gp[2]
-    ms = bq[1] + gp[1]
-    roofline = {"kernel": "ball_query + group_points(xyz) at SA1 size (N=%d, M=%d, K=%d), "
-                          "operator API" % (N, M, K), "bound": "hbm",
-                "achieved": round(nbytes / ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
-                "bytes_per_launch_pair": int(nbytes), "ms_ball_query": round(bq[1], 5),
-                "ms_group_points": round(gp[1], 5), "scenes_per_launch": B,
-                "note": "algorithmic bytes = B*(12N+12M+8MK+8M) + B*(4CN+8MK+4CMK), C=3"}
-    # HBM-side traffic of the same pair comes from rocprofv3 PMC passes (cannot be
-    # collected from inside this process); the committed summary is attached.
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            tr = json.load(f).get("ball_query+group_points[N=%d,M=%d,K=%d,B=%d]" % (N, M, K, B))
-        if tr:
-            roofline["traffic"] = tr["traffic_bytes"]
-            roofline["traffic_source"] = tr["source"]
-    except (OSError, ValueError):
-        pass
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            kname = "mlp_gemm_f16x2_kernel" if getattr(runner, "precision", "") == "f16x2" \
-                else "mlp_gemm_bf16x3_kernel"
-            tr = json.load(f).get("%s[step,B=%d,N=%d]" % (kname, B, N))
-        dense_traffic = (tr["traffic_bytes"], tr["source"]) if tr else None
-    except (OSError, ValueError):
-        dense_traffic = None
-    fq = probe.get("query_group[N=%d,M=%d,K=%d]" % (N, M, K))
-    if fq:   # the same pair as ONE pass (s4g_query_group_f32), same algorithmic bytes
-        roofline["fused_pair_ms"] = round(fq[1], 5)
-        roofline["fused_pair_achieved"] = round(fq[2] / fq[1] / 1e6, 2)
-        roofline["fused_pair_frac"] = round(fq[2] / fq[1] / 1e6 / HBM_PEAK_GBS, 4)
+    roofline = latency = io = None
+    if not args.no_extras:
+        # ---- one batch alone / one scene: the figures the pipeline hides
+        def timed_forward(data, reps):
+            ts = []
+            with torch.no_grad():
+                for _ in range(reps):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    runner(data)
+                    torch.cuda.synchronize()
+                    ts.append(1e3 * (time.perf_counter() - t1))
+            return percentile(ts, 0.5)
+        one = {"scene_points": pts[:1].contiguous()}
+        latency = {"latency_ms_one_batch": round(timed_forward(batch, 5), 3), "batch": B,
+                   "latency_ms_b1": round(timed_forward(one, 5), 3)}
+        if pipelined:
+            run_steps(3, data=one)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(30, data=one)
+            torch.cuda.synchronize()
+            latency["scenes_per_sec_b1"] = round(30 / (time.perf_counter() - t1), 2)
+        latency["scenes_per_sec_one_batch_at_a_time"] = round(1e3 * B / latency["latency_ms_one_batch"], 2)
+
+        # ---- host <-> device transfers of one step, apart from `value`
+        with torch.no_grad():
+            pred = runner(batch)
+        pin = pts_host.pin_memory()
+        outs_host = [torch.empty(pred[k].shape, dtype=pred[k].dtype).pin_memory() for k in heads]
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        h2d = d2h = 0.0
+        for rep in range(4):
+            torch.cuda.synchronize()
+            e[0].record()
+            pts.copy_(pin, non_blocking=True)
+            e[1].record()
+            for k, o in zip(heads, outs_host):
+                o.copy_(pred[k], non_blocking=True)
+            e[2].record()
+            torch.cuda.synchronize()
+            if rep:
+                h2d += e[0].elapsed_time(e[1]) / 3
+                d2h += e[1].elapsed_time(e[2]) / 3
+        io = {"h2d_ms_per_step": round(h2d, 4), "h2d_bytes": int(pts.numel() * 4),
+              "d2h_ms_per_step": round(d2h, 4), "d2h_bytes": int(sum(o.numel() for o in outs_host) * 4),
+              "note": "pinned host buffers, one step's clouds in / four head tensors out; not part of `value`"}
+
+        # ---- north-star roofline: the operator pair ball_query + group_points(xyz) at SA1
+        # size on this step's batch, through the public operator API (int64 indices),
+        # HIP events around each launch on the launch stream.
+        with torch.no_grad():
+            ctr = F.gather_points(pts, F.farthest_point_sample(pts, M))
+            for rep in range(2 + 10):
+                if rep == 2:
+                    torch.cuda.synchronize()
+                    F.OpTimer.reset(enabled=True)
+                gidx, _ = F.ball_query(pts, ctr, cfg.radius[0], K)
+                F.group_points(pts, gidx)
+                F.query_and_group(pts, ctr, cfg.radius[0], K)
+            torch.cuda.synchronize()
+            F.OpTimer.enabled = False
+        probe = F.OpTimer.summary()
+        bq = probe["ball_query[N=%d,M=%d,K=%d]" % (N, M, K)]
+        gp = probe["group_points[C=3,N=%d,M=%d,K=%d]" % (N, M, K)]
+        nbytes = bq[2] + gp[2]
+        ms = bq[1] + gp[1]
+        roofline = {"kernel": "ball_query + group_points(xyz) at SA1 size (N=%d, M=%d, K=%d), "
+                              "operator API" % (N, M, K), "bound": "hbm",
+                    "achieved": round(nbytes / ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_launch_pair": int(nbytes), "ms_ball_query": round(bq[1], 5),
+                    "ms_group_points": round(gp[1], 5), "scenes_per_launch": B,
+                    "note": "algorithmic bytes = B*(12N+12M+8MK+8M) + B*(4CN+8MK+4CMK), C=3"}
+        tb, src, why = load_traffic("ball_query+group_points[N=%d,M=%d,K=%d,B=%d]" % (N, M, K, B))
+        roofline["traffic"] = tb
+        roofline["traffic_source" if tb is not None else "traffic_note"] = src if tb is not None else why
+        fq = probe.get("query_group[N=%d,M=%d,K=%d]" % (N, M, K))
+        if fq:   # the same pair as ONE pass (s4g_query_group_f32), same algorithmic bytes
+            roofline["fused_pair_ms"] = round(fq[1], 5)
+            roofline["fused_pair_achieved"] = round(fq[2] / fq[1] / 1e6, 2)
+            roofline["fused_pair_frac"] = round(fq[2] / fq[1] / 1e6 / HBM_PEAK_GBS, 4)
+
+    # ---- dominant kernel: every MFMA contraction launch of one step
     if gemm_ms > 0:
         dense_tf = gemm_flops / gemm_ms / 1e9
-        if getattr(runner, "precision", "fp32") == "bf16":
-            roofline_dense = {"kernel": "mlp_gemm_bf16x3_kernel in single-product bf16 mode "
-                                        "(REDUCED PRECISION, not the headline configuration)",
-                              "bound": "mfma", "achieved": round(dense_tf, 1),
+        products = {"bf16": 1, "f16x2": 3, "bf16x3": 6}.get(precision)
+        if products is not None:
+            kname = {"bf16": "mlp_chain_bf16_kernel + mlp_gemm_bf16x3_kernel<single> (v_mfma_f32_32x32x16_bf16, "
+                             "ONE product per MAC: REDUCED PRECISION, the configs[4] roofline configuration)",
+                     "f16x2": "mlp_gemm_f16x2_fused2_kernel (fused layer chains) + mlp_gemm_f16x2_kernel "
+                              "(v_mfma_f32_32x32x16_f16, 3 products per fp32-equivalent product)",
+                     "bf16x3": "mlp_gemm_bf16x3_kernel (v_mfma_f32_32x32x16_bf16, 6 products per "
+                               "fp32-equivalent product)"}[precision]
+            roofline_dense = {"kernel": kname + ", all %d contraction launches of one step; flops = those "
+                                        "executed after moving the linear first SA / FP layers in front of the "
+                                        "grouping / interpolation" % (gemm_launches // args.steps),
+                              "bound": "mfma", "achieved": round(products * dense_tf, 1),
                               "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                              "frac": round(dense_tf / BF16_MFMA_PEAK_TF, 4),
-                              "ms_per_step": round(gemm_ms, 3)}
-        elif getattr(runner, "precision", "fp32") == "f16x2":
-            # three fp16 MFMA products per fp32-equivalent product: price the flops the
-            # matrix cores actually execute against the dense fp16 peak (= the bf16 one).
-            roofline_dense = {"kernel": "mlp_gemm_f16x2_kernel + mlp_gemm_f16x2_fused2_kernel (fused layer "
-                                        "chains) (v_mfma_f32_32x32x16_f16, 3 products per "
-                                        "fp32-equivalent product), all contraction launches of one step; "
-                                        "flops = those executed after moving the linear first SA / FP "
-                                        "layers in front of the grouping / interpolation",
-                              "bound": "mfma", "achieved": round(3 * dense_tf, 1),
-                              "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                              "frac": round(3 * dense_tf / BF16_MFMA_PEAK_TF, 4),
-                              "fp32_equivalent_TFLOPs": round(dense_tf, 2),
-                              "fp32_equivalent_vs_fp32_mfma_peak": round(dense_tf / FP32_MFMA_PEAK_TF, 4),
-                              "GFLOP_per_step_fp32_equivalent": round(gemm_flops / 1e9, 1),
-                              "ms_per_step": round(gemm_ms, 3)}
-        elif getattr(runner, "precision", "fp32") == "bf16x3":
-            # six bf16 MFMA products per fp32-equivalent product: price the flops the
-            # matrix cores actually execute against the dense bf16 peak.
-            roofline_dense = {"kernel": "mlp_gemm_bf16x3_kernel (v_mfma_f32_32x32x16_bf16, 6 products "
-                                        "per fp32-equivalent product), all launches of one step",
-                              "bound": "mfma", "achieved": round(6 * dense_tf, 1),
-                              "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                              "frac": round(6 * dense_tf / BF16_MFMA_PEAK_TF, 4),
+                              "frac": round(products * dense_tf / BF16_MFMA_PEAK_TF, 4),
+                              "mfma_products_per_mac": products,
                               "fp32_equivalent_TFLOPs": round(dense_tf, 2),
                               "fp32_equivalent_vs_fp32_mfma_peak": round(dense_tf / FP32_MFMA_PEAK_TF, 4),
                               "GFLOP_per_step_fp32_equivalent": round(gemm_flops / 1e9, 1),
@@ -280,17 +430,19 @@ def main():
                           "bound": "mfma", "achieved": round(dense_tf, 2),
                           "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                           "frac": round(dense_tf / FP32_MFMA_PEAK_TF, 4)}
-
-    roofline_dense["traffic"] = None
-    if dense_traffic and getattr(runner, "precision", "") in ("bf16x3", "f16x2"):
-        roofline_dense["traffic"] = dense_traffic[0]
-        roofline_dense["traffic_source"] = dense_traffic[1]
+    tb, src, why = load_traffic("contractions[step,B=%d,N=%d,precision=%s]" % (B, N, precision))
+    roofline_dense["traffic"] = tb
+    if tb is not None:
+        roofline_dense["traffic_source"] = src
         roofline_dense["traffic_unit"] = "bytes per step (all contraction launches)"
+    else:
+        roofline_dense["traffic_note"] = why
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
         from oracle import pn2_forward
-        torch.set_num_threads(os.cpu_count() or 1)
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
         sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
         one = pts[:1].cpu().numpy()
         t1 = time.perf_counter()
@@ -301,31 +453,35 @@ def main():
         err = max(float(np.max(np.abs(got[k].cpu().numpy() - ref[k]))) for k in heads)
         cpu_baseline = {"value": round(1.0 / cpu_s, 4), "unit": "scenes/sec",
                         "cores": torch.get_num_threads(), "kind": "port",
-                        "sample": "1 scene (scene %d) of the same workload, oracle C ops "
-                                  "(1 thread) + torch CPU conv/BN (%d threads)"
+                        "sample": "1 scene (scene %d) of the same workload: oracle C operators "
+                                  "(OpenMP over centroids / queries, FPS scan over a team of <= 8) + "
+                                  "torch CPU conv/BN (%d threads)"
                                   % (scene_ids[0], torch.get_num_threads()),
+                        "seconds": round(cpu_s, 2),
                         "max_abs_err_gpu_vs_cpu": err}
 
+    arith = {"f16x2": "fp32-class: contraction as scaled 2xfp16 split, 3 MFMA products, fp32 accumulate",
+             "bf16x3": "fp32-class: contraction as exact 3xbf16 split, fp32 accumulate",
+             "bf16": "REDUCED PRECISION: plain bf16 contraction, fp32 accumulate",
+             "fp32": "fp32 MFMA"}.get(precision, "library GEMM")
+    pipe_label = (", pipelined: up to %d batches submitted besides the one being collected" % args.in_flight
+                  if pipelined else ", one batch at a time")
     line = {
         "metric": "scenes/sec (25.6k-pt clouds) end-to-end grasp inference",
         "value": round(value, 3), "unit": "scenes/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if getattr(runner, "precision", "") == "bf16" else "f32", "data": "synthetic",
+        "dtype": "bf16" if precision == "bf16" else "f32", "data": "synthetic",
         "config": {"workload": "S4G PN2_CLS forward (3 SA + 3 FP + 4 heads), %d scenes/GPU/step, "
-                               "%d-pt %s clouds, fp32 (%s), impl=%s%s" % (B, args.points, args.variant,
-                                                                      {"f16x2": "contraction as scaled 2xfp16 split, 3 MFMA products, fp32 accumulate",
-                                                                       "bf16x3": "contraction as exact 3xbf16 split, fp32 accumulate",
-                                                                       "bf16": "REDUCED PRECISION: plain bf16 contraction",
-                                                                       "fp32": "fp32 MFMA"}.get(
-                                                                          getattr(runner, "precision", ""), "library GEMM"),
-                                                                      impl,
-                                                                    ", 1 batch in flight" if pipelined else ""),
+                               "%d-pt %s clouds, %s, impl=%s%s" % (B, args.points, args.variant, arith,
+                                                                   impl, pipe_label),
                    "scenes_per_gpu": B, "num_points": args.points, "global_batch": world * B,
+                   "in_flight": args.in_flight if pipelined else 0,
                    "parallelism": "scenes sharded over %d GPU(s), all-gather of 21 ch/point" % world},
         # `roofline`: the dominant kernel of the step (the MFMA contraction, >90 % of GPU time);
         # `roofline_ball_query_group_points`: the HBM-bound operator pair the north star names.
-        "roofline": roofline_dense, "roofline_ball_query_group_points": roofline, "kernels": kernels,
+        "roofline": roofline_dense, "roofline_ball_query_group_points": roofline,
+        "step_ms": step_ms, "latency": latency, "io": io, "kernels": kernels,
         "cpu_baseline": cpu_baseline,
     }
     print(json.dumps(line))

@@ -35,6 +35,13 @@ def test_bench_prints_one_contract_line():
     assert c["kind"] == "port" and c["max_abs_err_gpu_vs_cpu"] < 1e-4
     p = d["roofline_ball_query_group_points"]
     assert p["bound"] == "hbm" and p["unit"] == "GB/s" and 0 < p["frac"] < 1
+    assert ("traffic_source" in r) != ("traffic_note" in r)      # measured on this build, or null + why
+    s = d["step_ms"]
+    assert s["p10"] <= s["median"] <= s["p90"] and s["n"] == 2
+    lat = d["latency"]
+    assert lat["latency_ms_one_batch"] > 0 and lat["latency_ms_b1"] > 0 and lat["scenes_per_sec_b1"] > 0
+    assert d["io"]["h2d_bytes"] == 16 * 3 * 25600 * 4 and d["io"]["d2h_bytes"] == 16 * 21 * 25600 * 4
+    assert "besides the one being collected" in d["config"]["workload"] and d["config"]["in_flight"] == 2
 
 
 def test_bench_under_torchrun_takes_the_rccl_path():

@@ -24,6 +24,18 @@ def test_fps_closed_form_equals_literal_on_ties(oracle, N, M):
     assert (a[:, 0] == 0).all()
 
 
+@pytest.mark.parametrize("N,M", [(4096, 200), (9001, 300), (25600, 150)])
+def test_fps_team_scan_equals_literal_on_ties(oracle, N, M):
+    """N >= 4096: the closed-form FPS splits every step's scan over an OpenMP team and
+    merges the partial winners -- same index sequence as the serial literal emulation,
+    also on tie-heavy and duplicated clouds."""
+    rng = np.random.default_rng(N + M)
+    tie = _quantized(rng, 1, N, levels=12, scale=0.0625)
+    dup = rng.random((1, 3, N // 3), dtype=np.float32)[:, :, rng.integers(0, N // 3, size=N)]
+    for pts in (tie, np.ascontiguousarray(dup)):
+        assert np.array_equal(oracle.fps(pts, M), oracle.fps_literal(pts, M))
+
+
 @pytest.mark.parametrize("N,M", [(5, 5), (40, 9), (600, 17)])
 def test_fps_literal_matches_numpy_thread_emulation(oracle, N, M):
     rng = np.random.default_rng(7 + N)
