@@ -40,7 +40,7 @@ extern "C" {
 /* 1: operators; 2: f16x2 contraction fields, crop / voxel / outlier / grid 3-NN / _ws entry points;
  * 3: fused layer chains (W2 / W3 fields), GATHER_ADD / INTERP_ADD loaders, s4g_interp_add_cl_f32,
  *    s4g_group_points_ws_f32, device-side cell choice of s4g_three_nn_grid_f32 (cell < 0). */
-#define S4G_ABI_VERSION 3
+#define S4G_ABI_VERSION 4
 
 #define S4G_OK 0
 #define S4G_EINVAL (-1)     /* bad size / null pointer */
@@ -142,7 +142,7 @@ int s4g_three_interpolate_ws_f32(const float *feat_bcn2, const int64_t *idx_bn3,
  * features BEFORE the interpolation (and to the skip features separately); this call then
  * forms out[p][c] = act(y[p][c] + bias[c] + sum_k nw[p][k] * sparse[b*N2 + nidx[p][k]][c]) on
  * channels-last tensors (y may be NULL; C % 4 == 0, C <= 1024) and leaves max|out| in
- * out_amax64 (64 uint32 slots, zeroed by the caller; may be NULL).  No reference counterpart:
+ * out_amax64 (B rows of 64 uint32 slots, one row per scene, zeroed by the caller; may be NULL).  No reference counterpart:
  * modules.py:122-128 interpolates first; the two orders agree to fp32 round-off. */
 int s4g_interp_add_cl_f32(const float *y_pc, const float *sparse_rc, const int32_t *nidx_p3,
                           const float *nw_p3, const float *bias_c, int64_t B, int64_t N1, int64_t N2,
@@ -298,6 +298,11 @@ typedef struct s4g_gemm_desc {
   const float *bias3;
   int32_t Cout3, relu3;
   const float *loader_bias; /* S4G_GEMM_LOAD_INTERP_ADD: Cin floats */
+  /* ABI >= 4: activation maxima PER SCENE.  rows_per_scene > 0: a_amax / a_amax2 / out_amax are
+   * [P / rows_per_scene][64] slot rows and loader row p reads / feeds row p / rows_per_scene, so a
+   * scene's power-of-two scales -- and its results -- do not depend on the other scenes of the
+   * batch (a tile that straddles scenes joins their rows); 0: one 64-slot row for all rows. */
+  int32_t rows_per_scene;
 } s4g_gemm_desc_t;
 
 int s4g_mlp_gemm_f32(const s4g_gemm_desc_t *desc, s4g_stream_t stream);

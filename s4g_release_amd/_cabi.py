@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libs4g_hip.so")
 
-S4G_ABI_VERSION = 3
+S4G_ABI_VERSION = 4
 S4G_FLAG_FMAD = 1
 S4G_OP_FPS, S4G_OP_BALL_QUERY, S4G_OP_THREE_NN = 1, 2, 3
 
@@ -41,7 +41,7 @@ class GemmDesc(ctypes.Structure):
         ("a_amax_floor", _f32), ("out_amax", _vp), ("W_f16x2_frag", _vp),
         ("W2_f16x2_frag", _vp), ("w2_inv_scale", _vp), ("bias2", _vp), ("Cout2", _i32), ("relu2", _i32),
         ("W3_f16x2_frag", _vp), ("w3_inv_scale", _vp), ("bias3", _vp), ("Cout3", _i32), ("relu3", _i32),
-        ("loader_bias", _vp),
+        ("loader_bias", _vp), ("rows_per_scene", _i32),
     ]
 
 

@@ -300,8 +300,15 @@ __global__ __launch_bounds__(256) void interp_add_cl_kernel(
     *reinterpret_cast<float4*>(out + (size_t)p * C + c4) = make_float4(o[0], o[1], o[2], o[3]);
   }
   if (out_amax) {
+    // one 64-slot row per scene: the block's maximum goes to every scene its rows touch (one,
+    // whenever N1 is a multiple of the block's row count)
     const uint32_t wm = wave_max_u32(__float_as_uint(tmax));
-    if ((threadIdx.x & 63) == 0) atomicMax(out_amax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63), wm);
+    if ((threadIdx.x & 63) == 0) {
+      const int64_t r0 = (int64_t)blockIdx.x * IA_ROWS * rpb;
+      const int64_t r1 = (r0 + (int64_t)IA_ROWS * rpb < P ? r0 + (int64_t)IA_ROWS * rpb : P) - 1;
+      for (int64_t sc = r0 / N1; sc <= r1 / N1; ++sc)
+        atomicMax(out_amax + sc * 64 + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63), wm);
+    }
   }
 }
 

@@ -98,6 +98,7 @@ struct GemmParams {
   const float* a_amax2;        // 64 slots or NULL
   float a_amax_floor;
   uint32_t* out_amax;          // 64 slots or NULL
+  int rps;                     // loader rows per scene: slot row s of a_amax / out_amax belongs to scene s (0: one row)
   const uint16_t* Wfrag;       // f16x2 planes in MFMA-fragment order (resident-A kernel) or NULL
   const float* lbias;          // INTERP_ADD loader: bias of the layer whose output the loader forms
   // fused second layer (mlp_gemm_f16x2_fused2_kernel): out = max_K relu(bn(W2 relu(bn(W A))))
@@ -770,6 +771,24 @@ __device__ __forceinline__ float amax_slots(const float* __restrict__ slots, int
   return __uint_as_float(wave_max_u32(__float_as_uint(slots[lane])));
 }
 
+// Activation maxima are kept PER SCENE, so that a scene's scales -- and therefore its results --
+// do not depend on which other scenes share the batch: slot row s (64 words) belongs to scene
+// s = row / rps.  A tile takes the maximum over the scenes its rows [p_lo, p_hi] touch (one scene
+// whenever rps is a multiple of the tile height, which holds at every level of the shipped
+// configuration) and publishes its own maximum to each of them.
+__device__ __forceinline__ float amax_rows(const float* __restrict__ slots, int lane, int p_lo, int p_hi,
+                                           int rps) {
+  const int s0 = rps > 0 ? p_lo / rps : 0, s1 = rps > 0 ? p_hi / rps : 0;
+  float m = amax_slots(slots + (size_t)s0 * 64, lane);
+  for (int sc = s0 + 1; sc <= s1; ++sc) m = fmaxf(m, amax_slots(slots + (size_t)sc * 64, lane));
+  return m;
+}
+__device__ __forceinline__ void amax_publish(uint32_t* __restrict__ slots, uint32_t wm, int slot, int p_lo,
+                                             int p_hi, int rps) {
+  const int s0 = rps > 0 ? p_lo / rps : 0, s1 = rps > 0 ? p_hi / rps : 0;
+  for (int sc = s0; sc <= s1; ++sc) atomicMax(slots + (size_t)sc * 64 + (slot & 63), wm);
+}
+
 // NCB = 32-wide column blocks per wave: 2 -> 128 x 128 tile (three workgroups per
 // CU), 4 -> 128 x 256 tile, wave tile 64 x 128 (two workgroups per CU): 25 % less
 // LDS and L1 traffic per MFMA and twice the matrix work per barrier; used when
@@ -805,8 +824,15 @@ __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP || LOADER =
   // activation scale: the power of two that puts the tensor maximum in [2^14, 2^15)
   float amax = p.a_amax_floor;
   constexpr bool ADD_BOUNDS = LOADER == LOAD_GATHER_ADD || LOADER == LOAD_INTERP_ADD;   // the loader SUMS its inputs
-  if (p.a_amax) amax = ADD_BOUNDS ? amax + amax_slots(p.a_amax, lane) : fmaxf(amax, amax_slots(p.a_amax, lane));
-  if (p.a_amax2) amax = ADD_BOUNDS ? amax + amax_slots(p.a_amax2, lane) : fmaxf(amax, amax_slots(p.a_amax2, lane));
+  const int p_hi = min(p0 + GM_BM, p.P) - 1;   // rows of this tile: [p0, p_hi]
+  if (p.a_amax) {
+    const float m = amax_rows(p.a_amax, lane, p0, p_hi, p.rps);
+    amax = ADD_BOUNDS ? amax + m : fmaxf(amax, m);
+  }
+  if (p.a_amax2) {
+    const float m = amax_rows(p.a_amax2, lane, p0, p_hi, p.rps);
+    amax = ADD_BOUNDS ? amax + m : fmaxf(amax, m);
+  }
   uint32_t ex = __float_as_uint(amax) >> 23;
   ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
   ex = __builtin_amdgcn_readfirstlane(ex);
@@ -943,7 +969,7 @@ __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP || LOADER =
   }
   if (p.out_amax) {
     const uint32_t wm = wave_max_u32(__float_as_uint(fmaxf(tmax, 0.f)));
-    if (lane == 0) atomicMax(p.out_amax + ((blockIdx.x * 4 + wave) & 63), wm);
+    if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave, p0, p_hi, p.rps);
   }
   gemm_epilogue<EPI, NCB>(p, acc, bg, g, p0, n0, wave, wr, wc, li, lh, smemf);
 }
@@ -1008,8 +1034,15 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
 
   float amax = p.a_amax_floor;
   constexpr bool ADD_BOUNDS = LOADER == LOAD_GATHER_ADD || LOADER == LOAD_INTERP_ADD;   // the loader SUMS its inputs
-  if (p.a_amax) amax = ADD_BOUNDS ? amax + amax_slots(p.a_amax, lane) : fmaxf(amax, amax_slots(p.a_amax, lane));
-  if (p.a_amax2) amax = ADD_BOUNDS ? amax + amax_slots(p.a_amax2, lane) : fmaxf(amax, amax_slots(p.a_amax2, lane));
+  const int p_hi = min(p0 + BM, p.P) - 1;   // rows of this tile: [p0, p_hi]
+  if (p.a_amax) {
+    const float m = amax_rows(p.a_amax, lane, p0, p_hi, p.rps);
+    amax = ADD_BOUNDS ? amax + m : fmaxf(amax, m);
+  }
+  if (p.a_amax2) {
+    const float m = amax_rows(p.a_amax2, lane, p0, p_hi, p.rps);
+    amax = ADD_BOUNDS ? amax + m : fmaxf(amax, m);
+  }
   uint32_t ex = __float_as_uint(amax) >> 23;
   ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
   ex = __builtin_amdgcn_readfirstlane(ex);
@@ -1199,7 +1232,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
         }
       if (p.out_amax) {
         const uint32_t wm = wave_max_u32(__float_as_uint(tmax));
-        if (lane == 0) atomicMax(p.out_amax + ((blockIdx.x * 4 + wave + strip_done) & 63), wm);
+        if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave + strip_done, p0, p_hi, p.rps);
       }
     } else {
 #pragma unroll
@@ -1222,7 +1255,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
       }
       if (p.out_amax) {
         const uint32_t wm = wave_max_u32(__float_as_uint(fmaxf(tmax, 0.f)));
-        if (lane == 0) atomicMax(p.out_amax + ((blockIdx.x * 4 + wave + strip_done) & 63), wm);
+        if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave + strip_done, p0, p_hi, p.rps);
       }
       gemm_epilogue<EPI, 2>(p, acc, bg, g, p0, n0, wave, wr, 0, li, lh, smemf);
     }
@@ -1267,8 +1300,15 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, 2) void mlp_gemm_f16x2_fused2_
 
   float amax = p.a_amax_floor;
   constexpr bool ADD_BOUNDS = LOADER == LOAD_GATHER_ADD || LOADER == LOAD_INTERP_ADD;   // the loader SUMS its inputs
-  if (p.a_amax) amax = ADD_BOUNDS ? amax + amax_slots(p.a_amax, lane) : fmaxf(amax, amax_slots(p.a_amax, lane));
-  if (p.a_amax2) amax = ADD_BOUNDS ? amax + amax_slots(p.a_amax2, lane) : fmaxf(amax, amax_slots(p.a_amax2, lane));
+  const int p_hi = min(p0 + BM, p.P) - 1;   // rows of this tile: [p0, p_hi]
+  if (p.a_amax) {
+    const float m = amax_rows(p.a_amax, lane, p0, p_hi, p.rps);
+    amax = ADD_BOUNDS ? amax + m : fmaxf(amax, m);
+  }
+  if (p.a_amax2) {
+    const float m = amax_rows(p.a_amax2, lane, p0, p_hi, p.rps);
+    amax = ADD_BOUNDS ? amax + m : fmaxf(amax, m);
+  }
   uint32_t ex = __float_as_uint(amax) >> 23;
   ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
   ex = __builtin_amdgcn_readfirstlane(ex);
@@ -1552,7 +1592,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, 2) void mlp_gemm_f16x2_fused2_
         }
       if (p.out_amax) {
         const uint32_t wm = wave_max_u32(__float_as_uint(omax));
-        if (lane == 0) atomicMax(p.out_amax + ((blockIdx.x * 4 + wave + strip) & 63), wm);
+        if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave + strip, p0, p_hi, p.rps);
       }
     } else {
 #pragma unroll
@@ -1574,7 +1614,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, 2) void mlp_gemm_f16x2_fused2_
       }
       if (p.out_amax) {
         const uint32_t wm = wave_max_u32(__float_as_uint(fmaxf(omax, 0.f)));
-        if (lane == 0) atomicMax(p.out_amax + ((blockIdx.x * 4 + wave + strip) & 63), wm);
+        if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave + strip, p0, p_hi, p.rps);
       }
       gemm_epilogue<EPI_MAX, 2>(q, acc, bg2, g, p0, n0, wave, wr, 0, li, lh, smemf);
     }
@@ -1758,6 +1798,7 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   p.w_inv_scale = d->w_inv_scale;
   p.a_amax = d->a_amax; p.a_amax2 = d->a_amax2; p.a_amax_floor = d->a_amax_floor;
   p.out_amax = (uint32_t*)d->out_amax;
+  p.rps = d->rows_per_scene > 0 ? d->rows_per_scene : 0;
   p.Wfrag = (const uint16_t*)d->W_f16x2_frag;
   p.lbias = d->loader_bias;
   p.Wfrag2 = (const uint16_t*)d->W2_f16x2_frag;

@@ -256,10 +256,12 @@ class FusedPointNet2:
 
     # ------------------------------------------------------------------ launches
     def _gemm(self, name, layer, P, loader, epi, relu=True, layer2=None, layer3=None, name3="heads.0",
-              **kw):
+              rows_per_scene=0, **kw):
         d = GemmDesc()
         d.loader, d.epilogue, d.groups, d.relu = loader, epi, layer.groups, int(relu)
         d.P, d.Cin, d.Kpad, d.Cout = P, layer.cin, layer.kpad, layer.cout
+        # every launch's rows are B equal blocks, one per scene: the per-scene amax rows follow
+        d.rows_per_scene = rows_per_scene or (P // self._batch if P % self._batch == 0 else 0)
         d.W, d.bias = layer.W.data_ptr(), layer.bias.data_ptr()
         d.w_gstride, d.b_gstride = layer.cout * layer.kpad, layer.cout
         d.precision = {"fp32": 0, "bf16x3": 1, "bf16": 2, "f16x2": 3}[self.precision]
@@ -371,15 +373,17 @@ class FusedPointNet2:
     def _dense(self, xyz, geo):
         """The shared-MLP contractions of every layer (MFMA).
 
-        f16x2 precision: every launch leaves max|out| in a 64-slot row of `amax`
-        (atomicMax in its epilogue) and the launch that consumes the tensor derives
-        its power-of-two activation scale from that row."""
+        f16x2 precision: every launch leaves max|out| PER SCENE in a (B, 64)-slot block of
+        `amax` (atomicMax in its epilogue) and the launch that consumes the tensor derives
+        the power-of-two activation scale of a scene's rows from that scene's slots -- a
+        scene's outputs do not depend on which other scenes share its batch."""
         B, _, N0 = xyz.shape
         dev = xyz.device
+        self._batch = B
         level_xyz, level_n = geo["level_xyz"], geo["level_n"]
         n_launch = sum(len(sa["layers"]) for sa in self.sa) + \
             sum(len(fp["layers"]) for fp in self.fp) + len(self.head_layers) + 1 + len(self.sa) + 2 * len(self.fp)
-        amax = torch.zeros((n_launch, 64), dtype=torch.float32, device=dev)
+        amax = torch.zeros((n_launch, B, 64), dtype=torch.float32, device=dev)
         rows = iter(amax.unbind(0))
         level_feat = [(None, None)]                  # (tensor, amax row)
         feat = feat_amax = None

@@ -1,0 +1,146 @@
+"""A scene's results must not depend on which other scenes share its batch (configs[2]: 16
+scenes per step).  The f16x2 contraction scales activations by powers of two taken from running
+maxima; those maxima are kept PER SCENE (include/s4g_ops.h: rows_per_scene), so the batched
+forward is the single-scene forward, scene by scene -- also next to an outlier or a
+non-finite scene.  Reference: the forward has no cross-scene term at all (eval-mode BatchNorm,
+`PointNet2_tcls.py:99-148`)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as GU
+
+pytestmark = pytest.mark.gpu
+HEADS = ("score", "frame_R", "frame_t", "movable_logits")
+
+
+def _run(desc_kwargs):
+    from s4g_release_amd import _cabi
+    d = _cabi.GemmDesc()
+    for k, v in desc_kwargs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.data_ptr()
+        setattr(d, k, v)
+    rc = _cabi.lib().s4g_mlp_gemm_f32(ctypes.byref(d), torch.cuda.current_stream().cuda_stream)
+    _cabi.check(rc, "gemm")
+    torch.cuda.synchronize()
+
+
+def test_b16_full_size_every_scene_equals_itself_alone_and_the_oracle(dev):
+    """configs[2]: 16 scenes x 25 600 points through the fused path: every scene's four outputs
+    equal the same scene run alone (<= 1e-6; bit-identical in practice), indices identical, and
+    scenes 0 and 15 are within 1e-4 of the CPU oracle forward."""
+    from oracle import pn2_forward
+    from s4g_release_amd import synth
+    from s4g_release_amd.fused import FusedPointNet2
+    net = GU.build_full_model(20260101).to(dev)
+    run = FusedPointNet2(net)
+    pts = torch.from_numpy(synth.make_batch(list(range(16)), 25600)).to(dev)
+    with torch.no_grad():
+        full, inter = run({"scene_points": pts}, return_intermediates=True)
+        full = {k: v.clone() for k, v in full.items()}
+        inter = {k: v.clone() for k, v in inter.items()}
+        worst = 0.0
+        for s in range(16):
+            one, i1 = run({"scene_points": pts[s:s + 1].contiguous()}, return_intermediates=True)
+            for k in HEADS:
+                worst = max(worst, float((one[k][0] - full[k][s]).abs().max()))
+            for k in ("fps0", "fps1", "fps2", "ball0", "ball2", "nn0", "nn2"):
+                assert torch.equal(i1[k][0], inter[k][s]), (k, s)
+    assert worst <= 1e-6, worst
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    cfg = GU.FULL
+    for s in (0, 15):
+        ref = pn2_forward.forward(sd, pts[s:s + 1].cpu().numpy(), cfg["num_centroids"], cfg["radius"],
+                                  cfg["num_neighbours"])
+        for k in HEADS:
+            err = float(np.max(np.abs(full[k][s:s + 1].cpu().numpy() - ref[k])))
+            assert err < 1e-4, (s, k, err)
+
+
+def _layer(w):
+    from s4g_release_amd.fused import fragment_order, split_f16x2
+    planes, inv = split_f16x2(w)
+    return planes, inv, fragment_order(planes.unsqueeze(1))
+
+
+@pytest.mark.parametrize("chain", [False, True])
+def test_per_scene_scales_isolate_outlier_and_nonfinite_scenes(dev, chain):
+    """Four scenes of 256 rows: scene 1 is 2^12 times larger, scene 2 holds an inf and a NaN.
+    Launch 1 (plain contraction) publishes per-scene maxima; launch 2 (tiled kernel or fused
+    two-layer chain) consumes them.  Scenes 0 and 3 must come out bit-identical to the same two
+    launches on those scenes alone, and fp32-accurate; scene 1 is fp32-accurate at its own scale."""
+    g = torch.Generator(device="cpu").manual_seed(11)
+    S, R, C = 4, 256, 128
+    A = torch.randn(S * R, C, generator=g)
+    A[R:2 * R] *= 4096.0
+    A[2 * R + 5, 7] = float("inf")
+    A[2 * R + 9, 3] = float("nan")
+    A = A.to(dev)
+    W1 = (torch.randn(C, C, generator=g) / C ** 0.5).to(dev)
+    W2 = (torch.randn(C, C, generator=g) / C ** 0.5).to(dev)
+    W3 = (torch.randn(C, C, generator=g) / C ** 0.5).to(dev)
+    b1, b2, b3 = (torch.randn(C, generator=g).to(dev) for _ in range(3))
+    p1, i1, f1 = _layer(W1)
+    p2, i2, f2 = _layer(W2)
+    p3, i3, f3 = _layer(W3)
+
+    def two_launches(a, scenes):
+        rows = a.shape[0]
+        h = torch.full((rows, C), float("nan"), device=dev)
+        out = torch.full((rows, C), float("nan"), device=dev)
+        a_amax = torch.zeros((scenes, 64), device=dev)
+        a_amax[:, 3] = a.view(scenes, -1).abs().amax(dim=1).nan_to_num(nan=float("inf"))
+        h_amax = torch.zeros((scenes, 64), device=dev)
+        common = dict(loader=0, epilogue=0, groups=1, relu=1, P=rows, Cin=C, Kpad=C, Cout=C, lda=C, ldc=C,
+                      precision=3, Kpad16=C, rows_per_scene=R, a_amax_floor=0.0)
+        _run(dict(common, W=W1, bias=b1, A=a, out=h, W_f16x2=p1, w_inv_scale=i1, a_amax=a_amax,
+                  out_amax=h_amax))
+        kw = dict(common, W=W2, bias=b2, A=h, out=out, W_f16x2=p2, w_inv_scale=i2, a_amax=h_amax,
+                  out_amax=torch.zeros((scenes, 64), device=dev))
+        if chain:
+            kw.update(W_f16x2_frag=f2, W2_f16x2_frag=f3, w2_inv_scale=i3, bias2=b3, Cout2=C, relu2=1)
+        _run(kw)
+        return h, out, h_amax
+
+    h, out, h_amax = two_launches(A, S)
+    # the published maxima are per scene: the small scenes' rows do not see the big scene
+    hmax = h.view(S, -1).abs().amax(dim=1)
+    for s in (0, 1, 3):
+        assert h_amax[s].max().item() == hmax[s].item(), s
+    assert h_amax[0].max().item() < 1e-2 * h_amax[1].max().item()
+    for s in (0, 3):
+        a_s = A[s * R:(s + 1) * R].contiguous()
+        _, alone, _ = two_launches(a_s, 1)
+        assert torch.equal(alone, out[s * R:(s + 1) * R]), s
+    for s in (0, 1, 3):
+        a_s = A[s * R:(s + 1) * R].double()
+        ref = ((a_s @ W1.double().t() + b1.double()).clamp_min(0) @ W2.double().t() + b2.double()).clamp_min(0)
+        if chain:
+            ref = (ref @ W3.double().t() + b3.double()).clamp_min(0)
+        got = out[s * R:(s + 1) * R].double()
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max().item() < 1e-5 * ref.abs().max().item(), s
+
+
+def test_batch_with_a_rescaled_scene_leaves_the_others_unchanged(dev):
+    """Network level: scenes 0..3 with scene 1 replaced by a copy blown up 8x about its centroid
+    (other feature magnitudes, other neighbourhood statistics): scenes 0, 2, 3 equal their
+    single-scene results, every index tensor included."""
+    from s4g_release_amd import synth
+    from s4g_release_amd.fused import FusedPointNet2
+    net = GU.build_full_model(20260101).to(dev)
+    run = FusedPointNet2(net)
+    pts = torch.from_numpy(synth.make_batch([0, 1, 2, 3], 25600)).to(dev)
+    c = pts[1].mean(dim=1, keepdim=True)
+    pts[1] = (pts[1] - c) * 8.0 + c
+    with torch.no_grad():
+        full = {k: v.clone() for k, v in run({"scene_points": pts}).items()}
+        for s in (0, 2, 3):
+            one = run({"scene_points": pts[s:s + 1].contiguous()})
+            for k in HEADS:
+                assert float((one[k][0] - full[k][s]).abs().max()) <= 1e-6, (s, k)
+    for k in HEADS:
+        assert torch.isfinite(full[k]).all()
