@@ -400,9 +400,10 @@ def main():
         dense_tf = gemm_flops / gemm_ms / 1e9
         products = {"bf16": 1, "f16x2": 3, "bf16x3": 6}.get(precision)
         if products is not None:
-            kname = {"bf16": "mlp_chain_bf16_kernel + mlp_gemm_bf16x3_kernel<single> (v_mfma_f32_32x32x16_bf16, "
-                             "ONE product per MAC: REDUCED PRECISION, the configs[4] roofline configuration)",
-                     "f16x2": "mlp_gemm_f16x2_fused2_kernel (fused layer chains) + mlp_gemm_f16x2_kernel "
+            kname = {"bf16": "mlp_chain_kernel<PL=1> (fused layer chains, one bf16 plane) + mlp_gemm_bf16x3_kernel in "
+                             "single-product mode (v_mfma_f32_32x32x16_bf16, ONE product per MAC: REDUCED "
+                             "PRECISION, the configs[4] roofline configuration)",
+                     "f16x2": "mlp_chain_kernel<PL=2> (fused layer chains) + mlp_gemm_f16x2_kernel "
                               "(v_mfma_f32_32x32x16_f16, 3 products per fp32-equivalent product)",
                      "bf16x3": "mlp_gemm_bf16x3_kernel (v_mfma_f32_32x32x16_bf16, 6 products per "
                                "fp32-equivalent product)"}[precision]

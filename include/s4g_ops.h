@@ -277,7 +277,11 @@ typedef struct s4g_gemm_desc {
    * fits LDS) use the resident-A kernel, which streams W fragments straight into
    * the matrix-core operand registers. */
   const void *W_f16x2_frag;
-  /* ABI >= 3, optional: a SECOND layer fused behind this one (S4G_GEMM_F16X2, loader PLAIN
+  /* ABI >= 4: with precision S4G_GEMM_BF16 the three *_f16x2_frag pointers hold ONE bf16 plane
+   * each in the same fragment order ([groups][Cout/32][Kpad16/16][64 lanes][8 bf16]) and select the
+   * single-product form of the fused chains below (no scales: w*_inv_scale, a_amax*, out_amax are
+   * ignored) -- the reduced-precision roofline configuration.
+   * ABI >= 3, optional: a SECOND layer fused behind this one (S4G_GEMM_F16X2, loader PLAIN
    * GATHER_MLP1, GATHER_ADD or INTERP_ADD, Kpad16 == Cout == C with C = 128, 256 or 512 -- for the plain
    * loader + STORE also Kpad16 == 2 C == 512: the first layer then runs through two panel loads
    * --, Cout2 % 64 == 0; epilogue MAX

@@ -101,7 +101,7 @@ struct GemmParams {
   int rps;                     // loader rows per scene: slot row s of a_amax / out_amax belongs to scene s (0: one row)
   const uint16_t* Wfrag;       // f16x2 planes in MFMA-fragment order (resident-A kernel) or NULL
   const float* lbias;          // INTERP_ADD loader: bias of the layer whose output the loader forms
-  // fused second layer (mlp_gemm_f16x2_fused2_kernel): out = max_K relu(bn(W2 relu(bn(W A))))
+  // fused second layer (mlp_chain_kernel): out = max_K relu(bn(W2 relu(bn(W A))))
   const uint16_t* Wfrag2;
   const float* w_inv_scale2;
   const float* bias2;
@@ -1280,8 +1280,20 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
 // less -- no spills in the deep-first-layer and eight-wave forms
 constexpr int GF_RING = 2;
 
-template <int LOADER, int EPI2, int RW, int KC>
-__global__ __launch_bounds__(RW == 8 ? 512 : 256, 2) void mlp_gemm_f16x2_fused2_kernel(const GemmParams p) {
+// PL = planes per operand: 2 = the f16x2 split above (three fp16 products per step, power-of-two
+// scales), 1 = ONE bf16 plane and one product (S4G_GEMM_BF16, the reduced-precision roofline
+// configuration: bf16 has fp32's exponent range, so there are no scales, no maxima and no
+// barrier for them; the panel is half as large, so twice as many workgroups fit a CU).
+template <int PL>
+__device__ __forceinline__ f32x16 chain_mfma(const uint4 a, const uint4 b, const f32x16 c) {
+  if constexpr (PL == 2)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int LOADER, int EPI2, int RW, int KC, int PL>
+__global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) void mlp_chain_kernel(const GemmParams p) {
   // RW = 2: 128 positions, 128-wide layers, 4 waves; RW = 1: 64 positions, 256-wide layers, 4 waves;
   // RW = 8: 64 positions, 512-wide layers, EIGHT waves (one workgroup per CU: its 133 KB panel)
   constexpr int CW = RW == 8 ? 8 : 4 / RW, RWN = RW == 8 ? 1 : RW;
@@ -1289,8 +1301,8 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, 2) void mlp_gemm_f16x2_fused2_
   constexpr int RS = 8 * NW, RPT = BM / RS;   // loader: 8 lanes per row, RS rows per pass
   constexpr int astr = K + 8, aplane = BM * astr, KS = K >> 4;
   extern __shared__ __attribute__((aligned(16))) float smemf[];
-  uint16_t* Ah = reinterpret_cast<uint16_t*>(smemf);   // [2][BM][K + 8]
-  float* scr = reinterpret_cast<float*>(Ah + 2 * aplane);   // [NW waves][128] scale | bias, then NW tile maxima
+  uint16_t* Ah = reinterpret_cast<uint16_t*>(smemf);   // [PL][BM][K + 8]
+  float* scr = reinterpret_cast<float*>(Ah + PL * aplane);   // [NW waves][128] scale | bias, then NW tile maxima
   const int g = blockIdx.y;
 
   const int t = threadIdx.x;
@@ -1298,43 +1310,43 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, 2) void mlp_gemm_f16x2_fused2_
   const int wave = t >> 6;
   const int p0 = blockIdx.x * BM;
 
-  float amax = p.a_amax_floor;
+  float amax = PL == 2 ? p.a_amax_floor : 1.f;
   constexpr bool ADD_BOUNDS = LOADER == LOAD_GATHER_ADD || LOADER == LOAD_INTERP_ADD;   // the loader SUMS its inputs
   const int p_hi = min(p0 + BM, p.P) - 1;   // rows of this tile: [p0, p_hi]
-  if (p.a_amax) {
+  if (PL == 2 && p.a_amax) {
     const float m = amax_rows(p.a_amax, lane, p0, p_hi, p.rps);
     amax = ADD_BOUNDS ? amax + m : fmaxf(amax, m);
   }
-  if (p.a_amax2) {
+  if (PL == 2 && p.a_amax2) {
     const float m = amax_rows(p.a_amax2, lane, p0, p_hi, p.rps);
     amax = ADD_BOUNDS ? amax + m : fmaxf(amax, m);
   }
   uint32_t ex = __float_as_uint(amax) >> 23;
   ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
   ex = __builtin_amdgcn_readfirstlane(ex);
-  const float sa = __uint_as_float((268u - ex) << 23);
-  const float inv_sa = __uint_as_float((ex - 14u) << 23);
+  const float sa = PL == 2 ? __uint_as_float((268u - ex) << 23) : 1.f;
+  const float inv_sa = PL == 2 ? __uint_as_float((ex - 14u) << 23) : 1.f;
 
   const int wr = wave / CW, wc = wave % CW;
   const int li = lane & 31, lh = lane >> 5;
   const int wc_u = __builtin_amdgcn_readfirstlane(wc);
   const uint32_t wf_lane = (uint32_t)lane * 16u;
-  constexpr size_t cb_stride = (size_t)KS * 2048;               // bytes between n32 and n32 + 1
+  constexpr size_t cb_stride = (size_t)KS * PL * 1024;          // bytes between n32 and n32 + 1
   constexpr size_t strip_stride = (size_t)CW * 2 * cb_stride;   // bytes between 128-channel strips
   // layer 1 may contract over kchunks * K inputs: its panel is loaded K columns at a time and
   // the accumulators run through all chunks before the first epilogue
   constexpr int kchunks = KC;   // Kpad16 / K
   const size_t cbs1 = (size_t)kchunks * cb_stride;              // layer 1's bytes between n32 blocks
-  const char* __restrict__ w1 = reinterpret_cast<const char*>(p.Wfrag + (size_t)g * p.Cout * p.Kpad16 * 2) +
+  const char* __restrict__ w1 = reinterpret_cast<const char*>(p.Wfrag + (size_t)g * p.Cout * p.Kpad16 * PL) +
                                 (size_t)(wc_u * 2) * cbs1;
   // chain: layer 1 -> [layer 2 when a third layer follows] -> final layer (2 or 3)
   const bool tri = p.Wfrag3 != nullptr;
-  const char* __restrict__ wmid = reinterpret_cast<const char*>(p.Wfrag2 + (size_t)g * p.Cout2 * K * 2) +
+  const char* __restrict__ wmid = reinterpret_cast<const char*>(p.Wfrag2 + (size_t)g * p.Cout2 * K * PL) +
                                   (size_t)(wc_u * 2) * cb_stride;
   const int CoutF = tri ? p.Cout3 : p.Cout2;
-  const float* __restrict__ scF = (tri ? p.w_inv_scale3 : p.w_inv_scale2) + (size_t)g * CoutF;
+  const float* __restrict__ scF = PL == 2 ? (tri ? p.w_inv_scale3 : p.w_inv_scale2) + (size_t)g * CoutF : nullptr;
   const float* __restrict__ bgF = (tri ? p.bias3 : p.bias2) + (size_t)g * CoutF;
-  const char* __restrict__ w2 = tri ? reinterpret_cast<const char*>(p.Wfrag3 + (size_t)g * CoutF * K * 2) +
+  const char* __restrict__ w2 = tri ? reinterpret_cast<const char*>(p.Wfrag3 + (size_t)g * CoutF * K * PL) +
                                           (size_t)(wc_u * 2) * cb_stride
                                     : wmid;
   const int nstrip2 = (CoutF + 64 * CW - 1) / (64 * CW);
@@ -1342,15 +1354,15 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, 2) void mlp_gemm_f16x2_fused2_
   // out; its ring must not prefetch fragments that do not exist
   const bool active0 = wc_u * 64 < CoutF;
 
-  uint4 ring[GF_RING][2][2];
+  uint4 ring[GF_RING][2][PL];
 #pragma unroll
   for (int d = 0; d < GF_RING; ++d)
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
+      for (int pl = 0; pl < PL; ++pl)
         ring[d][cb][pl] = *reinterpret_cast<const uint4*>(
-            w1 + ((size_t)cb * cbs1 + (size_t)(d * 2 + pl) * 1024) + wf_lane);
+            w1 + ((size_t)cb * cbs1 + (size_t)(d * PL + pl) * 1024) + wf_lane);
 
   // (the loader's per-row state stays live through the first layer only when that layer is
   // more than one panel deep: KC > 1)
@@ -1374,11 +1386,16 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, 2) void mlp_gemm_f16x2_fused2_
       for (int kt = 0; kt < DEPTH; ++kt)
 #pragma unroll
         for (int s = 0; s < RPT; ++s) {
-          uint2 h, l;
-          split2_h<false>(ra[kt][s], sa, h, l);
           uint16_t* dst = Ah + (srow + RS * s) * astr + (kt0 + kt) * 32 + chunk * 4;
-          *reinterpret_cast<uint2*>(dst) = h;
-          *reinterpret_cast<uint2*>(dst + aplane) = l;
+          if constexpr (PL == 2) {
+            uint2 h, l;
+            split2_h<false>(ra[kt][s], sa, h, l);
+            *reinterpret_cast<uint2*>(dst) = h;
+            *reinterpret_cast<uint2*>(dst + aplane) = l;
+          } else {
+            *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pk_bf16(ra[kt][s].x, ra[kt][s].y),
+                                                        cvt_pk_bf16(ra[kt][s].z, ra[kt][s].w));
+          }
         }
       if (DEPTH < NKT) __builtin_amdgcn_sched_barrier(0);
     }
@@ -1397,14 +1414,13 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, 2) void mlp_gemm_f16x2_fused2_
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   };
-  f16x8 afn[2][2];
+  uint4 afn[2][PL];
   auto prime_a = [&]() {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-        afn[rb][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(
-            a_lane + pl * aplane + rb * 32 * astr));
+      for (int pl = 0; pl < PL; ++pl)
+        afn[rb][pl] = *reinterpret_cast<const uint4*>(a_lane + pl * aplane + rb * 32 * astr);
   };
 
   // one 128-deep strip: 8 steps of 12 MFMAs; W fragments through the ring, refilled RING
@@ -1413,51 +1429,52 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, 2) void mlp_gemm_f16x2_fused2_
   _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                  \
     const int d = ks % GF_RING;                                                                        \
     const int ksn = ks + 1 == KS ? 0 : ks + 1;                                                         \
-    f16x8 af[2][2], bf[2][2];                                                                          \
-    _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) { \
+    uint4 af[2][PL], bf[2][PL];                                                                        \
+    _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) { \
       af[rb][pl] = afn[rb][pl];                                                                        \
-      afn[rb][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(                         \
-          a_lane + pl * aplane + rb * 32 * astr + ksn * 16));                                          \
+      afn[rb][pl] = *reinterpret_cast<const uint4*>(a_lane + pl * aplane + rb * 32 * astr + ksn * 16); \
     }                                                                                                  \
-    _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)   \
-      bf[cb][pl] = __builtin_bit_cast(f16x8, ring[d][cb][pl]);                                         \
+    _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)  \
+      bf[cb][pl] = ring[d][cb][pl];                                                                    \
     {                                                                                                  \
       const int kr = ks + GF_RING;                                                                     \
       const char* src = kr < KS ? (wcur) : (wnext);                                                    \
       const size_t cbs = kr < KS ? (cbs_cur) : (cbs_next);                                             \
       const int kk = kr < KS ? kr : kr - KS;                                                           \
-      _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) \
+      _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) \
         ring[d][cb][pl] = *reinterpret_cast<const uint4*>(                                             \
-            src + ((size_t)cb * cbs + (size_t)(kk * 2 + pl) * 1024) + wf_lane);                        \
+            src + ((size_t)cb * cbs + (size_t)(kk * PL + pl) * 1024) + wf_lane);                       \
     }                                                                                                  \
-    S4G_F2_TERM(SWAPPED, 0, 1)                                                                         \
-    S4G_F2_TERM(SWAPPED, 1, 0)                                                                         \
+    if constexpr (PL == 2) {                                                                           \
+      S4G_F2_TERM(SWAPPED, 0, 1)                                                                       \
+      S4G_F2_TERM(SWAPPED, 1, 0)                                                                       \
+    }                                                                                                  \
     S4G_F2_TERM(SWAPPED, 0, 0)                                                                         \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                    \
+    _Pragma("unroll") for (int q = 0; q < 2 * PL; ++q) {                                               \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                               \
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                               \
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                               \
     }                                                                                                  \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                 \
+    if constexpr (PL == 2) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                          \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
   }
 #define S4G_F2_TERM(SWAPPED, PA, PB)                                                                   \
   if constexpr (SWAPPED) {                                                                             \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0][PB], af[0][PA], acc[0][0], 0, 0, 0);      \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0][PB], af[1][PA], acc[0][1], 0, 0, 0);      \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[1][PB], af[0][PA], acc[1][0], 0, 0, 0);      \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[1][PB], af[1][PA], acc[1][1], 0, 0, 0);      \
+    acc[0][0] = chain_mfma<PL>(bf[0][PB], af[0][PA], acc[0][0]);                                       \
+    acc[0][1] = chain_mfma<PL>(bf[0][PB], af[1][PA], acc[0][1]);                                       \
+    acc[1][0] = chain_mfma<PL>(bf[1][PB], af[0][PA], acc[1][0]);                                       \
+    acc[1][1] = chain_mfma<PL>(bf[1][PB], af[1][PA], acc[1][1]);                                       \
   } else {                                                                                             \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][PA], bf[0][PB], acc[0][0], 0, 0, 0);      \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][PA], bf[1][PB], acc[0][1], 0, 0, 0);      \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][PA], bf[0][PB], acc[1][0], 0, 0, 0);      \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][PA], bf[1][PB], acc[1][1], 0, 0, 0);      \
+    acc[0][0] = chain_mfma<PL>(af[0][PA], bf[0][PB], acc[0][0]);                                       \
+    acc[0][1] = chain_mfma<PL>(af[0][PA], bf[1][PB], acc[0][1]);                                       \
+    acc[1][0] = chain_mfma<PL>(af[1][PA], bf[0][PB], acc[1][0]);                                       \
+    acc[1][1] = chain_mfma<PL>(af[1][PA], bf[1][PB], acc[1][1]);                                       \
   }
 
   // ---- panel phases: H = relu(bn(W A)), C channels = one strip, operands swapped
   const char* wcur = w1;
-  const float* __restrict__ scp = p.w_inv_scale + (size_t)g * p.b_gstride;
+  const float* __restrict__ scp = PL == 2 ? p.w_inv_scale + (size_t)g * p.b_gstride : nullptr;
   const float* __restrict__ bp = p.bias + (size_t)g * p.b_gstride;
   int relu_ph = p.relu;
   float inv_in = inv_sa, inv_sh = 1.f;
@@ -1468,7 +1485,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, 2) void mlp_gemm_f16x2_fused2_
   prime_a();
   {
     const int n = wc * 64 + lane;   // channel whose scale / bias this lane stages for its wave
-    epi_s[lane] = inv_in * scp[n];
+    epi_s[lane] = PL == 2 ? inv_in * scp[n] : 1.f;
     epi_s[64 + lane] = bp[n];
   }
   if (KC > 1 && ph == 0) {
@@ -1505,41 +1522,49 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, 2) void mlp_gemm_f16x2_fused2_
           float x = __fmaf_rn(acc[nb][pb][4 * j + e], scv[e], bv[e]);
           if (relu_ph) x = fmaxf(x, 0.f);
           acc[nb][pb][4 * j + e] = x;
-          tmax = fmaxf(tmax, fabsf(x));
+          if constexpr (PL == 2) tmax = fmaxf(tmax, fabsf(x));
         }
     }
-  {
+  float sh = 1.f;
+  if constexpr (PL == 2) {
     const uint32_t wm = wave_max_u32(__float_as_uint(tmax));
     if (lane == 0) scr[NW * 128 + wave] = __uint_as_float(wm);
   }
   __syncthreads();   // every wave is done with the old panel; the four maxima are visible
-  float hmax = scr[NW * 128];
+  if constexpr (PL == 2) {
+    float hmax = scr[NW * 128];
 #pragma unroll
-  for (int w = 1; w < NW; ++w) hmax = fmaxf(hmax, scr[NW * 128 + w]);
-  uint32_t exh = __float_as_uint(hmax) >> 23;
-  exh = exh < 15u ? 15u : (exh > 240u ? 240u : exh);
-  exh = __builtin_amdgcn_readfirstlane(exh);
-  const float sh = __uint_as_float((268u - exh) << 23);
-  inv_sh = __uint_as_float((exh - 14u) << 23);
+    for (int w = 1; w < NW; ++w) hmax = fmaxf(hmax, scr[NW * 128 + w]);
+    uint32_t exh = __float_as_uint(hmax) >> 23;
+    exh = exh < 15u ? 15u : (exh > 240u ? 240u : exh);
+    exh = __builtin_amdgcn_readfirstlane(exh);
+    sh = __uint_as_float((268u - exh) << 23);
+    inv_sh = __uint_as_float((exh - 14u) << 23);
+  }
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int pb = 0; pb < 2; ++pb) {
-        const float4 v = make_float4(acc[nb][pb][4 * j], acc[nb][pb][4 * j + 1], acc[nb][pb][4 * j + 2],
-                                     acc[nb][pb][4 * j + 3]);
-        uint2 h, l;
-        split2_h<false>(v, sh, h, l);
         uint16_t* dst = Ah + (wr * 64 + pb * 32 + li) * astr + wc * 64 + nb * 32 + 8 * j + 4 * lh;
-        *reinterpret_cast<uint2*>(dst) = h;
-        *reinterpret_cast<uint2*>(dst + aplane) = l;
+        if constexpr (PL == 2) {
+          const float4 v = make_float4(acc[nb][pb][4 * j], acc[nb][pb][4 * j + 1], acc[nb][pb][4 * j + 2],
+                                       acc[nb][pb][4 * j + 3]);
+          uint2 h, l;
+          split2_h<false>(v, sh, h, l);
+          *reinterpret_cast<uint2*>(dst) = h;
+          *reinterpret_cast<uint2*>(dst + aplane) = l;
+        } else {
+          *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pk_bf16(acc[nb][pb][4 * j], acc[nb][pb][4 * j + 1]),
+                                                      cvt_pk_bf16(acc[nb][pb][4 * j + 2], acc[nb][pb][4 * j + 3]));
+        }
       }
   __syncthreads();
   // the next panel phase (three-layer chains) reads this panel through layer 2's weights
   inv_in = inv_sh;
   wcur = wmid;
-  scp = p.w_inv_scale2 + (size_t)g * p.Cout2;
+  scp = PL == 2 ? p.w_inv_scale2 + (size_t)g * p.Cout2 : nullptr;
   bp = p.bias2 + (size_t)g * p.Cout2;
   relu_ph = p.relu2;
   }
@@ -1555,7 +1580,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, 2) void mlp_gemm_f16x2_fused2_
   for (int strip = 0; strip < nstrip2; ++strip, wstrip += strip_stride) {
     if ((strip * CW + wc_u) * 64 >= CoutF) break;
     const int n = (strip * CW + wc) * 64 + lane;
-    const float e_sc = inv_sh * scF[n];
+    const float e_sc = PL == 2 ? inv_sh * scF[n] : 1.f;
     const float e_bias = bg2[n];
     const char* wnext = ((strip + 1) * CW + wc_u) * 64 < CoutF ? wstrip + strip_stride : wstrip;
     S4G_F2_STRIP(EPI2 == EPI_STORE, wstrip, cb_stride, wnext, cb_stride)
@@ -1624,18 +1649,18 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, 2) void mlp_gemm_f16x2_fused2_
 #undef S4G_F2_TERM
 }
 
-template <int LOADER, int EPI2, int RW, int KC>
-static int launch_gemm_f16x2_fused2(const GemmParams& p, int groups, hipStream_t st) {
+template <int LOADER, int EPI2, int RW, int KC, int PL>
+static int launch_mlp_chain(const GemmParams& p, int groups, hipStream_t st) {
   constexpr int CW = RW == 8 ? 8 : 4 / RW, RWN = RW == 8 ? 1 : RW;
   constexpr int BM = 64 * RWN, K = 64 * CW, NW = RWN * CW;
-  constexpr size_t lds = sizeof(uint16_t) * 2 * BM * (size_t)(K + 8) + sizeof(float) * (NW * 128 + 16);
+  constexpr size_t lds = sizeof(uint16_t) * PL * BM * (size_t)(K + 8) + sizeof(float) * (NW * 128 + 16);
   static_assert(lds <= (RW == 8 ? 160 : 80) * 1024, "two workgroups per CU (one for the 8-wave form)");
   static const hipError_t attr = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&mlp_gemm_f16x2_fused2_kernel<LOADER, EPI2, RW, KC>),
+      reinterpret_cast<const void*>(&mlp_chain_kernel<LOADER, EPI2, RW, KC, PL>),
       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr != hipSuccess) return (int)attr;
   const dim3 grid((unsigned)((p.P + BM - 1) / BM), (unsigned)groups);
-  hipLaunchKernelGGL((mlp_gemm_f16x2_fused2_kernel<LOADER, EPI2, RW, KC>), grid, dim3(64 * NW), lds, st, p);
+  hipLaunchKernelGGL((mlp_chain_kernel<LOADER, EPI2, RW, KC, PL>), grid, dim3(64 * NW), lds, st, p);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }
@@ -1861,17 +1886,19 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
                c256 = d->Cout == 256 && (d->Kpad16 == 256 || d->Kpad16 == 512),
                c512 = d->Cout == 512 && d->Kpad16 == 512;
     const bool store = d->epilogue == S4G_GEMM_EPI_STORE;
-    if (!h2 || (!store && (d->epilogue != S4G_GEMM_EPI_MAX || d->K != 64 || (d->P & 63))) ||
+    const bool bf1 = d->precision == S4G_GEMM_BF16;   // one bf16 plane, one product, no scales
+    if ((!h2 && !bf1) || (!store && (d->epilogue != S4G_GEMM_EPI_MAX || d->K != 64 || (d->P & 63))) ||
         (!c128 && !c256 && !c512) || d->Cout2 <= 0 || (d->Cout2 & 63) || (!store && d->groups != 1) || !d->W_f16x2_frag ||
-        (d->W3_f16x2_frag && (d->Cout2 != d->Cout || d->Cout3 <= 0 || (d->Cout3 & 63) || !d->w3_inv_scale ||
-                              !d->bias3)) ||
-        !d->w2_inv_scale || !d->bias2 ||
+        (d->W3_f16x2_frag && (d->Cout2 != d->Cout || d->Cout3 <= 0 || (d->Cout3 & 63) ||
+                              (h2 && !d->w3_inv_scale) || !d->bias3)) ||
+        (h2 && !d->w2_inv_scale) || !d->bias2 ||
         (store && (((d->ldc | d->c_coff | d->c_gcol) & 3) || ((uintptr_t)d->out & 15))))
       return S4G_EINVAL;
 #define S4G_FUSED2_CASE(L, E, R, KCH)                                                        \
   if (d->loader == L && (int)d->epilogue == (int)E && (c128 ? 2 : (c256 ? 1 : 8)) == R &&     \
       d->Kpad16 / d->Cout == KCH)                                                             \
-    return launch_gemm_f16x2_fused2<L, E, R, KCH>(p, d->groups, st);
+    return bf1 ? launch_mlp_chain<L, E, R, KCH, 1>(p, d->groups, st)                 \
+               : launch_mlp_chain<L, E, R, KCH, 2>(p, d->groups, st);
     S4G_FUSED2_LIST(S4G_FUSED2_CASE)
 #undef S4G_FUSED2_CASE
     return S4G_EUNSUPPORTED;

@@ -92,13 +92,13 @@ def split_f16x2(w):
 
 
 def fragment_order(planes):
-    """(2, G, Cout, K16) fp16 planes -> (G, Cout/32, K16/16, 2, 64, 8): each 32-channel x
+    """(PL, G, Cout, K16) 16-bit planes -> (G, Cout/32, K16/16, PL, 64, 8): each 32-channel x
     16-deep MFMA operand fragment as one contiguous 1 KB block per plane, lane =
     32 * (k // 8 % 2) + n % 32 (the 32x32x16 A/B operand layout)."""
     if planes.dim() == 3:
         planes = planes.unsqueeze(1)
-    two, G, cout, k16 = planes.shape
-    x = planes.view(2, G, cout // 32, 32, k16 // 16, 2, 8)      # pl g n32 li ks lh i
+    npl, G, cout, k16 = planes.shape
+    x = planes.reshape(npl, G, cout // 32, 32, k16 // 16, 2, 8)  # pl g n32 li ks lh i
     return x.permute(1, 2, 4, 0, 5, 3, 6).contiguous()           # g n32 ks pl lh li i
 
 
@@ -120,6 +120,8 @@ class _Layer:
         self.W3 = split_bf16x3(w16)
         self.Wh2, self.w_inv_scale = split_f16x2(w16)
         self.Wfrag = fragment_order(self.Wh2) if self.cout % 32 == 0 else None
+        # the hi bf16 plane alone in the same fragment order: the single-product chains
+        self.Wfrag_bf16 = fragment_order(self.W3[:1])[:, :, :, 0].contiguous() if self.cout % 32 == 0 else None
 
 
 class FusedPointNet2:
@@ -244,7 +246,7 @@ class FusedPointNet2:
         fused form of the contraction for this loader / epilogue / first-layer depth (the
         library is asked: s4g_gemm_chain_supported)."""
         c = l1.cout
-        if not (self.precision == "f16x2" and self.fuse2 and l1.groups == l2.groups and
+        if not (self.precision in ("f16x2", "bf16") and self.fuse2 and l1.groups == l2.groups and
                 l2.cin == c and l2.kpad16 == c and l2.cout % 64 == 0 and
                 l1.Wfrag is not None and l2.Wfrag is not None):
             return False
@@ -267,8 +269,10 @@ class FusedPointNet2:
         d.precision = {"fp32": 0, "bf16x3": 1, "bf16": 2, "f16x2": 3}[self.precision]
         d.Kpad16, d.W_bf16x3 = layer.kpad16, layer.W3.data_ptr()
         d.W_f16x2, d.w_inv_scale = layer.Wh2.data_ptr(), layer.w_inv_scale.data_ptr()
-        if layer.Wfrag is not None:
-            d.W_f16x2_frag = layer.Wfrag.data_ptr()
+        bf16 = self.precision == "bf16"      # chains take ONE bf16 plane in fragment order
+        frag = (lambda l: l.Wfrag_bf16) if bf16 else (lambda l: l.Wfrag)
+        if layer.Wfrag is not None and (not bf16 or layer2 is not None):
+            d.W_f16x2_frag = frag(layer).data_ptr()
         for k, v in kw.items():
             if isinstance(v, torch.Tensor):
                 v = v.data_ptr()
@@ -276,13 +280,13 @@ class FusedPointNet2:
                 setattr(d, k, v)
         flops = 2.0 * P * layer.cout * layer.cin * layer.groups
         if layer2 is not None:   # second layer fused behind this one (intermediate stays in LDS)
-            d.W2_f16x2_frag = layer2.Wfrag.data_ptr()
+            d.W2_f16x2_frag = frag(layer2).data_ptr()
             d.w2_inv_scale, d.bias2 = layer2.w_inv_scale.data_ptr(), layer2.bias.data_ptr()
             d.Cout2, d.relu2 = layer2.cout, 1
             flops += 2.0 * P * layer2.cout * layer2.cin * layer2.groups
             name = "%s+%s" % (name, name[:-1] + str(int(name[-1]) + 1))
         if layer3 is not None:   # ... and a third one (layer 2's output stays in LDS too)
-            d.W3_f16x2_frag = layer3.Wfrag.data_ptr()
+            d.W3_f16x2_frag = frag(layer3).data_ptr()
             d.w3_inv_scale, d.bias3 = layer3.w_inv_scale.data_ptr(), layer3.bias.data_ptr()
             d.Cout3, d.relu3 = layer3.cout, 1
             flops += 2.0 * P * layer3.cout * layer3.cin * layer3.groups
@@ -397,7 +401,7 @@ class FusedPointNet2:
             x = x_amax = None
             # the last two layers as ONE launch (C -> C -> Cout2 with C = 128 or 256, intermediate
             # in LDS); the first of the pair then reads through the MLP1 or the plain loader
-            pre = sa["pre"] if self.precision == "f16x2" else None
+            pre = sa["pre"] if self.precision in ("f16x2", "bf16") else None
             lp = len(layers) - 2                  # first layer of the candidate pair
             first_loader = (LOAD_GATHER_MLP1 if (lp == 1 and sa["mlp1"] is not None) else
                             LOAD_GATHER_ADD if (lp == 1 and pre is not None) else LOAD_PLAIN)
@@ -490,7 +494,7 @@ class FusedPointNet2:
                                      self._fusable(fl[-2], fl[-1], LOAD_INTERP_ADD, EPI_STORE))
                     else:
                         in_loader = self.fp_loader_add != "none" and fi in self.fp_loader_add
-                    in_loader = in_loader and self.precision == "f16x2" and len(fl) >= 2
+                    in_loader = in_loader and self.precision in ("f16x2", "bf16") and len(fl) >= 2
                     if in_loader and fuse2 and not self._fusable(fl[-2], fl[-1], LOAD_INTERP_ADD, EPI_STORE):
                         in_loader = False
                     s_amax = next(rows) if in_loader else None
