@@ -311,6 +311,39 @@ typedef struct s4g_gemm_desc {
 
 int s4g_mlp_gemm_f32(const s4g_gemm_desc_t *desc, s4g_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * The four per-point heads as ONE launch (ABI >= 4).  Replaces, for inference,
+ * PointNet2_tcls.py:126-140: mlp_seg / mlp_R / mlp_t / mlp_movable (four SharedMLP stacks
+ * C -> H0 -> H1 -> H2 -> H3 over the SAME (B, C, N) input, definitions :83-95) and their
+ * Conv1d logit layers (+ Sigmoid on movable_logit), BatchNorm folded by the caller.  A workgroup
+ * keeps the 64 x C input panel and every hidden activation in LDS; only X and the four
+ * (B, c_h, N) outputs touch HBM.  Shipped widths only: C = 256, H = (512, 256, 256, 128).
+ *   precision    S4G_GEMM_F16X2 (fp32-class) or S4G_GEMM_BF16 (one bf16 plane, reduced precision)
+ *   W_frag[l]    layer l's planes in MFMA-fragment order ([Cout/32][K/16][planes][64][8]):
+ *                l = 0: the four first layers stacked (4 H0 x C); l = 1..3: (4, H_l, H_{l-1});
+ *                l = 4: the logit layers zero-padded to (4, 32, H3)
+ *   bias[l], w_inv_scale[l]  per output channel, same stacking (w_inv_scale: F16X2 only)
+ *   out[h], channels[h]      head h's (B, channels[h], N) fp32 tensor; sigmoid_head = index of the
+ *                head whose logits pass through a sigmoid (-1: none)
+ *   a_amax / a_amax_floor / rows_per_scene   bound |X| per scene (F16X2), as in s4g_gemm_desc_t
+ * ------------------------------------------------------------------------- */
+typedef struct s4g_heads_desc {
+  int32_t precision, P, N, ldx;
+  int32_t C, H0, H1, H2, H3;
+  const float *X; /* (P, ldx >= C) channels-last */
+  const void *W_frag[5];
+  const float *bias[5];
+  const float *w_inv_scale[5];
+  float *out[4];
+  int32_t channels[4];
+  int32_t sigmoid_head;
+  const float *a_amax;
+  float a_amax_floor;
+  int32_t rows_per_scene;
+} s4g_heads_desc_t;
+
+int s4g_heads_chain_f32(const s4g_heads_desc_t *desc, s4g_stream_t stream);
+
 /* 1 when s4g_mlp_gemm_f32 has a fused-chain form (W2_f16x2_frag set) for this first-layer
  * loader, final epilogue, chain width C (= Cout = Cout2 of a three-layer chain) and first-layer
  * depth Kpad16; callers decide with it which layers to hand over as one launch. */

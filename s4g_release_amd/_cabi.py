@@ -45,9 +45,21 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class HeadsDesc(ctypes.Structure):
+    """ctypes mirror of `s4g_heads_desc_t` (include/s4g_ops.h)."""
+    _fields_ = [
+        ("precision", _i32), ("P", _i32), ("N", _i32), ("ldx", _i32),
+        ("C", _i32), ("H0", _i32), ("H1", _i32), ("H2", _i32), ("H3", _i32),
+        ("X", _vp), ("W_frag", _vp * 5), ("bias", _vp * 5), ("w_inv_scale", _vp * 5),
+        ("out", _vp * 4), ("channels", _i32 * 4), ("sigmoid_head", _i32),
+        ("a_amax", _vp), ("a_amax_floor", _f32), ("rows_per_scene", _i32),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/s4g_ops.h one to one.
 SIGNATURES = {
     "s4g_mlp_gemm_f32": (_int, [ctypes.POINTER(GemmDesc), _vp]),
+    "s4g_heads_chain_f32": (_int, [ctypes.POINTER(HeadsDesc), _vp]),
     "s4g_ball_query_i32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _sz,
                                   _int, _vp]),
     "s4g_three_nn_weights_i32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _sz,

@@ -33,13 +33,12 @@
 // so that the N-tiles sharing an A panel run back to back on one XCD (L2).
 #include <stdlib.h>
 
-#include "s4g_common.h"
+#include "mlp_common.h"
 
 #include <type_traits>
 
 namespace s4g {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GM_BM = 128;
 constexpr int GM_BN = 128;
@@ -538,14 +537,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void mlp_gemm_kernel(const GemmParam
 // host; activations stay fp32 in HBM and are split by the loader while it
 // stages them into LDS.
 // ---------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
 
 // split 4 floats into three planes of 4 bf16 (packed as uint2 each)
 __device__ __forceinline__ void split3(const float4 v, uint2& h, uint2& m, uint2& l) {
@@ -736,58 +728,12 @@ __global__ __launch_bounds__(64 * WAVES, (NS == 1 && WAVES == 4 && LOADER != LOA
 // A is split once per workgroup while it is staged into LDS as two fp16
 // planes (same LDS bytes as fp32); W arrives pre-split.
 // ---------------------------------------------------------------------------
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 // LDS rows are 32 halves (64 B, no padding); the 16-byte chunk c of row r sits at
 // position c ^ ((r >> 2) & 3).  A 16-lane b128 read phase (16 consecutive rows,
 // one chunk) and a 16-lane b128 / 32-lane b64 write phase (4 consecutive rows, all
 // chunks) then touch all 64 banks exactly once.
 constexpr int GH_STR = 32;
-
-__device__ __forceinline__ uint32_t pack_h2(float a, float b) {
-  f16x2 v;
-  v.x = (_Float16)a;
-  v.y = (_Float16)b;
-  return __builtin_bit_cast(uint32_t, v);
-}
-
-template <bool CLAMP>
-__device__ __forceinline__ void split2_h(const float4 v, float s, uint2& h, uint2& l) {
-  float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
-  float r[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    if constexpr (CLAMP) x[e] = __builtin_amdgcn_fmed3f(x[e], -65504.f, 65504.f);
-    r[e] = x[e] - (float)(_Float16)x[e];
-  }
-  h.x = pack_h2(x[0], x[1]);
-  h.y = pack_h2(x[2], x[3]);
-  l.x = pack_h2(r[0], r[1]);
-  l.y = pack_h2(r[2], r[3]);
-}
-
-__device__ __forceinline__ float amax_slots(const float* __restrict__ slots, int lane) {
-  return __uint_as_float(wave_max_u32(__float_as_uint(slots[lane])));
-}
-
-// Activation maxima are kept PER SCENE, so that a scene's scales -- and therefore its results --
-// do not depend on which other scenes share the batch: slot row s (64 words) belongs to scene
-// s = row / rps.  A tile takes the maximum over the scenes its rows [p_lo, p_hi] touch (one scene
-// whenever rps is a multiple of the tile height, which holds at every level of the shipped
-// configuration) and publishes its own maximum to each of them.
-__device__ __forceinline__ float amax_rows(const float* __restrict__ slots, int lane, int p_lo, int p_hi,
-                                           int rps) {
-  const int s0 = rps > 0 ? p_lo / rps : 0, s1 = rps > 0 ? p_hi / rps : 0;
-  float m = amax_slots(slots + (size_t)s0 * 64, lane);
-  for (int sc = s0 + 1; sc <= s1; ++sc) m = fmaxf(m, amax_slots(slots + (size_t)sc * 64, lane));
-  return m;
-}
-__device__ __forceinline__ void amax_publish(uint32_t* __restrict__ slots, uint32_t wm, int slot, int p_lo,
-                                             int p_hi, int rps) {
-  const int s0 = rps > 0 ? p_lo / rps : 0, s1 = rps > 0 ? p_hi / rps : 0;
-  for (int sc = s0; sc <= s1; ++sc) atomicMax(slots + (size_t)sc * 64 + (slot & 63), wm);
-}
 
 // NCB = 32-wide column blocks per wave: 2 -> 128 x 128 tile (three workgroups per
 // CU), 4 -> 128 x 256 tile, wave tile 64 x 128 (two workgroups per CU): 25 % less
@@ -1284,14 +1230,6 @@ constexpr int GF_RING = 2;
 // scales), 1 = ONE bf16 plane and one product (S4G_GEMM_BF16, the reduced-precision roofline
 // configuration: bf16 has fp32's exponent range, so there are no scales, no maxima and no
 // barrier for them; the panel is half as large, so twice as many workgroups fit a CU).
-template <int PL>
-__device__ __forceinline__ f32x16 chain_mfma(const uint4 a, const uint4 b, const f32x16 c) {
-  if constexpr (PL == 2)
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
 template <int LOADER, int EPI2, int RW, int KC, int PL>
 __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) void mlp_chain_kernel(const GemmParams p) {
   // RW = 2: 128 positions, 128-wide layers, 4 waves; RW = 1: 64 positions, 256-wide layers, 4 waves;

@@ -1,0 +1,348 @@
+// The four per-point heads of the S4G network as ONE launch.
+//
+// Reference: PointNet2_tcls.py:83-95 (definitions) and :126-140 (forward): four SharedMLP stacks
+// 256 -> 512 -> 256 -> 256 -> 128 (conv1x1 -> BN -> ReLU each, nn_utils/conv.py:24-34) that all
+// read the same (B, 256, N) feature tensor, each followed by a Conv1d(128 -> c, bias) with
+// c = 3 / 9 / 4 / 5 and a sigmoid on the last head.  36 % of the network's multiply-adds.
+//
+// Layer by layer this path wrote a (B N, 2048) tensor (heads.0), read it back, wrote (B N, 512)
+// and read that for the logits: 5.7 GB of the 10.5 GB a 16-scene step moves, 33 GB of a
+// 32 x 51 200-point step.  Here a workgroup owns 64 positions and walks ALL layers of ALL heads:
+//   X (64 x 256, loaded, scaled and split once)                       -> LDS panel A, stays
+//   per head g:  H0 = relu(W0 X)      512 wide, as two 256-wide halves -> LDS panel B
+//                H1 = relu(W1 H0)     accumulated over the two halves  -> panel B
+//                H2 = relu(W2 H1), H3 = relu(W3 H2) (128 wide)         -> panel B
+//                logits = Wl H3 + b (sigmoid on head 3)                -> (B, c, N) tensors
+// Nothing but X (once) and the 21 output channels crosses HBM.  Eight waves: wave w owns
+// channels 32 w .. 32 w + 31 of a 256-wide layer for all 64 positions (2 accumulator blocks);
+// W never touches LDS -- the host stores it in MFMA-fragment order and a wave streams its
+// fragments through a two-deep register ring exactly like mlp_chain_kernel.  Operands are
+// swapped (D = W A^T), so a lane ends up with 4 consecutive channels of ONE position: panel
+// writes are 8-byte LDS stores and the logits leave as 128-byte rows of one channel.
+//   PL = 2: fp32-class f16x2 arithmetic (two fp16 planes, three products, per-tile
+//           power-of-two scales found by a wave-max + one barrier per layer);
+//   PL = 1: one bf16 plane, one product, no scales (S4G_GEMM_BF16, configs[4]).
+#include "mlp_common.h"
+
+namespace s4g {
+
+struct HeadsParams {
+  int P, N;                // positions (B * N), points per scene
+  const float* X;          // (P, 256) channels-last fp32
+  int ldx;
+  const uint16_t* W[5];    // fragment-ordered planes: heads.0 (2048 x 256), heads.1 (4, 256, 512),
+                           // heads.2 (4, 256, 256), heads.3 (4, 128, 256), logits (4, 32, 128)
+  const float* bias[5];
+  const float* wsc[5];     // per-channel inverse weight scales (PL == 2)
+  float* out[4];
+  int ch[4];
+  int sigmoid_head;
+  const float* a_amax;     // per-scene maxima of X (PL == 2)
+  float a_floor;
+  int rps;
+};
+
+constexpr int HD_RING = 2;
+
+template <int PL>
+__global__ __launch_bounds__(512, PL == 2 ? 2 : 4) void mlp_heads_kernel(const HeadsParams p) {
+  constexpr int BM = 64, C = 256, NW = 8, astr = C + 8, aplane = BM * astr;
+  constexpr int FB = PL * 1024;            // bytes of one (32 channels x 16 k) fragment block
+  extern __shared__ __attribute__((aligned(16))) float smemf[];
+  uint16_t* PA = reinterpret_cast<uint16_t*>(smemf);   // X       [PL][BM][C + 8]
+  uint16_t* PB = PA + PL * aplane;                      // hidden  [PL][BM][C + 8]
+  float* scr = reinterpret_cast<float*>(PB + PL * aplane);   // [NW][32 scale | 32 bias], then NW maxima
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int p0 = blockIdx.x * BM;
+  const uint32_t wf_lane = (uint32_t)lane * 16u;
+
+  // activation scale of X (per scene, see amax_rows)
+  float sa = 1.f, inv_sa = 1.f;
+  if constexpr (PL == 2) {
+    float amax = p.a_floor;
+    if (p.a_amax) amax = fmaxf(amax, amax_rows(p.a_amax, lane, p0, min(p0 + BM, p.P) - 1, p.rps));
+    uint32_t ex = __float_as_uint(amax) >> 23;
+    ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
+    ex = __builtin_amdgcn_readfirstlane(ex);
+    sa = __uint_as_float((268u - ex) << 23);
+    inv_sa = __uint_as_float((ex - 14u) << 23);
+  }
+
+  // fragment block (n32, ks) of layer L whose rows are nks blocks deep
+  auto wptr = [&](int L, int n32, int nks, int ks) {
+    return reinterpret_cast<const char*>(p.W[L]) + ((size_t)n32 * nks + ks) * FB;
+  };
+  auto w0 = [&](int g, int h) { return wptr(0, g * 16 + h * 8 + wv, 16, 0); };
+  auto w1 = [&](int g, int h) { return wptr(1, g * 8 + wv, 32, h * 16); };
+  auto w2 = [&](int g) { return wptr(2, g * 8 + wv, 16, 0); };
+  auto w3 = [&](int g) { return wptr(3, g * 4 + (wv & 3), 16, 0); };
+  auto wl = [&](int g) { return wptr(4, g, 8, 0); };
+
+  uint4 ring[HD_RING][PL];
+  {
+    const char* w = w0(0, 0);
+#pragma unroll
+    for (int d = 0; d < HD_RING; ++d)
+#pragma unroll
+      for (int pl = 0; pl < PL; ++pl)
+        ring[d][pl] = *reinterpret_cast<const uint4*>(w + d * FB + pl * 1024 + wf_lane);
+  }
+
+  // ---- prologue: X -> panel A (one round trip: 8 x 16 bytes per thread in flight)
+  {
+    const int row = t >> 3, chunk = t & 7;
+    const bool ok = p0 + row < p.P;
+    const float* src = p.X + (size_t)(ok ? p0 + row : 0) * p.ldx + chunk * 4;
+    float4 ra[8];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+      ra[kt] = ok ? *reinterpret_cast<const float4*>(src + kt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      uint16_t* dst = PA + row * astr + kt * 32 + chunk * 4;
+      if constexpr (PL == 2) {
+        uint2 h, l;
+        split2_h<false>(ra[kt], sa, h, l);
+        *reinterpret_cast<uint2*>(dst) = h;
+        *reinterpret_cast<uint2*>(dst + aplane) = l;
+      } else {
+        *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pk_bf16(ra[kt].x, ra[kt].y), cvt_pk_bf16(ra[kt].z, ra[kt].w));
+      }
+    }
+  }
+  __syncthreads();
+
+  // NKS 16-deep steps of ACC[rb] += W(32 channels) . PANEL(rows ROWOFF + 32 rb ..)^T.  W fragments
+  // come through the ring, refilled HD_RING steps ahead from this strip (WCUR) or the next one
+  // (WNEXT); the first step starts from a literal zero accumulator (no register zeroing).
+#define S4G_HD_TERM(NRB, PA_, PB_, ZERO)                                                            \
+  _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)                                                \
+    acc[rb] = chain_mfma<PL>(bf[PB_], af[rb][PA_], (ZERO) ? zero16 : acc[rb]);
+#define S4G_HD_STRIP(PANEL, NRB, ROWOFF, WCUR, NKS, WNEXT)                                          \
+  {                                                                                                 \
+    const uint16_t* a_lane = (PANEL) + ((ROWOFF) + li) * astr + 8 * lh;                             \
+    uint4 afn[2][PL];                                                                               \
+    _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb) _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) \
+      afn[rb][pl] = *reinterpret_cast<const uint4*>(a_lane + pl * aplane + rb * 32 * astr);         \
+    const char* wcur_ = (WCUR);                                                                     \
+    const char* wnext_ = (WNEXT);                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) {                                            \
+      const int d = ks % HD_RING;                                                                   \
+      const int ksn = ks + 1 == NKS ? 0 : ks + 1;                                                   \
+      uint4 af[2][PL], bf[PL];                                                                      \
+      _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb) _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) { \
+        af[rb][pl] = afn[rb][pl];                                                                   \
+        afn[rb][pl] = *reinterpret_cast<const uint4*>(a_lane + pl * aplane + rb * 32 * astr + ksn * 16); \
+      }                                                                                             \
+      _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) bf[pl] = ring[d][pl];                       \
+      {                                                                                             \
+        const int kr = ks + HD_RING;                                                                \
+        const char* src = kr < NKS ? wcur_ + kr * FB : wnext_ + (kr - NKS) * FB;                    \
+        _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)                                           \
+          ring[d][pl] = *reinterpret_cast<const uint4*>(src + pl * 1024 + wf_lane);                 \
+      }                                                                                             \
+      if constexpr (PL == 2) {                                                                      \
+        S4G_HD_TERM(NRB, 0, 1, ks == 0)                                                             \
+        S4G_HD_TERM(NRB, 1, 0, false)                                                               \
+        S4G_HD_TERM(NRB, 0, 0, false)                                                               \
+      } else {                                                                                      \
+        S4G_HD_TERM(NRB, 0, 0, ks == 0)                                                             \
+      }                                                                                             \
+      _Pragma("unroll") for (int q = 0; q < PL; ++q) {                                              \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                          \
+      }                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                            \
+    }                                                                                               \
+  }
+
+  f32x16 zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+  f32x16 acc[2];
+  float* epi_s = scr + wv * 64;
+
+  // scale | bias of this wave's 32 channels, staged once per phase (read back as float4 per
+  // register quad: lane holds channels 8 j + 4 lh + (0..3))
+  auto stage_sb = [&](int L, int gch, float mul) {
+    epi_s[lane] = lane < 32 ? (PL == 2 ? mul * p.wsc[L][gch + lane] : 1.f) : p.bias[L][gch + lane - 32];
+  };
+
+  // acc (NRB blocks of 32 positions x this wave's 32 channels) -> relu(acc * scale + bias) ->
+  // tile maximum (one barrier: also the point after which nobody reads the old panel B) ->
+  // split with the tile's own power-of-two scale -> panel B rows ROWOFF.., columns PCH0..
+  float inv_sh = 1.f;
+  auto panel_epilogue = [&](auto nrb_tag, int rowoff, int pch0) {
+    constexpr int NRB = decltype(nrb_tag)::value;
+    float tmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 sc4 = *reinterpret_cast<const float4*>(epi_s + 8 * j + 4 * lh);
+      const float4 b4 = *reinterpret_cast<const float4*>(epi_s + 32 + 8 * j + 4 * lh);
+      const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+      const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = fmaxf(__fmaf_rn(acc[rb][4 * j + e], scv[e], bv[e]), 0.f);
+          acc[rb][4 * j + e] = x;
+          if constexpr (PL == 2) tmax = fmaxf(tmax, x);
+        }
+    }
+    float sh = 1.f;
+    if constexpr (PL == 2) {
+      const uint32_t wm = wave_max_u32(__float_as_uint(tmax));
+      if (lane == 0) scr[NW * 64 + wv] = __uint_as_float(wm);
+    }
+    __syncthreads();
+    if constexpr (PL == 2) {
+      float hmax = scr[NW * 64];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) hmax = fmaxf(hmax, scr[NW * 64 + w]);
+      uint32_t exh = __float_as_uint(hmax) >> 23;
+      exh = exh < 15u ? 15u : (exh > 240u ? 240u : exh);
+      exh = __builtin_amdgcn_readfirstlane(exh);
+      sh = __uint_as_float((268u - exh) << 23);
+      inv_sh = __uint_as_float((exh - 14u) << 23);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+        uint16_t* dst = PB + (rowoff + rb * 32 + li) * astr + pch0 + 8 * j + 4 * lh;
+        if constexpr (PL == 2) {
+          const float4 v = make_float4(acc[rb][4 * j], acc[rb][4 * j + 1], acc[rb][4 * j + 2], acc[rb][4 * j + 3]);
+          uint2 h, l;
+          split2_h<false>(v, sh, h, l);
+          *reinterpret_cast<uint2*>(dst) = h;
+          *reinterpret_cast<uint2*>(dst + aplane) = l;
+        } else {
+          *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pk_bf16(acc[rb][4 * j], acc[rb][4 * j + 1]),
+                                                      cvt_pk_bf16(acc[rb][4 * j + 2], acc[rb][4 * j + 3]));
+        }
+      }
+    __syncthreads();
+  };
+  using two = std::integral_constant<int, 2>;
+  using one = std::integral_constant<int, 1>;
+
+  for (int g = 0; g < 4; ++g) {
+    f32x16 acc1[2];   // heads.1 accumulated over the two halves of its 512 inputs, in units of 1 / w_scale
+    // ---- heads.0 half 0 -> B;  heads.1 over that half
+    stage_sb(0, g * 512 + wv * 32, inv_sa);
+    S4G_HD_STRIP(PA, 2, 0, w0(g, 0), 16, w1(g, 0))
+    panel_epilogue(two{}, 0, wv * 32);
+    S4G_HD_STRIP(PB, 2, 0, w1(g, 0), 16, w0(g, 1))
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[rb][r] = acc[rb][r] * inv_sh;
+    // ---- heads.0 half 1 -> B;  heads.1 over that half, then its epilogue -> B
+    stage_sb(0, g * 512 + 256 + wv * 32, inv_sa);
+    S4G_HD_STRIP(PA, 2, 0, w0(g, 1), 16, w1(g, 1))
+    panel_epilogue(two{}, 0, wv * 32);
+    S4G_HD_STRIP(PB, 2, 0, w1(g, 1), 16, w2(g))
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][r] = __fmaf_rn(acc[rb][r], inv_sh, acc1[rb][r]);
+    stage_sb(1, g * 256 + wv * 32, 1.f);
+    panel_epilogue(two{}, 0, wv * 32);
+    // ---- heads.2 -> B
+    stage_sb(2, g * 256 + wv * 32, inv_sh);
+    S4G_HD_STRIP(PB, 2, 0, w2(g), 16, w3(g))
+    panel_epilogue(two{}, 0, wv * 32);
+    // ---- heads.3 (128 wide): wave = (32-position block wv >> 2) x (32-channel block wv & 3) -> B
+    {
+      const int rbw = wv >> 2, cg = wv & 3;
+      stage_sb(3, g * 128 + cg * 32, inv_sh);
+      const char* after = wv < 2 ? wl(g) : w0(g < 3 ? g + 1 : g, 0);
+      S4G_HD_STRIP(PB, 1, rbw * 32, w3(g), 16, after)
+      panel_epilogue(one{}, rbw * 32, cg * 32);
+    }
+    // ---- logits: waves 0 and 1, one 32-position block each; (B, c, N) channel-first stores
+    if (wv < 2) {
+      stage_sb(4, g * 32, inv_sh);
+      S4G_HD_STRIP(PB, 1, wv * 32, wl(g), 8, w0(g < 3 ? g + 1 : g, 0))
+      const int row = p0 + wv * 32 + li;
+      const int b = row / p.N, pt = row - b * p.N;
+      const int nch = p.ch[g];
+      float* __restrict__ base = p.out[g] + (size_t)b * nch * p.N + pt;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 sc4 = *reinterpret_cast<const float4*>(epi_s + 8 * j + 4 * lh);
+        const float4 b4 = *reinterpret_cast<const float4*>(epi_s + 32 + 8 * j + 4 * lh);
+        const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = 8 * j + 4 * lh + e;
+          float x = __fmaf_rn(acc[0][4 * j + e], scv[e], bv[e]);
+          if (g == p.sigmoid_head) x = 1.0f / (1.0f + expf(-x));
+          if (c < nch && row < p.P) base[(size_t)c * p.N] = x;
+        }
+      }
+    }
+  }
+#undef S4G_HD_STRIP
+#undef S4G_HD_TERM
+}
+
+template <int PL>
+static int launch_heads(const HeadsParams& p, hipStream_t st) {
+  constexpr size_t lds = sizeof(uint16_t) * 2 * PL * 64 * (256 + 8) + sizeof(float) * (8 * 64 + 16);
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  static bool done[64] = {};
+  if (dev < 0 || dev >= 64 || !done[dev]) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_heads_kernel<PL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    if (dev >= 0 && dev < 64) done[dev] = true;
+  }
+  hipLaunchKernelGGL((mlp_heads_kernel<PL>), dim3((unsigned)((p.P + 63) / 64)), dim3(512), lds, st, p);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
+
+}  // namespace s4g
+
+extern "C" int s4g_heads_chain_f32(const s4g_heads_desc_t* d, s4g_stream_t stream) {
+  using namespace s4g;
+  if (!d || d->P < 0 || d->N <= 0 || !d->X || (d->ldx & 3) || d->ldx < 256 || ((uintptr_t)d->X & 15))
+    return S4G_EINVAL;
+  if (d->precision != S4G_GEMM_F16X2 && d->precision != S4G_GEMM_BF16) return S4G_EINVAL;
+  if (d->C != 256 || d->H0 != 512 || d->H1 != 256 || d->H2 != 256 || d->H3 != 128) return S4G_EUNSUPPORTED;
+  HeadsParams p;
+  p.P = d->P;
+  p.N = d->N;
+  p.X = d->X;
+  p.ldx = d->ldx;
+  for (int l = 0; l < 5; ++l) {
+    if (!d->W_frag[l] || !d->bias[l] || (d->precision == S4G_GEMM_F16X2 && !d->w_inv_scale[l])) return S4G_EINVAL;
+    p.W[l] = (const uint16_t*)d->W_frag[l];
+    p.bias[l] = d->bias[l];
+    p.wsc[l] = d->w_inv_scale[l];
+  }
+  for (int h = 0; h < 4; ++h) {
+    if (!d->out[h] || d->channels[h] <= 0 || d->channels[h] > 32) return S4G_EINVAL;
+    p.out[h] = d->out[h];
+    p.ch[h] = d->channels[h];
+  }
+  p.sigmoid_head = d->sigmoid_head;
+  p.a_amax = d->a_amax;
+  p.a_floor = d->a_amax_floor;
+  p.rps = d->rows_per_scene > 0 ? d->rows_per_scene : 0;
+  if (d->precision == S4G_GEMM_F16X2 && !d->a_amax && !(d->a_amax_floor > 0.f)) return S4G_EINVAL;
+  if (d->P == 0) return S4G_OK;
+  hipStream_t st = (hipStream_t)stream;
+  return d->precision == S4G_GEMM_F16X2 ? launch_heads<2>(p, st) : launch_heads<1>(p, st);
+}

@@ -33,6 +33,7 @@ from . import functions as _F
 _i32 = ctypes.c_int32
 _fp = ctypes.c_void_p
 GemmDesc = _cabi.GemmDesc
+HeadsDesc = _cabi.HeadsDesc
 
 LOAD_PLAIN, LOAD_GATHER, LOAD_INTERP, LOAD_GATHER_MLP1, LOAD_GATHER_ADD, LOAD_INTERP_ADD = 0, 1, 2, 3, 4, 5
 EPI_STORE, EPI_MAX, EPI_CF = 0, 1, 2
@@ -240,6 +241,22 @@ class FusedPointNet2:
         self.logit_layer = _Layer(_pad_k(wl), bl, 4 * cl)
         self.sigmoid_from = sum(chans[:3])
         self._streams = None
+        # all four heads as ONE launch (s4g_heads_chain_f32: input panel and every hidden
+        # activation stay in LDS) where the widths are the shipped ones; S4G_HEADS_FUSED=0 keeps
+        # the layer-chain launches
+        hl = self.head_layers
+        self.heads_fused = None
+        if (os.environ.get("S4G_HEADS_FUSED", "1") != "0" and precision in ("f16x2", "bf16") and depth == 4 and
+                hl[0].cin == 256 and hl[0].cout == 4 * 512 and
+                [(l.cout, l.cin, l.groups) for l in hl[1:]] == [(256, 512, 4), (256, 256, 4), (128, 256, 4)] and
+                cl == 128 and max(chans) <= 32 and len(chans) == 4):
+            wpad = torch.zeros((4, 32, cl), dtype=torch.float32, device=self.dev)
+            bpad = torch.zeros((4, 32), dtype=torch.float32, device=self.dev)
+            for h, (_, lg) in enumerate(heads):
+                c = lg.weight.shape[0]
+                wpad[h, :c] = lg.weight.detach().flatten(1)
+                bpad[h, :c] = lg.bias.detach()
+            self.heads_fused = list(hl) + [_Layer(wpad, bpad, cl, groups=4)]
 
     def _fusable(self, l1, l2, loader=LOAD_PLAIN, epi=EPI_STORE):
         """Two consecutive layers one launch can take: widths that chain (C -> C -> Cout2) and a
@@ -295,6 +312,33 @@ class FusedPointNet2:
                        0, flops):
             rc = _cabi.lib().s4g_mlp_gemm_f32(ctypes.byref(d), _F._stream())
         _cabi.check(rc, "mlp_gemm " + name)
+
+    def _heads(self, x, x_amax, outs, B, N0):
+        """heads.0 .. heads.3 + logits of all four heads: one launch (s4g_heads_chain_f32)."""
+        d = HeadsDesc()
+        bf16 = self.precision == "bf16"
+        d.precision = 2 if bf16 else 3
+        d.P, d.N, d.ldx = B * N0, N0, x.shape[1]
+        d.C, d.H0, d.H1, d.H2, d.H3 = 256, 512, 256, 256, 128
+        d.X = x.data_ptr()
+        flops = 0.0
+        for l, layer in enumerate(self.heads_fused):
+            d.W_frag[l] = (layer.Wfrag_bf16 if bf16 else layer.Wfrag).data_ptr()
+            d.bias[l] = layer.bias.data_ptr()
+            d.w_inv_scale[l] = layer.w_inv_scale.data_ptr()
+            if l < 4:
+                flops += 2.0 * B * N0 * layer.cout * layer.cin * layer.groups
+        flops += 2.0 * B * N0 * sum(self.head_channels) * 128      # the logit layers' real channels
+        for h, o in enumerate(outs):
+            d.out[h] = o.data_ptr()
+            d.channels[h] = self.head_channels[h]
+        d.sigmoid_head = 3
+        d.a_amax = None if x_amax is None else x_amax.data_ptr()
+        d.a_amax_floor = 0.0
+        d.rows_per_scene = N0
+        with _F._timed("gemm[heads.0-3+logits P=%d K=256 N=4x(512,256,256,128,c)]" % (B * N0), 0, flops):
+            rc = _cabi.lib().s4g_heads_chain_f32(ctypes.byref(d), _F._stream())
+        _cabi.check(rc, "heads_chain")
 
     def _fps_gather(self, xyz, M):
         B, _, N = xyz.shape
@@ -462,7 +506,8 @@ class FusedPointNet2:
             # last FP level: the first head layer (shared input, groups == 1) rides along as a
             # third layer, so the per-point features never go through HBM before the heads
             h0 = self.head_layers[0]
-            fuse3 = (fuse2 and fi == len(self.fp) - 1 and self.fuse3 and fl[-1].cout == fl[-2].cout and
+            fuse3 = (fuse2 and fi == len(self.fp) - 1 and self.fuse3 and self.heads_fused is None and
+                     fl[-1].cout == fl[-2].cout and
                      h0.groups == 1 and h0.cin == fl[-1].cout and h0.kpad16 == fl[-1].cout and
                      h0.cout % 64 == 0 and h0.Wfrag is not None)
             for l, layer in enumerate(fl):
@@ -543,6 +588,11 @@ class FusedPointNet2:
         # heads
         P = B * N0
         x, x_amax = sparse_feat, sparse_amax
+        names = ("score", "frame_R", "frame_t", "movable_logits")
+        if self.heads_fused is not None and x.shape[1] == 256:
+            outs = [torch.empty((B, c, N0), dtype=torch.float32, device=dev) for c in self.head_channels]
+            self._heads(x, x_amax, outs, B, N0)
+            return dict(zip(names, outs))
         l0 = self.head_layers[0]
         if not heads0_fused:
             h = torch.empty((P, l0.cout), dtype=torch.float32, device=dev)

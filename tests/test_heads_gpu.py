@@ -1,0 +1,114 @@
+"""s4g_heads_chain_f32: the four per-point heads (PointNet2_tcls.py:83-95,126-140 -- four
+SharedMLP stacks 256 -> 512 -> 256 -> 256 -> 128 on a shared input, Conv1d logits, sigmoid on
+the movable head) as one launch, against an fp64 restatement of the same layers."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+CH = (3, 9, 4, 5)
+
+
+def _layers(dev, seed):
+    from s4g_release_amd.fused import _Layer
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    W0 = (r(2048, 256) / 16).to(dev)
+    W1 = (r(4, 256, 512) / 512 ** 0.5).to(dev)
+    W2 = (r(4, 256, 256) / 16).to(dev)
+    W3 = (r(4, 128, 256) / 16).to(dev)
+    WL = torch.zeros(4, 32, 128)
+    bL = torch.zeros(4, 32)
+    for h, c in enumerate(CH):
+        WL[h, :c] = r(c, 128) / 128 ** 0.5
+        bL[h, :c] = r(c)
+    b = [r(2048).to(dev), r(4, 256).to(dev), r(4, 256).to(dev), r(4, 128).to(dev), bL.to(dev)]
+    Ws = [W0, W1, W2, W3, WL.to(dev)]
+    layers = [_Layer(W0, b[0], 256)] + [_Layer(Ws[i], b[i], Ws[i].shape[-1], groups=4) for i in range(1, 5)]
+    return Ws, b, layers
+
+
+def _run(dev, layers, X, B, N, precision, amax=None, floor=0.0):
+    from s4g_release_amd import _cabi
+    d = _cabi.HeadsDesc()
+    d.precision = precision
+    d.P, d.N, d.ldx = B * N, N, X.shape[1]
+    d.C, d.H0, d.H1, d.H2, d.H3 = 256, 512, 256, 256, 128
+    d.X = X.data_ptr()
+    for l, layer in enumerate(layers):
+        d.W_frag[l] = (layer.Wfrag_bf16 if precision == 2 else layer.Wfrag).data_ptr()
+        d.bias[l] = layer.bias.data_ptr()
+        d.w_inv_scale[l] = layer.w_inv_scale.data_ptr()
+    outs = [torch.full((B, c, N), float("nan"), device=dev) for c in CH]
+    for h, o in enumerate(outs):
+        d.out[h] = o.data_ptr()
+        d.channels[h] = CH[h]
+    d.sigmoid_head = 3
+    d.a_amax = None if amax is None else amax.data_ptr()
+    d.a_amax_floor = floor
+    d.rows_per_scene = N
+    rc = _cabi.lib().s4g_heads_chain_f32(ctypes.byref(d), torch.cuda.current_stream().cuda_stream)
+    _cabi.check(rc, "heads")
+    torch.cuda.synchronize()
+    return outs
+
+
+def _reference(Ws, b, X, B, N, rnd=lambda t: t.double()):
+    outs = []
+    x = rnd(X)
+    for h, c in enumerate(CH):
+        y = (x @ rnd(Ws[0][h * 512:(h + 1) * 512]).t() + b[0][h * 512:(h + 1) * 512].double()).clamp_min(0)
+        for l in (1, 2, 3):
+            y = (rnd(y.float()) @ rnd(Ws[l][h]).t() + b[l][h].double()).clamp_min(0)
+        o = rnd(y.float()) @ rnd(Ws[4][h, :c]).t() + b[4][h, :c].double()
+        if h == 3:
+            o = torch.sigmoid(o)
+        outs.append(o.view(B, N, c).permute(0, 2, 1))
+    return outs
+
+
+@pytest.mark.parametrize("B,N", [(2, 100), (1, 64), (3, 171)])
+def test_heads_chain_f16x2_is_fp32_class(dev, B, N):
+    Ws, b, layers = _layers(dev, 7 + N)
+    g = torch.Generator(device="cpu").manual_seed(N)
+    X = (torch.randn(B * N, 256, generator=g) * torch.tensor([1.0, 40.0, 0.02])[:B, None]
+         .repeat_interleave(N, dim=0)).to(dev)      # scenes of very different magnitude
+    amax = torch.zeros((B, 64), device=dev)
+    amax[:, 5] = X.view(B, -1).abs().amax(dim=1)
+    outs = _run(dev, layers, X, B, N, 3, amax=amax)
+    ref = _reference(Ws, b, X, B, N)
+    for h in range(4):
+        assert torch.isfinite(outs[h]).all()
+        err = (outs[h].double() - ref[h]).abs()
+        scale = ref[h].abs().amax(dim=(1, 2), keepdim=True).clamp_min(1.0)     # per scene
+        assert (err / scale).max().item() < 2e-5, (h, (err / scale).max().item())
+
+
+def test_heads_chain_bf16_matches_a_reference_rounded_at_the_same_points(dev):
+    B, N = 2, 150
+    Ws, b, layers = _layers(dev, 3)
+    X = torch.randn(B * N, 256, generator=torch.Generator(device="cpu").manual_seed(1)).to(dev)
+    outs = _run(dev, layers, X, B, N, 2)
+    ref = _reference(Ws, b, X, B, N, rnd=lambda t: t.to(torch.bfloat16).double())
+    exact = _reference(Ws, b, X, B, N)
+    for h in range(4):
+        scale = max(1.0, ref[h].abs().max().item())
+        assert torch.isfinite(outs[h]).all()
+        assert (outs[h].double() - ref[h]).abs().max().item() < 3e-3 * scale
+        assert (outs[h].double() - ref[h]).abs().mean().item() < 5e-5 * scale
+        assert (outs[h].double() - exact[h]).abs().max().item() < 8e-2 * scale
+
+
+def test_heads_chain_rejects_other_widths_and_bad_arguments(dev):
+    from s4g_release_amd import _cabi
+    Ws, b, layers = _layers(dev, 1)
+    X = torch.randn(64, 256, device=dev)
+    d = _cabi.HeadsDesc()
+    d.precision, d.P, d.N, d.ldx = 3, 64, 64, 256
+    d.C, d.H0, d.H1, d.H2, d.H3 = 256, 512, 256, 256, 64          # not the shipped widths
+    d.X = X.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    assert _cabi.lib().s4g_heads_chain_f32(ctypes.byref(d), st) != 0
+    d.H3 = 128
+    assert _cabi.lib().s4g_heads_chain_f32(ctypes.byref(d), st) != 0     # no weights / outputs given
