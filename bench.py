@@ -443,21 +443,29 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         from oracle import pn2_forward
         ncores = os.cpu_count() or 1
-        torch.set_num_threads(ncores)
         sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
         one = pts[:1].cpu().numpy()
-        t1 = time.perf_counter()
-        ref = pn2_forward.forward(sd, one, cfg.num_centroids, cfg.radius, cfg.num_neighbours)
-        cpu_s = time.perf_counter() - t1
+        # torch's CPU convolutions do not scale to hundreds of threads on these short layers (256
+        # threads measured 13x SLOWER than 8): time the scene at a few team sizes, report the best
+        best = None
+        for nt in sorted({min(ncores, 16), min(ncores, 64)}):
+            torch.set_num_threads(nt)
+            os.environ["OMP_NUM_THREADS"] = str(nt)
+            t1 = time.perf_counter()
+            ref = pn2_forward.forward(sd, one, cfg.num_centroids, cfg.radius, cfg.num_neighbours)
+            dt = time.perf_counter() - t1
+            if best is None or dt < best[0]:
+                best = (dt, nt)
+        cpu_s, nt = best
         with torch.no_grad():
             got = runner({"scene_points": pts[:1]})
         err = max(float(np.max(np.abs(got[k].cpu().numpy() - ref[k]))) for k in heads)
         cpu_baseline = {"value": round(1.0 / cpu_s, 4), "unit": "scenes/sec",
-                        "cores": torch.get_num_threads(), "kind": "port",
+                        "cores": nt, "kind": "port",
                         "sample": "1 scene (scene %d) of the same workload: oracle C operators "
                                   "(OpenMP over centroids / queries, FPS scan over a team of <= 8) + "
-                                  "torch CPU conv/BN (%d threads)"
-                                  % (scene_ids[0], torch.get_num_threads()),
+                                  "torch CPU conv/BN, best of %s threads on a %d-core host"
+                                  % (scene_ids[0], sorted({min(ncores, 16), min(ncores, 64)}), ncores),
                         "seconds": round(cpu_s, 2),
                         "max_abs_err_gpu_vs_cpu": err}
 

@@ -39,6 +39,87 @@ def decode_top_poses(pred, scene_points, K=50, convention="demo"):
     return np.stack(Hs), np.stack(Ss), np.stack(Is)
 
 
+REAL2TRAIN = np.array([[0, 1, 0, 0], [1, 0, 0, 0], [0, 0, -1, 0], [0, 0, 0, 1]], dtype=np.float64)   # grasp_detector.py:26
+TRAIN2REAL = np.linalg.inv(REAL2TRAIN)                                                                 # :27
+
+
+def _orthogonalization(rot, trans):
+    """GraspDetector.orthogonalization, grasp_detector.py:124-135."""
+    x = rot[:, :, 0]
+    x = x / np.linalg.norm(x, axis=1, keepdims=True)
+    y = rot[:, :, 1]
+    y = y - np.sum(x * y, axis=1, keepdims=True) * x
+    y = y / np.linalg.norm(y, axis=1, keepdims=True)
+    z = np.cross(x, y)
+    mat44 = np.tile(np.eye(4), [rot.shape[0], 1, 1])
+    mat44[:, :3, :3] = np.stack([x, y, z], axis=2)
+    mat44[:, :3, 3] = trans
+    return mat44
+
+
+def detector_post_processing(pred, points, score_threshold, vertical_degree_threshold,
+                             direction_matrix, vertical_direction=(0.0, 0.0, 1.0), frame=TRAIN2REAL,
+                             literal=False):
+    """GraspDetector.post_processing (grasp_detector.py:137-185) for ONE scene: pred values are
+    numpy (C, N), points (3, N).  direction_matrix = camera2base[:3,:3] @ TRAIN2REAL[:3,:3] (:155).
+    Returns (mat44 (n,4,4) f64 in `frame`, scores (n,), point index (n,)).
+
+    literal=False (what the product implements): survivors of the score threshold in DESCENDING
+    score order (`argsort(...)[::-1]`, :151), each with ITS OWN rotation / translation / position,
+    filtered by the verticalness test.
+    literal=True: the reference's indexing exactly as written -- `index_high2low` (positions inside
+    `high_score_index`) is used as a POINT index for `frame_R` (:154) and `index_good_direction`
+    (positions in that permuted list) as positions inside `high_score_index` (:160), so row i pairs
+    the rotation of point index_high2low[j] with position / score / translation of point
+    high_score_index[j] (a defect of the reference: SURVEY Appendix D style, not reproduced by the
+    product; restated here so the difference is testable)."""
+    all_scores = F.softmax(torch.from_numpy(pred["score"]), dim=0).numpy()                    # :143
+    C = all_scores.shape[0]
+    score_value = np.linspace(0, 1, C + 1)[1:][:, np.newaxis]                                 # :145
+    all_scores = np.sum(score_value * all_scores, axis=0)                                     # :146
+    high = np.nonzero(all_scores > score_threshold)[0]                                        # :149
+    high2low = np.argsort(all_scores[high])[::-1]                                             # :150
+    vdir = np.asarray(vertical_direction, dtype=np.float32)[np.newaxis, :]                    # :80
+    dm = np.asarray(direction_matrix, dtype=np.float64)
+    pts = points.T if points.shape[0] == 3 else points                                        # :161-162
+    t_score = np.array([0.08, 0.06, 0.04, 0.02])[np.newaxis, :pred["frame_t"].shape[0]]       # :177
+    if literal:
+        rotation = pred["frame_R"][:, high2low].transpose(1, 0).reshape([-1, 3, 3])           # :153-154
+        x_direction = -dm @ rotation[:, :, 0].T                                               # :155
+        vertical_degree = np.sum(x_direction.T * vdir, axis=1)                                # :156
+        good = np.nonzero(vertical_degree > vertical_degree_threshold)[0]                     # :157
+        valid = high[good]                                                                    # :160
+        rotation = rotation[good]                                                             # :164
+    else:
+        order = high[high2low]                                  # point indices, best score first
+        rotation = pred["frame_R"][:, order].transpose(1, 0).reshape([-1, 3, 3])
+        x_direction = -dm @ rotation[:, :, 0].T
+        vertical_degree = np.sum(x_direction.T * vdir, axis=1)
+        good = np.nonzero(vertical_degree > vertical_degree_threshold)[0]
+        valid = order[good]
+        rotation = rotation[good]
+    p = pts[valid, :]                                                                         # :163
+    translation = F.softmax(torch.from_numpy(pred["frame_t"][:, valid]), dim=0).numpy().T     # :165-166
+    scores = all_scores[valid]                                                                # :167
+    gt = -(translation * t_score).sum(1, keepdims=True) * rotation[:, :, 0] + p              # :178
+    mat44 = _orthogonalization(rotation.astype(np.float64), gt)                               # :179
+    mat44 = np.matmul(np.asarray(frame, dtype=np.float64)[np.newaxis], mat44)                 # :180
+    return mat44, scores, valid
+
+
+def importance_sampling(scores, random_numbers):
+    """grasp_detector.py:237-251 with the uniform draws passed in (the reference calls
+    np.random.rand(num_selected) unseeded): indices of the selected poses."""
+    scores_cum = np.cumsum(np.exp(5 * scores))                                                # :239
+    random_score = np.sort(np.asarray(random_numbers)) * scores_cum[-1]                       # :240
+    out, index = [], 0
+    for target in random_score:                                                               # :243-247
+        while scores_cum[index] < target:
+            index += 1
+        out.append(index)
+    return np.array(out)
+
+
 def view_non_collision(poses, scene_points, half_bottom_width=0.057, bottom_length=0.16,
                        finger_width=0.023, half_hand_thickness=0.012, finger_length=0.09,
                        back_margin=0.0, back_threshold=10 * np.sqrt(8), finger_threshold=10):

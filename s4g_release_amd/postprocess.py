@@ -58,6 +58,77 @@ def decode_top_poses(predictions, scene_points, num_poses=50, convention="demo")
     return H, top, sel
 
 
+REAL2TRAIN = ((0., 1., 0., 0.), (1., 0., 0., 0.), (0., 0., -1., 0.), (0., 0., 0., 1.))   # grasp_detector.py:26
+TRAIN2REAL = REAL2TRAIN                               # :27 (the matrix is its own inverse)
+
+
+def detect_poses(predictions, scene_points, score_threshold=0.7, verticalness_threshold=0.2,
+                 direction_matrix=None, vertical_direction=(0.0, 0.0, 1.0), frame=TRAIN2REAL,
+                 max_poses=1024):
+    """`GraspDetector.post_processing` (grasp_detector.py:137-185) for a whole batch, on the device
+    and without a host round trip: expected score with the detector's class values (:145-146),
+    score threshold (:149), survivors in descending score order (:150-151), verticalness filter
+    `(-direction_matrix @ R[:, 0]) . vertical_direction > threshold` (:155-157; direction_matrix is
+    the caller's `camera2base[:3,:3] @ TRAIN2REAL[:3,:3]`, identity if None), translation decode
+    and Gram-Schmidt (:124-135,177-179), result moved into the caller's frame (`frame @ H`, :180).
+
+    Returns (H (B, max_poses, 4, 4) fp32, score (B, max_poses), index (B, max_poses) int64,
+    count (B,) int64): per scene the first count[b] rows are the detections, best first; rows past
+    the count are zero / -1.  Every pose is paired with its own point's rotation and translation
+    (the reference mixes up two index lists there, see oracle/postprocess.py)."""
+    xyz = _F._f32c(scene_points, "scene_points")
+    R = _F._f32c(predictions["frame_R"], "frame_R")
+    t = _F._f32c(predictions["frame_t"], "frame_t")
+    score = expected_score(predictions["score"], "detector")                    # (B, N)
+    B, _, N = xyz.shape
+    dev = xyz.device
+    dm = torch.eye(3, device=dev) if direction_matrix is None else \
+        torch.as_tensor(direction_matrix, dtype=torch.float32, device=dev)
+    v = torch.as_tensor(vertical_direction, dtype=torch.float32, device=dev)
+    w = -(dm.t() @ v)                                                           # (-A r0) . v == r0 . (-A^T v)
+    r0 = R.view(B, 3, 3, N)[:, :, 0, :]                                         # first column of every R
+    vertical = (r0 * w.view(1, 3, 1)).sum(dim=1)                                # (B, N)
+    keep = (score > score_threshold) & (vertical > verticalness_threshold)
+    key = torch.where(keep, score, torch.full_like(score, float("-inf")))
+    K = min(int(max_poses), N)
+    top, sel = torch.sort(key, dim=1, descending=True, stable=True)
+    top, sel = top[:, :K], sel[:, :K].contiguous()
+    count = keep.sum(dim=1).clamp(max=K)
+    bins = torch.tensor(T_BINS[:t.shape[1]], dtype=torch.float32, device=dev)
+    H = torch.empty((B, K, 4, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _cabi.lib().s4g_decode_poses_f32(xyz.data_ptr(), R.data_ptr(), t.data_ptr(),
+                                              sel.data_ptr(), B, N, K, t.shape[1], bins.data_ptr(),
+                                              H.data_ptr(), _F._stream())
+    _cabi.check(rc, "decode_poses")
+    fr = torch.as_tensor(frame, dtype=torch.float32, device=dev)
+    H = torch.matmul(fr.view(1, 1, 4, 4), H)
+    valid = torch.arange(K, device=dev).view(1, K) < count.view(B, 1)
+    H = torch.where(valid.view(B, K, 1, 1), H, torch.zeros_like(H))
+    top = torch.where(valid, top, torch.zeros_like(top))
+    sel = torch.where(valid, sel, torch.full_like(sel, -1))
+    return H, top, sel, count
+
+
+def importance_sampling(score, count, num_selected, generator=None):
+    """grasp_detector.py:237-251 on the device: `num_selected` draws per scene from the first
+    count[b] poses with probability proportional to exp(5 score) (sorted uniforms against the
+    cumulative sum = systematic inverse-CDF sampling).  Returns indices (B, num_selected) into the
+    pose list (ascending); scenes with count <= num_selected keep 0..count-1 (padded with -1)."""
+    B, K = score.shape
+    dev = score.device
+    valid = torch.arange(K, device=dev).view(1, K) < count.view(B, 1)
+    wgt = torch.where(valid, torch.exp(5.0 * score.double()), torch.zeros((), dtype=torch.float64, device=dev))
+    cum = torch.cumsum(wgt, dim=1)
+    u = torch.rand((B, num_selected), generator=generator, device=dev, dtype=torch.float64)
+    target = torch.sort(u, dim=1)[0] * cum[:, -1:]
+    pick = torch.searchsorted(cum, target, right=False).clamp(max=K - 1)
+    ar = torch.arange(num_selected, device=dev).view(1, -1).expand(B, -1)
+    few = count.view(B, 1) <= num_selected
+    pick = torch.where(few, torch.where(ar < count.view(B, 1), ar, torch.full_like(ar, -1)), pick)
+    return pick
+
+
 @dataclass
 class GripperConfig:
     """configs/gripper_config.py:10-21 and processing_config.py:25,37-40."""

@@ -90,3 +90,31 @@ def test_randomize_bn_is_deterministic_and_nontrivial():
     assert all(torch.equal(a[k], b[k]) for k in a)
     k = "sa_modules.0.mlp.0.bn.running_var"
     assert not torch.allclose(a[k], torch.ones_like(a[k]))
+
+
+def test_detector_oracle_literal_restatement_and_its_index_mixup():
+    """oracle/postprocess.py restates GraspDetector.post_processing twice: `literal` follows the
+    reference's indexing as written (it uses positions inside `high_score_index` as point indices
+    for frame_R), the default pairs every pose with its own point.  The two agree exactly when the
+    high-score set is a prefix 0..n-1 whose scores already descend (then both index lists are the
+    identity) and differ otherwise."""
+    import numpy as np
+    from oracle import postprocess as OP
+    rng = np.random.default_rng(2)
+    N = 400
+    pred = {"score": np.zeros((3, N), np.float32), "frame_R": rng.standard_normal((9, N)).astype(np.float32),
+            "frame_t": rng.standard_normal((4, N)).astype(np.float32)}
+    pts = rng.random((3, N)).astype(np.float32)
+    pred["score"][2] = np.linspace(6, -6, N)           # expected score strictly descending in the index
+    a = OP.detector_post_processing(pred, pts, 0.7, 0.1, np.eye(3))
+    b = OP.detector_post_processing(pred, pts, 0.7, 0.1, np.eye(3), literal=True)
+    assert len(a[2]) > 10 and np.array_equal(a[2], b[2]) and np.allclose(a[0], b[0]) and np.allclose(a[1], b[1])
+    assert (np.diff(a[1]) <= 0).all()
+    pred["score"][2] = rng.standard_normal(N) * 4      # generic scores: the literal pairing differs
+    a = OP.detector_post_processing(pred, pts, 0.7, 0.1, np.eye(3))
+    b = OP.detector_post_processing(pred, pts, 0.7, 0.1, np.eye(3), literal=True)
+    assert (np.diff(a[1]) <= 0).all() and not (np.diff(b[1]) <= 0).all()
+    # frames are orthonormal and carry the caller's frame change
+    R = a[0][:, :3, :3]
+    assert np.allclose(np.einsum("nij,nik->njk", R, R), np.eye(3), atol=1e-9)
+    assert np.allclose(np.abs(np.linalg.det(R)), 1.0)

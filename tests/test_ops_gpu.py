@@ -128,7 +128,7 @@ def bq_mode(monkeypatch):
     return set_mode
 
 
-@pytest.mark.parametrize("mode", ["cell", "grid", "scan"])
+@pytest.mark.parametrize("mode", ["cell", "grid", "grid4", "scan"])
 @pytest.mark.parametrize("variant,N,M,r,K", [
     ("tabletop-v1", 25600, 5120, 0.02, 64),    # SA1
     ("tabletop-v1", 25600, 2000, 0.01, 32),    # scene wider than 32 cells: toroidal aliasing
@@ -150,7 +150,7 @@ def test_ball_query_grid_and_scan_paths(F, oracle, dev, bq_mode, mode, variant, 
     assert cnt[0, 0].item() == 0 and (idx[0, 0] == 0).all()
 
 
-@pytest.mark.parametrize("mode", ["cell", "grid"])
+@pytest.mark.parametrize("mode", ["cell", "grid", "grid4"])
 def test_ball_query_grid_out_of_range_scene_falls_back(F, oracle, dev, bq_mode, mode):
     """A scene spanning > 4096 cells trips the exactness flag: its centroids take
     the index-order scan inside the grid kernel; the other scene stays on the grid."""
@@ -167,7 +167,7 @@ def test_ball_query_grid_out_of_range_scene_falls_back(F, oracle, dev, bq_mode, 
     assert np.array_equal(g2.cpu().numpy(), oracle.group_points(pts, ridx))
 
 
-@pytest.mark.parametrize("mode", ["auto", "scan", "cell"])
+@pytest.mark.parametrize("mode", ["auto", "scan", "cell", "grid"])
 @pytest.mark.parametrize("N,M,r", [(25600, 5120, 0.02), (5120, 1024, 0.08)])
 def test_query_and_group_equals_operator_pair(F, oracle, dev, bq_mode, mode, N, M, r):
     bq_mode(mode)
