@@ -352,6 +352,208 @@ __global__ __launch_bounds__(THREADS) void fps_hybrid_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------
+// Two-CU cluster for 25 600 < N <= 51 200 points.
+//
+// One CU's register file holds 25 600 points (512 threads x 50 x 4 floats); the hybrid kernel
+// above keeps only x and the min-distances there and re-reads y / z from L2 every step (6.5 us
+// per step, bound by one CU's L2 read rate).  Here TWO workgroups share a scene, each with half
+// of the points entirely in registers (fps_reg_kernel's loop on q = h * PPT + p, so a thread's
+// points still share j mod bs and the tie rule is untouched), and the two local winners are
+// exchanged through L2 once per step:
+//   * wave 0, lanes 0..4 publish (distance bits, tie key, x, y, z) as five naturally aligned
+//     8-byte {payload, step} granules, each ONE write-through store (agent-scope relaxed atomic
+//     = global_store_dwordx2 sc1), into the slot of this step's parity;
+//   * the same lanes poll the partner's five granules with L1-bypassing loads until every tag
+//     equals the step number -- a granule validates itself, so no fence and no separate flag
+//     (MI355X_MICROARCH.md hand-off price list: ~1 us per hop);
+//   * both sides then pick the winner by the same rule (larger distance, then smaller tie key)
+//     and hand it to their other waves through LDS (one more barrier).
+// Slot reuse is safe without further synchronisation: a workgroup can be at most one step ahead
+// of its partner (it needs the partner's record of step i to leave step i), and step i + 2
+// reuses step i's slot.  The tags of a previous launch never match because the caller zeroes
+// the exchange buffer (step numbers start at 1).  Every poll loop is bounded: a partner that
+// never shows up (which would mean the two workgroups are not co-resident for seconds) sets an
+// error flag instead of hanging the device.
+struct FpsXch {
+  unsigned long long g[8];   // 5 granules used; 64 bytes per (scene, parity, half)
+};
+constexpr int FPS_XCH_SPIN = 1 << 24;
+
+template <int THREADS, int PPT, bool FMAD, typename IdxT>
+__global__ __launch_bounds__(THREADS) void fps_cluster_kernel(
+    const float* __restrict__ xyz, int N, int M, IdxT* __restrict__ idx, float* __restrict__ ctr,
+    int lg_bs, FpsXch* __restrict__ xch, int* __restrict__ err) {
+  constexpr int WAVES = THREADS / 64;
+  __shared__ FpsSlot slots[2][FPS_MAX_WAVES];
+  __shared__ FpsSlot glob[2];
+  const int b = blockIdx.x >> 1;
+  const int h = blockIdx.x & 1;           // which half of the points this workgroup owns
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const float* __restrict__ px = xyz + (size_t)b * 3 * N;
+  const float* __restrict__ py = px + N;
+  const float* __restrict__ pz = py + N;
+  IdxT* __restrict__ out = idx + (size_t)b * M;
+  float* __restrict__ cout = ctr ? ctr + (size_t)b * 3 * M : nullptr;
+  FpsXch* __restrict__ xb = xch + (size_t)b * 4;   // [parity][half]
+
+  float x[PPT], y[PPT], z[PPT], md[PPT];
+  const int jbase = t + THREADS * PPT * h;
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    const int j = jbase + THREADS * p;
+    const bool ok = j < N;
+    const int jj = ok ? j : 0;
+    x[p] = px[jj];
+    y[p] = py[jj];
+    z[p] = pz[jj];
+    md[p] = ok ? __builtin_inff() : -1.0f;
+  }
+  const uint32_t bs_mask = (1u << lg_bs) - 1u;
+  const uint32_t rkey = (__brev((uint32_t)t & bs_mask) >> (32 - lg_bs)) << 23;
+
+  int cur = 0;
+  float cx = px[0], cy = py[0], cz = pz[0];
+  if (t == 0 && h == 0) {
+    out[0] = 0;
+    if (cout) {
+      cout[0] = cx;
+      cout[M] = cy;
+      cout[2 * M] = cz;
+    }
+  }
+  bool dead = false;   // the partner never answered: finish the loop without waiting again
+
+  for (int i = 1; i < M; ++i) {
+    float best = 0.0f;
+    int bestp = -1;
+    const fps_v2f cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
+#pragma unroll
+    for (int p = 0; p + 1 < PPT; p += 2) {
+      const fps_v2f xv = {x[p], x[p + 1]}, yv = {y[p], y[p + 1]}, zv = {z[p], z[p + 1]};
+      const fps_v2f dx = xv - cx2, dy = yv - cy2, dz = zv - cz2;
+      fps_v2f d;
+      if constexpr (FMAD) {
+        d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+      } else {
+        d = (dx * dx + dy * dy) + dz * dz;
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float m;
+        asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(d[e]), "v"(md[p + e]));
+        md[p + e] = m;
+        if (m > best) {
+          best = m;
+          bestp = p + e;
+        }
+      }
+    }
+    static_assert((PPT & 1) == 0, "points are scanned in pairs");
+    const uint32_t jbest = (bestp < 0) ? (uint32_t)cur : (uint32_t)(jbase + THREADS * bestp);
+    const uint32_t tie = rkey | jbest;
+    const uint32_t dbits = __float_as_uint(best);
+    const uint32_t wmax = wave_max_u32(dbits);
+    uint64_t win = __ballot(dbits == wmax);
+    uint32_t wtie;
+    if (__popcll(win) > 1) {
+      wtie = wave_min_u32((dbits == wmax) ? tie : 0xFFFFFFFFu);
+      win = __ballot(dbits == wmax && tie == wtie);
+    } else {
+      wtie = __builtin_amdgcn_readlane(tie, __ffsll((unsigned long long)win) - 1);
+    }
+    const int wl = __ffsll((unsigned long long)win) - 1;
+    const int pw = __builtin_amdgcn_readlane(bestp, wl);
+    float sx = cx, sy = cy, sz = cz;
+    if (pw >= 0) fps_pick<PPT, 0, PPT>(x, y, z, pw, wl, sx, sy, sz);
+    // ---- this workgroup's winner (every wave computes it from the LDS slots)
+    if (lane == 0) {
+      FpsSlot s;
+      s.d = wmax;
+      s.tie = wtie;
+      s.x = sx;
+      s.y = sy;
+      s.z = sz;
+      s.pad[0] = s.pad[1] = s.pad[2] = 0;
+      slots[i & 1][wave] = s;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const FpsSlot s = slots[i & 1][lane & (WAVES - 1)];
+      const uint32_t bmax = row16_max_u32(s.d);
+      uint64_t w2 = __ballot(s.d == bmax) & ((1ull << WAVES) - 1ull);
+      uint32_t btie;
+      if (__popcll(w2) > 1) {
+        const uint32_t cand = (s.d == bmax) ? s.tie : 0xFFFFFFFFu;
+        btie = __builtin_amdgcn_readlane(row16_min_u32(cand), 0);
+        w2 = __ballot(s.d == bmax && s.tie == btie);
+      } else {
+        btie = __builtin_amdgcn_readlane(s.tie, __ffsll((unsigned long long)w2) - 1);
+      }
+      const int l2 = __ffsll((unsigned long long)w2) - 1;
+      const uint32_t ld = __builtin_amdgcn_readlane(bmax, 0);
+      const uint32_t lx = __builtin_amdgcn_readlane(__float_as_uint(s.x), l2);
+      const uint32_t ly = __builtin_amdgcn_readlane(__float_as_uint(s.y), l2);
+      const uint32_t lz = __builtin_amdgcn_readlane(__float_as_uint(s.z), l2);
+      // ---- exchange with the partner workgroup: five {payload, step} granules
+      const uint32_t mine = lane == 0 ? ld : lane == 1 ? btie : lane == 2 ? lx : lane == 3 ? ly : lz;
+      unsigned long long theirs = 0;
+      if (lane < 5) {
+        __hip_atomic_store(&xb[(i & 1) * 2 + h].g[lane], ((unsigned long long)(uint32_t)i << 32) | mine,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (!dead) {
+        int spins = 0;
+        for (;;) {
+          if (lane < 5)
+            theirs = __hip_atomic_load(&xb[(i & 1) * 2 + (h ^ 1)].g[lane], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+          const bool ready = lane >= 5 || (uint32_t)(theirs >> 32) == (uint32_t)i;
+          if (__all(ready)) break;
+          if (++spins > FPS_XCH_SPIN) {
+            dead = true;
+            if (lane == 0) atomicExch(err, 1);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      const uint32_t tv = (uint32_t)theirs;
+      const uint32_t rd = __builtin_amdgcn_readlane(tv, 0), rtie = __builtin_amdgcn_readlane(tv, 1);
+      const bool remote = !dead && (rd > ld || (rd == ld && rtie < btie));
+      if (lane == 0) {
+        FpsSlot gsl;
+        gsl.d = dead ? 1u : 0u;
+        gsl.tie = remote ? rtie : btie;
+        gsl.x = __uint_as_float(remote ? __builtin_amdgcn_readlane(tv, 2) : lx);
+        gsl.y = __uint_as_float(remote ? __builtin_amdgcn_readlane(tv, 3) : ly);
+        gsl.z = __uint_as_float(remote ? __builtin_amdgcn_readlane(tv, 4) : lz);
+        gsl.pad[0] = gsl.pad[1] = gsl.pad[2] = 0;
+        glob[i & 1] = gsl;
+      }
+    }
+    __syncthreads();
+    {
+      const FpsSlot gsl = glob[i & 1];
+      cur = (int)(gsl.tie & FPS_JMASK);
+      cx = gsl.x;
+      cy = gsl.y;
+      cz = gsl.z;
+      dead = gsl.d != 0u;
+    }
+    if (t == 0 && h == 0) {
+      out[i] = (IdxT)cur;
+      if (cout) {
+        cout[i] = cx;
+        cout[M + i] = cy;
+        cout[2 * M + i] = cz;
+      }
+    }
+  }
+}
+
 // Streaming fallback: any N < 2^23.  min-distance in `temp` (B,N) fp32.
 template <bool FMAD, typename IdxT>
 __global__ __launch_bounds__(FPS_THREADS) void fps_stream_kernel(
@@ -832,6 +1034,12 @@ static int ref_block_lg(int64_t n) {
   return cnt;
 }
 
+static bool fps_use_cluster() {   // S4G_FPS_MODE=hybrid: the single-CU kernel for 25 600 < N <= 51 200
+  const char* e = getenv("S4G_FPS_MODE");
+  return !(e && e[0] == 'h');
+}
+static size_t fps_cluster_ws_bytes(int64_t B) { return (size_t)B * 4 * sizeof(FpsXch) + 64; }
+
 template <bool FMAD, typename IdxT>
 static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
                       IdxT* idx, float* ctr, void* ws, size_t ws_bytes,
@@ -916,6 +1124,18 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
 #undef S4G_FPS_PRUNED
   }
   if (launched) return S4G_OK;
+  // two workgroups per scene, all points in registers, winners exchanged through L2 once per
+  // step (S4G_FPS_MODE=hybrid keeps the single-CU kernel below)
+  if (N <= (int64_t)512 * 100 && fps_use_cluster() && ws && ws_bytes >= fps_cluster_ws_bytes(B)) {
+    FpsXch* xch = (FpsXch*)ws;
+    int* err = (int*)((char*)ws + (size_t)B * 4 * sizeof(FpsXch));
+    const hipError_t e = hipMemsetAsync(ws, 0, fps_cluster_ws_bytes(B), stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((fps_cluster_kernel<512, 50, FMAD, IdxT>), dim3((unsigned)(2 * B)), dim3(512), 0,
+                       stream, xyz, (int)N, (int)M, idx, ctr, lg, xch, err);
+    S4G_LAUNCH_CHECK();
+    return S4G_OK;
+  }
   if (N <= (int64_t)512 * 100) {   // x + min-distance in registers, y / z streamed from L2
     hipLaunchKernelGGL((fps_hybrid_kernel<512, 100, 10, FMAD, IdxT>), grid, dim3(512), 0, stream, xyz,
                        (int)N, (int)M, idx, ctr, lg);
@@ -933,7 +1153,7 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
 size_t fps_workspace_bytes(int64_t B, int64_t N) {
   if (N <= 0 || B <= 0) return 0;
   if (N <= (int64_t)512 * 50) return fps_use_pruned(N) ? fps_sort_ws(nullptr, B, N).total : 0;
-  if (N <= (int64_t)512 * 100) return 0;   // hybrid kernel
+  if (N <= (int64_t)512 * 100) return fps_cluster_ws_bytes(B);   // cluster kernel's exchange slots
   return (size_t)B * (size_t)N * sizeof(float);
 }
 

@@ -739,7 +739,9 @@ constexpr int GH_STR = 32;
 // CU), 4 -> 128 x 256 tile, wave tile 64 x 128 (two workgroups per CU): 25 % less
 // LDS and L1 traffic per MFMA and twice the matrix work per barrier; used when
 // Cout > 128.
-template <int LOADER, int EPI, int NCB>
+// PL = 2: the f16x2 split; PL = 1: ONE bf16 plane per operand and one product (S4G_GEMM_BF16: W is
+// the hi plane of W_bf16x3, no scales) -- the same tile loop at a third of the matrix work.
+template <int LOADER, int EPI, int NCB, int PL>
 __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP || LOADER == LOAD_INTERP_ADD) ? 2 : 3) void mlp_gemm_f16x2_kernel(
     const GemmParams p) {
   constexpr int BN = 64 * NCB;
@@ -748,7 +750,7 @@ __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP || LOADER =
   constexpr int WPLANE = BN * GH_STR;     // halves per W plane
   extern __shared__ __attribute__((aligned(16))) float smemf[];
   uint16_t* Ah = reinterpret_cast<uint16_t*>(smemf);  // [2][BM][40]
-  uint16_t* Wh = Ah + 2 * APLANE;                     // [2][BN][40]
+  uint16_t* Wh = Ah + PL * APLANE;                    // [PL][BN][32]
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -765,25 +767,25 @@ __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP || LOADER =
   const int p0 = mt * GM_BM;
   const int n0 = nt * BN;
   const float* __restrict__ bg = p.bias + (size_t)g * p.b_gstride;
-  const uint16_t* __restrict__ Wg = p.Wh2 + (size_t)g * p.Cout * p.Kpad16;
+  const uint16_t* __restrict__ Wg = (PL == 2 ? p.Wh2 : p.W3) + (size_t)g * p.Cout * p.Kpad16;
 
   // activation scale: the power of two that puts the tensor maximum in [2^14, 2^15)
-  float amax = p.a_amax_floor;
+  float amax = PL == 2 ? p.a_amax_floor : 1.f;
   constexpr bool ADD_BOUNDS = LOADER == LOAD_GATHER_ADD || LOADER == LOAD_INTERP_ADD;   // the loader SUMS its inputs
   const int p_hi = min(p0 + GM_BM, p.P) - 1;   // rows of this tile: [p0, p_hi]
-  if (p.a_amax) {
+  if (PL == 2 && p.a_amax) {
     const float m = amax_rows(p.a_amax, lane, p0, p_hi, p.rps);
     amax = ADD_BOUNDS ? amax + m : fmaxf(amax, m);
   }
-  if (p.a_amax2) {
+  if (PL == 2 && p.a_amax2) {
     const float m = amax_rows(p.a_amax2, lane, p0, p_hi, p.rps);
     amax = ADD_BOUNDS ? amax + m : fmaxf(amax, m);
   }
   uint32_t ex = __float_as_uint(amax) >> 23;
   ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
   ex = __builtin_amdgcn_readfirstlane(ex);
-  const float sa = __uint_as_float((268u - ex) << 23);       // 2^(141 - ex)
-  const float inv_sa = __uint_as_float((ex - 14u) << 23);    // 2^(ex - 141)
+  const float sa = PL == 2 ? __uint_as_float((268u - ex) << 23) : 1.f;       // 2^(141 - ex)
+  const float inv_sa = PL == 2 ? __uint_as_float((ex - 14u) << 23) : 1.f;   // 2^(ex - 141)
 
   ALoader<LOADER, RPT, RS> ld;
   ld.init(p, p0, g, t);
@@ -816,7 +818,7 @@ __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP || LOADER =
   const int f_off[2] = {((0 + lh) ^ fswz) * 8, ((2 + lh) ^ fswz) * 8};   // chunk 2 ks + lh
 
   float4 ra[RPT];
-  uint4 rw[2][WPT];
+  uint4 rw[PL][WPT];
   const int ntile_k = (p.Kpad16 + BK - 1) / BK;
 
   auto gload = [&](int kt) {
@@ -826,7 +828,7 @@ __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP || LOADER =
     for (int s = 0; s < RPT; ++s) ra[s] = live ? ld.load(p, s, k0, t) : f4zero();
     const bool wlive = kt * BK + wchunk * 8 < p.Kpad16;
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
+    for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
       for (int s = 0; s < WPT; ++s)
         rw[pl][s] = (wlive && wok[s])
@@ -836,45 +838,49 @@ __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP || LOADER =
   auto lstore = [&]() {
 #pragma unroll
     for (int s = 0; s < RPT; ++s) {
-      uint2 h, l;
-      split2_h<LOADER == LOAD_GATHER>(ra[s], sa, h, l);
       uint16_t* dst = Ah + (srow + RS * s) * GH_STR + (((chunk >> 1) ^ ((srow >> 2) & 3)) * 8) + (chunk & 1) * 4;
-      *reinterpret_cast<uint2*>(dst) = h;
-      *reinterpret_cast<uint2*>(dst + APLANE) = l;
+      if constexpr (PL == 2) {
+        uint2 h, l;
+        split2_h<LOADER == LOAD_GATHER>(ra[s], sa, h, l);
+        *reinterpret_cast<uint2*>(dst) = h;
+        *reinterpret_cast<uint2*>(dst + APLANE) = l;
+      } else {
+        *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pk_bf16(ra[s].x, ra[s].y), cvt_pk_bf16(ra[s].z, ra[s].w));
+      }
     }
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
+    for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
       for (int s = 0; s < WPT; ++s)
         *reinterpret_cast<uint4*>(Wh + pl * WPLANE + (wrow + WRS * s) * GH_STR +
                                   ((wchunk ^ ((wrow >> 2) & 3)) * 8)) = rw[pl][s];
   };
 
-#define S4G_H2_TERM(PA, PB)                                                                              \
-  acc[0][cp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][PA], bf[0][PB], acc[0][cp], 0, 0, 0);         \
-  acc[0][cp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][PA], bf[1][PB], acc[0][cp + 1], 0, 0, 0); \
-  acc[1][cp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][PA], bf[0][PB], acc[1][cp], 0, 0, 0);         \
-  acc[1][cp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][PA], bf[1][PB], acc[1][cp + 1], 0, 0, 0);
+#define S4G_H2_TERM(PA, PB)                                                        \
+  acc[0][cp] = chain_mfma<PL>(af[0][PA], bf[0][PB], acc[0][cp]);                     \
+  acc[0][cp + 1] = chain_mfma<PL>(af[0][PA], bf[1][PB], acc[0][cp + 1]);             \
+  acc[1][cp] = chain_mfma<PL>(af[1][PA], bf[0][PB], acc[1][cp]);                     \
+  acc[1][cp + 1] = chain_mfma<PL>(af[1][PA], bf[1][PB], acc[1][cp + 1]);
   auto compute_ks = [&](int ks) {
-    f16x8 af[2][2];
+    uint4 af[2][PL];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-        af[rb][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(
-            Ah + pl * APLANE + a_row + rb * 32 * GH_STR + f_off[ks]));
+      for (int pl = 0; pl < PL; ++pl)
+        af[rb][pl] = *reinterpret_cast<const uint4*>(Ah + pl * APLANE + a_row + rb * 32 * GH_STR + f_off[ks]);
 #pragma unroll
     for (int cp = 0; cp < NCB; cp += 2) {
-      f16x8 bf[2][2];
+      uint4 bf[2][PL];
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-          bf[cb][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(
-              Wh + pl * WPLANE + b_row + (cp + cb) * 32 * GH_STR + f_off[ks]));
-      // three products per tile, the small cross terms first
-      S4G_H2_TERM(0, 1)
-      S4G_H2_TERM(1, 0)
+        for (int pl = 0; pl < PL; ++pl)
+          bf[cb][pl] = *reinterpret_cast<const uint4*>(Wh + pl * WPLANE + b_row + (cp + cb) * 32 * GH_STR + f_off[ks]);
+      // three products per tile, the small cross terms first (one product for a single plane)
+      if constexpr (PL == 2) {
+        S4G_H2_TERM(0, 1)
+        S4G_H2_TERM(1, 0)
+      }
       S4G_H2_TERM(0, 0)
     }
   };
@@ -898,7 +904,7 @@ __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP || LOADER =
   for (int cb = 0; cb < NCB; ++cb) {
     const int n = n0 + wc * 32 * NCB + cb * 32 + li;
     const bool nok = n < p.Cout;
-    const float sc = nok ? inv_sa * p.w_inv_scale[(size_t)g * p.b_gstride + n] : 0.f;
+    const float sc = nok ? (PL == 2 ? inv_sa * p.w_inv_scale[(size_t)g * p.b_gstride + n] : 1.f) : 0.f;
     const float bias = nok ? bg[n] : 0.f;
     float mx = -__builtin_inff(), mn = __builtin_inff();
 #pragma unroll
@@ -913,26 +919,26 @@ __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP || LOADER =
     const float hi = mx + bias, lo = mn + bias;
     tmax = fmaxf(tmax, p.relu ? hi : fmaxf(fabsf(hi), fabsf(lo)));
   }
-  if (p.out_amax) {
+  if (PL == 2 && p.out_amax) {
     const uint32_t wm = wave_max_u32(__float_as_uint(fmaxf(tmax, 0.f)));
     if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave, p0, p_hi, p.rps);
   }
   gemm_epilogue<EPI, NCB>(p, acc, bg, g, p0, n0, wave, wr, wc, li, lh, smemf);
 }
 
-template <int LOADER, int EPI, int NCB>
+template <int LOADER, int EPI, int NCB, int PL>
 static int launch_gemm_f16x2_cfg(GemmParams p, int groups, hipStream_t st) {
   constexpr int BN = 64 * NCB;
   p.ntiles = (p.Cout + BN - 1) / BN;
-  size_t lds = sizeof(uint16_t) * 2 * (GM_BM + BN) * GH_STR;
+  size_t lds = sizeof(uint16_t) * PL * (GM_BM + BN) * GH_STR;
   const size_t epi = sizeof(float) * 4 * 32 * (32 * NCB + 4);   // staged epilogue stores
   if (lds < epi) lds = epi;
   static const hipError_t attr = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&mlp_gemm_f16x2_kernel<LOADER, EPI, NCB>),
+      reinterpret_cast<const void*>(&mlp_gemm_f16x2_kernel<LOADER, EPI, NCB, PL>),
       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr != hipSuccess) return (int)attr;
   const dim3 grid((unsigned)(p.mtiles * p.ntiles), (unsigned)groups);
-  hipLaunchKernelGGL((mlp_gemm_f16x2_kernel<LOADER, EPI, NCB>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((mlp_gemm_f16x2_kernel<LOADER, EPI, NCB, PL>), grid, dim3(256), lds, st, p);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }
@@ -1618,7 +1624,7 @@ static int launch_gemm_f16x2_resident(const GemmParams& p, int groups, hipStream
   return S4G_OK;
 }
 
-template <int LOADER, int EPI>
+template <int LOADER, int EPI, int PL = 2>
 static int launch_gemm_f16x2(const GemmParams& p, int groups, hipStream_t st) {
   static const int force = [] { const char* e = getenv("S4G_GEMM_NCB"); return e ? atoi(e) : 0; }();
   // S4G_GEMM_RESIDENT=0 never / 1 whenever the shape qualifies / unset: only where it
@@ -1631,7 +1637,7 @@ static int launch_gemm_f16x2(const GemmParams& p, int groups, hipStream_t st) {
     // resident-A kernel: short contractions whose A panel fits LDS twice per CU
     const bool vec_ok = ((p.ldc | p.c_coff | p.c_gcol) & 3) == 0 &&
                         ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
-    if (!no_resident && !force && p.Wfrag && (EPI != EPI_STORE || vec_ok) &&
+    if (PL == 2 && !no_resident && !force && p.Wfrag && (EPI != EPI_STORE || vec_ok) &&
         (EPI != EPI_MAX || p.K == 64) && (any_resident || p.Cout >= 1024)) {
       if (p.Kpad16 == 256 && p.Cout % 256 == 0)
         return launch_gemm_f16x2_resident<LOADER, EPI, 1, 256>(p, groups, st);
@@ -1646,8 +1652,8 @@ static int launch_gemm_f16x2(const GemmParams& p, int groups, hipStream_t st) {
   const bool wide = force ? force == 4
                           : p.Cout > 128 && (LOADER == LOAD_PLAIN || LOADER == LOAD_GATHER_MLP1 ||
                                              LOADER == LOAD_GATHER_ADD);
-  if (wide) return launch_gemm_f16x2_cfg<LOADER, EPI, 4>(p, groups, st);
-  return launch_gemm_f16x2_cfg<LOADER, EPI, 2>(p, groups, st);
+  if (wide) return launch_gemm_f16x2_cfg<LOADER, EPI, 4, PL>(p, groups, st);
+  return launch_gemm_f16x2_cfg<LOADER, EPI, 2, PL>(p, groups, st);
 }
 
 template <int LOADER, int EPI, int NS, int WAVES>
@@ -1841,9 +1847,13 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
 #undef S4G_FUSED2_CASE
     return S4G_EUNSUPPORTED;
   }
+  // single-product bf16: the swizzled-LDS tile kernel with one plane (S4G_BF16_TILED=0: the bf16x3
+  // kernel's hi-plane-only mode it replaced)
+  static const bool bf16_tiled = [] { const char* e = getenv("S4G_BF16_TILED"); return !(e && e[0] == '0'); }();
 #define S4G_GEMM_CASE(L, E)                                            \
   if (d->loader == L && d->epilogue == E)                              \
     return h2 ? launch_gemm_f16x2<L, E>(p, d->groups, st)              \
+           : (p.bf16_single && bf16_tiled) ? launch_gemm_f16x2<L, E, 1>(p, d->groups, st) \
            : split ? launch_gemm_bf16x3<L, E>(p, d->groups, st)        \
                    : launch_gemm<L, E>(p, d->groups, st);
   S4G_GEMM_CASE(LOAD_PLAIN, EPI_STORE)

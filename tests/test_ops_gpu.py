@@ -60,8 +60,12 @@ def test_fps_pruned_variant_is_exact(F, oracle, dev, monkeypatch, N, M, variant)
     assert np.array_equal(F.farthest_point_sample(_t(pts, dev), M).cpu().numpy(), got)
 
 
-def test_fps_hybrid_kernel_large_cloud(F, oracle, dev):
-    """25 600 < N <= 51 200: x + min-distance in registers, y / z re-read from L2."""
+@pytest.mark.parametrize("mode", ["cluster", "hybrid"])
+def test_fps_hybrid_kernel_large_cloud(F, oracle, dev, monkeypatch, mode):
+    """25 600 < N <= 51 200.  cluster (default): two workgroups per scene, each with half of the
+    points in registers, the local winners exchanged through L2 every step; hybrid
+    (S4G_FPS_MODE=hybrid): one workgroup, x + min-distance in registers, y / z re-read from L2."""
+    monkeypatch.setenv("S4G_FPS_MODE", mode)
     pts = synth.make_batch([2], 51200)
     got = F.farthest_point_sample(_t(pts, dev), 300).cpu().numpy()
     assert np.array_equal(got, oracle.fps(pts, 300))
@@ -69,6 +73,24 @@ def test_fps_hybrid_kernel_large_cloud(F, oracle, dev):
         pts = synth.make_batch([6], n, variant=variant)
         got = F.farthest_point_sample(_t(pts, dev), 200).cpu().numpy()
         assert np.array_equal(got, oracle.fps(pts, 200)), (n, variant)
+
+
+@pytest.mark.parametrize("variant", ["tabletop-v1", "dup-heavy"])
+def test_fps_cluster_full_size_batch_ties_and_fmad(F, oracle, dev, variant):
+    """configs[4] geometry: FPS 51 200 -> 5 120 with ALL 5 119 steps, three scenes (six cooperating
+    workgroups), exact ties that straddle the two halves (duplicate-heavy cloud), both arithmetic
+    contracts; the int32 + centroid-gather entry point of the fast path agrees."""
+    pts = synth.make_batch([0, 1, 7], 51200, variant=variant)
+    got = F.farthest_point_sample(_t(pts, dev), 5120).cpu().numpy()
+    assert np.array_equal(got, oracle.fps(pts, 5120))
+    q = _quantized(np.random.default_rng(1), 2, 40000, levels=24, scale=0.03125)
+    assert np.array_equal(F.farthest_point_sample(_t(q, dev), 400).cpu().numpy(), oracle.fps(q, 400))
+    try:
+        F.set_distance_mode("fmad")
+        got = F.farthest_point_sample(_t(pts[:1], dev), 600).cpu().numpy()
+    finally:
+        F.set_distance_mode("strict")
+    assert np.array_equal(got, oracle.fps(pts[:1], 600, fmad=1))
 
 
 def test_fps_streaming_fallback_very_large_cloud(F, oracle, dev):
