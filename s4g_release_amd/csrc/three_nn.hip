@@ -112,6 +112,94 @@ __device__ __forceinline__ void nn_write(IdxT* __restrict__ idx, float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------
+// SPLIT scan for small key sets (24 <= N2 <= 2048: the two coarse FP levels).  The
+// lane-per-query scan above is a serial chain of N2 steps on ~1 wave per SIMD (FP2 size,
+// 5 120 x 1 024: 0.23 ms at 18 GB/s).  Here S lanes share a query: the keys sit in LDS as
+// 16-byte records, sub-lane s scans keys s, s + S, s + 2 S, ... (ascending inside a lane, so
+// the strict '<' insertion keeps the earlier key among equals exactly like the reference,
+// interpolate_kernel.cu:63-73), and the S partial triples are merged by a xor butterfly with
+// the (distance, key index) order -- the same three keys in the same order as one index-order
+// scan.  N2 / S steps instead of N2, S times as many waves.
+// ---------------------------------------------------------------------------
+template <bool FMAD, bool WEIGHTS, typename IdxT, int S>
+__global__ __launch_bounds__(NN_THREADS) void three_nn_split_kernel(
+    const float* __restrict__ q, const float* __restrict__ key, int N1, int N2, float eps,
+    IdxT* __restrict__ idx, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float4 keys[];
+  const int b = blockIdx.y;
+  const int t = threadIdx.x;
+  const float* __restrict__ kx = key + (size_t)b * 3 * N2;
+  for (int j = t; j < N2; j += NN_THREADS) keys[j] = make_float4(kx[j], kx[N2 + j], kx[2 * N2 + j], 0.f);
+  __syncthreads();
+  constexpr int QPB = NN_THREADS / S;
+  const int i = blockIdx.x * QPB + t / S;
+  const int sub = t % S;
+  const float* __restrict__ qx = q + (size_t)b * 3 * N1;
+  const int ii = i < N1 ? i : N1 - 1;
+  const float x1 = qx[ii], y1 = qx[N1 + ii], z1 = qx[2 * N1 + ii];
+  float b0 = __builtin_inff(), b1 = b0, b2 = b0;
+  int i0 = -1, i1 = -1, i2 = -1;
+  for (int j = sub; j < N2; j += S) {
+    const float4 k = keys[j];
+    const float d = dist2<FMAD>(k.x, k.y, k.z, x1, y1, z1);
+    const bool c0 = d < b0, c1 = d < b1, c2 = d < b2;
+    const bool c01 = c0 | c1;
+    b2 = c01 ? b1 : (c2 ? d : b2);
+    i2 = c01 ? i1 : (c2 ? j : i2);
+    b1 = c0 ? b0 : (c1 ? d : b1);
+    i1 = c0 ? i0 : (c1 ? j : i1);
+    b0 = c0 ? d : b0;
+    i0 = c0 ? j : i0;
+  }
+#pragma unroll
+  for (int off = 1; off < S; off <<= 1) {
+    const float pb[3] = {__shfl_xor(b0, off), __shfl_xor(b1, off), __shfl_xor(b2, off)};
+    const int pi[3] = {__shfl_xor(i0, off), __shfl_xor(i1, off), __shfl_xor(i2, off)};
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const float d = pb[e];
+      const int j = pi[e];
+      const bool c0 = nn_less(d, j, b0, i0), c1 = nn_less(d, j, b1, i1), c2 = nn_less(d, j, b2, i2);
+      const bool c01 = c0 | c1;
+      b2 = c01 ? b1 : (c2 ? d : b2);
+      i2 = c01 ? i1 : (c2 ? j : i2);
+      b1 = c0 ? b0 : (c1 ? d : b1);
+      i1 = c0 ? i0 : (c1 ? j : i1);
+      b0 = c0 ? d : b0;
+      i0 = c0 ? j : i0;
+    }
+  }
+  if (i < N1 && sub == 0)
+    nn_write<WEIGHTS, IdxT>(idx, out, ((size_t)b * N1 + i) * 3, i0, i1, i2, b0, b1, b2, eps);
+}
+
+// lane-per-query scan or, for the small key sets, the split scan (S4G_NN_SPLIT=0: never)
+template <bool FMAD, bool WEIGHTS, typename IdxT>
+static int launch_three_nn_scan(const float* q, const float* k, int64_t B, int64_t N1, int64_t N2,
+                                float eps, IdxT* idx, float* out, hipStream_t st) {
+  const char* e = getenv("S4G_NN_SPLIT");
+  const bool split = !(e && e[0] == '0') && N2 >= 24 && N2 <= 2048;
+  if (split) {
+    const size_t lds = sizeof(float4) * (size_t)N2;
+    if (N2 >= 256) {
+      const dim3 grid((unsigned)((N1 + NN_THREADS / 8 - 1) / (NN_THREADS / 8)), (unsigned)B);
+      hipLaunchKernelGGL((three_nn_split_kernel<FMAD, WEIGHTS, IdxT, 8>), grid, dim3(NN_THREADS), lds, st, q, k,
+                         (int)N1, (int)N2, eps, idx, out);
+    } else {
+      const dim3 grid((unsigned)((N1 + NN_THREADS / 4 - 1) / (NN_THREADS / 4)), (unsigned)B);
+      hipLaunchKernelGGL((three_nn_split_kernel<FMAD, WEIGHTS, IdxT, 4>), grid, dim3(NN_THREADS), lds, st, q, k,
+                         (int)N1, (int)N2, eps, idx, out);
+    }
+  } else {
+    const dim3 grid((unsigned)((N1 + NN_THREADS - 1) / NN_THREADS), (unsigned)B);
+    hipLaunchKernelGGL((three_nn_kernel<FMAD, WEIGHTS, IdxT>), grid, dim3(NN_THREADS), 0, st, q, k, (int)N1,
+                       (int)N2, eps, idx, out);
+  }
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
+
 // Cell edge for the operator-API grid search, chosen on the device (no host read):
 // `factor` x the mean distance from a key to its third-nearest other key, measured on 64
 // sample keys spread over the batch (one wave per sample scans its scene's keys, lanes
@@ -336,19 +424,10 @@ extern "C" int s4g_three_nn_f32(const float* q_b3n1, const float* k_b3n2,
     return S4G_EINVAL;  // N2 >= 3: interpolate_kernel.cu:106
   if (B == 0 || N1 == 0) return S4G_OK;
   if (!q_b3n1 || !k_b3n2 || !idx_bn3 || !d2_bn3) return S4G_EINVAL;
-  const dim3 grid((unsigned)((N1 + s4g::NN_THREADS - 1) / s4g::NN_THREADS),
-                  (unsigned)B);
   hipStream_t st = (hipStream_t)stream;
   if (flags & S4G_FLAG_FMAD)
-    hipLaunchKernelGGL((s4g::three_nn_kernel<true, false, int64_t>), grid,
-                       dim3(s4g::NN_THREADS), 0, st, q_b3n1, k_b3n2, (int)N1,
-                       (int)N2, 0.f, idx_bn3, d2_bn3);
-  else
-    hipLaunchKernelGGL((s4g::three_nn_kernel<false, false, int64_t>), grid,
-                       dim3(s4g::NN_THREADS), 0, st, q_b3n1, k_b3n2, (int)N1,
-                       (int)N2, 0.f, idx_bn3, d2_bn3);
-  S4G_LAUNCH_CHECK();
-  return S4G_OK;
+    return s4g::launch_three_nn_scan<true, false, int64_t>(q_b3n1, k_b3n2, B, N1, N2, 0.f, idx_bn3, d2_bn3, st);
+  return s4g::launch_three_nn_scan<false, false, int64_t>(q_b3n1, k_b3n2, B, N1, N2, 0.f, idx_bn3, d2_bn3, st);
 }
 
 extern "C" int s4g_three_nn_weights_i32(const float* q_b3n1, const float* k_b3n2,
@@ -363,19 +442,10 @@ extern "C" int s4g_three_nn_weights_i32(const float* q_b3n1, const float* k_b3n2
     return S4G_EINVAL;
   if (B == 0 || N1 == 0) return S4G_OK;
   if (!q_b3n1 || !k_b3n2 || !idx_bn3 || !w_bn3) return S4G_EINVAL;
-  const dim3 grid((unsigned)((N1 + s4g::NN_THREADS - 1) / s4g::NN_THREADS),
-                  (unsigned)B);
   hipStream_t st = (hipStream_t)stream;
   if (flags & S4G_FLAG_FMAD)
-    hipLaunchKernelGGL((s4g::three_nn_kernel<true, true, int32_t>), grid,
-                       dim3(s4g::NN_THREADS), 0, st, q_b3n1, k_b3n2, (int)N1,
-                       (int)N2, eps, idx_bn3, w_bn3);
-  else
-    hipLaunchKernelGGL((s4g::three_nn_kernel<false, true, int32_t>), grid,
-                       dim3(s4g::NN_THREADS), 0, st, q_b3n1, k_b3n2, (int)N1,
-                       (int)N2, eps, idx_bn3, w_bn3);
-  S4G_LAUNCH_CHECK();
-  return S4G_OK;
+    return s4g::launch_three_nn_scan<true, true, int32_t>(q_b3n1, k_b3n2, B, N1, N2, eps, idx_bn3, w_bn3, st);
+  return s4g::launch_three_nn_scan<false, true, int32_t>(q_b3n1, k_b3n2, B, N1, N2, eps, idx_bn3, w_bn3, st);
 }
 
 extern "C" size_t s4g_three_nn_grid_workspace_bytes(int64_t B, int64_t N1, int64_t N2) {

@@ -353,6 +353,25 @@ def three_nn_weights_grid(query_xyz, key_xyz, cell, eps=1e-10):
     return idx, w
 
 
+def three_nn_weights(query_xyz, key_xyz, eps=1e-10):
+    """Fast-path 3-NN by index-order scan: (index (B,N1,3) int32, interpolation weights
+    (B,N1,3) fp32), bit-identical to `search_nn_distance` + `interp_weights`
+    (`s4g_three_nn_weights_i32`: split scan for small key sets, lane-per-query scan otherwise)."""
+    query_xyz = _f32c(query_xyz, "query_xyz")
+    key_xyz = _f32c(key_xyz, "key_xyz")
+    B, _, N1 = query_xyz.shape
+    N2 = key_xyz.size(2)
+    if not N2 >= 3:
+        raise RuntimeError("num_key is not greater than or equal to num_neighbours")
+    idx = torch.empty((B, N1, 3), dtype=torch.int32, device=query_xyz.device)
+    w = torch.empty((B, N1, 3), dtype=torch.float32, device=query_xyz.device)
+    with torch.cuda.device(query_xyz.device):
+        rc = _cabi.lib().s4g_three_nn_weights_i32(_ptr(query_xyz), _ptr(key_xyz), B, N1, N2, float(eps),
+                                                  _ptr(idx), _ptr(w), None, 0, _DIST_FLAGS, _stream())
+    _cabi.check(rc, "three_nn_weights")
+    return idx, w
+
+
 def interp_weights(distance, eps=1e-10):
     """Inverse-distance weights of FeatureInterpolator.forward (modules.py:118-120)
     in one launch instead of three elementwise ones."""

@@ -318,6 +318,34 @@ def test_three_nn_ties_and_errors(F, oracle, dev):
         F.search_nn_distance(_t(q, dev), _t(k[:, :, :2], dev), 3)  # N2 >= 3
 
 
+@pytest.mark.parametrize("N1,N2", [(333, 24), (1000, 100), (1024, 256), (777, 1000), (5120, 1024), (300, 2048)])
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_three_nn_split_scan_ties_and_sizes(F, oracle, dev, monkeypatch, N1, N2, split):
+    """Small key sets take the split scan (S lanes per query, keys in LDS, butterfly merge on
+    (distance, key index)); S4G_NN_SPLIT=0 keeps the lane-per-query scan.  Exact ties everywhere
+    (coordinates on a coarse lattice, duplicated keys), fmad contract and the int32 + weights
+    entry point included."""
+    monkeypatch.setenv("S4G_NN_SPLIT", split)
+    rng = np.random.default_rng(N1 + N2)
+    q, k = _quantized(rng, 2, N1, levels=6), _quantized(rng, 2, N2, levels=6)
+    idx, d2 = F.search_nn_distance(_t(q, dev), _t(k, dev), 3)
+    ridx, rd2 = oracle.three_nn(q, k)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d2.cpu().numpy(), rd2)
+    pts = rng.random((2, 3, N1), dtype=np.float32)
+    keys = np.ascontiguousarray(pts[:, :, rng.integers(0, N1, size=N2)])       # duplicated keys
+    try:
+        F.set_distance_mode("fmad")
+        idx, d2 = F.search_nn_distance(_t(pts, dev), _t(keys, dev), 3)
+    finally:
+        F.set_distance_mode("strict")
+    ridx, rd2 = oracle.three_nn(pts, keys, fmad=1)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d2.cpu().numpy(), rd2)
+    i32, w = F.three_nn_weights(_t(pts, dev), _t(keys, dev))
+    ridx, rd2 = oracle.three_nn(pts, keys)
+    assert np.array_equal(i32.cpu().numpy().astype(np.int64), ridx)
+    assert np.array_equal(w.cpu().numpy(), oracle.interp_weights(rd2))
+
+
 @pytest.mark.parametrize("C,N2,N1", [(1024, 256, 1024), (512, 5120, 25600), (5, 9, 100)])
 def test_three_interpolate_matches_oracle(F, oracle, dev, C, N2, N1):
     rng = np.random.default_rng(C)

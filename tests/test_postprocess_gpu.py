@@ -57,10 +57,37 @@ def test_batched_collision_check_matches_oracle(dev):
                                   torch.from_numpy(pts).to(dev), K)
     ok, counts = PP.view_non_collision(H, torch.from_numpy(pts).to(dev))
     rok, rcounts = OP.view_non_collision(H.cpu().numpy(), pts)
-    # a point within one fp32 ulp of a box face may fall on either side
-    assert np.abs(counts.cpu().numpy().astype(np.int64) - rcounts).max() <= 1
-    agree = (ok.cpu().numpy() == rok).mean()
-    assert agree >= 0.95, agree
+    counts_np, ok_np = counts.cpu().numpy().astype(np.int64), ok.cpu().numpy()
+    # Every disagreement must be explained by points that sit within a few fp32 ulps of a box
+    # face (the 4x4 . 4xN product is summed in a different order on the two sides): classify the
+    # points in float64 and count, per pose and per counter, those closer than `tol` to any face
+    # that decides the counter -- the two counts may differ by at most that many.
+    g = OP_gripper = dict(hbw=0.057, bl=0.16, fw=0.023, hht=0.012, fl=0.09, margin=0.0)
+    hbs = g["hbw"] - g["fw"]
+    tol = 4e-6
+    Hn = H.cpu().numpy().astype(np.float64)
+    explained = 0
+    for b in range(B):
+        homo = np.concatenate([pts[b].astype(np.float64), np.ones((1, N))], 0)
+        for k in range(K):
+            loc = np.linalg.inv(Hn[b, k]).astype(np.float32).astype(np.float64) @ homo
+            x, y, z = loc[0], loc[1], loc[2]
+            near = lambda v, faces: np.min(np.abs(v[None, :] - np.array(faces)[:, None]), axis=0) < tol
+            inside = lambda v, lo, hi: (v > lo - tol) & (v < hi + tol)
+            region = inside(x, -g["bl"], g["fl"]) & inside(z, -g["hht"], g["hht"]) & inside(y, -g["hbw"], g["hbw"])
+            amb_back = region & (near(x, [g["fl"], -g["bl"], -g["margin"]]) | near(y, [g["hbw"], -g["hbw"]]) |
+                                 near(z, [g["hht"], -g["hht"]]))
+            amb_fing = region & (near(x, [g["fl"], -g["bl"]]) | near(y, [g["hbw"], -g["hbw"], hbs, -hbs]) |
+                                 near(z, [g["hht"], -g["hht"]]))
+            for c, amb in ((0, amb_back), (1, amb_fing)):
+                diff = abs(int(counts_np[b, k, c]) - int(rcounts[b, k, c]))
+                assert diff <= int(amb.sum()), (b, k, c, diff, int(amb.sum()))
+                explained += diff
+            if ok_np[b, k] != rok[b, k]:     # only when a count sits at its threshold, give or take the ambiguous points
+                at_edge = (abs(rcounts[b, k, 0] - 10 * np.sqrt(8)) <= amb_back.sum() + 1) or \
+                          (abs(rcounts[b, k, 1] - 10) <= amb_fing.sum() + 1)
+                assert at_edge, (b, k, counts_np[b, k], rcounts[b, k])
+    assert (ok_np == rok).mean() >= 0.95
     assert counts.cpu().numpy().sum() > 0          # the gripper does touch the table-top cloud
 
 
