@@ -22,6 +22,8 @@
 //   PL = 2: fp32-class f16x2 arithmetic (two fp16 planes, three products, per-tile
 //           power-of-two scales found by a wave-max + one barrier per layer);
 //   PL = 1: one bf16 plane, one product, no scales (S4G_GEMM_BF16, configs[4]).
+#include <stdlib.h>
+
 #include "mlp_common.h"
 
 namespace s4g {
@@ -42,11 +44,13 @@ struct HeadsParams {
   int rps;
 };
 
-constexpr int HD_RING = 2;
-
-template <int PL>
-__global__ __launch_bounds__(512, PL == 2 ? 2 : 4) void mlp_heads_kernel(const HeadsParams p) {
-  constexpr int BM = 64, C = 256, NW = 8, astr = C + 8, aplane = BM * astr;
+// NRBT = 32-position blocks per workgroup: 2 (64 positions; the f16x2 panels fill the LDS) or 4
+// (128 positions, single-plane bf16 only: every W fragment then feeds four MFMAs instead of two,
+// which halves the W bytes streamed per position -- the single product makes that stream three
+// times as heavy per MFMA as in the f16x2 form).
+template <int PL, int HD_RING, int NRBT>
+__global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) {
+  constexpr int BM = 32 * NRBT, C = 256, NW = 8, astr = C + 8, aplane = BM * astr;
   constexpr int FB = PL * 1024;            // bytes of one (32 channels x 16 k) fragment block
   extern __shared__ __attribute__((aligned(16))) float smemf[];
   uint16_t* PA = reinterpret_cast<uint16_t*>(smemf);   // X       [PL][BM][C + 8]
@@ -92,9 +96,10 @@ __global__ __launch_bounds__(512, PL == 2 ? 2 : 4) void mlp_heads_kernel(const H
         ring[d][pl] = *reinterpret_cast<const uint4*>(w + d * FB + pl * 1024 + wf_lane);
   }
 
-  // ---- prologue: X -> panel A (one round trip: 8 x 16 bytes per thread in flight)
-  {
-    const int row = t >> 3, chunk = t & 7;
+  // ---- prologue: X -> panel A (one round trip per 64 rows: 8 x 16 bytes per thread in flight)
+#pragma unroll 1
+  for (int r0 = 0; r0 < BM; r0 += 64) {
+    const int row = r0 + (t >> 3), chunk = t & 7;
     const bool ok = p0 + row < p.P;
     const float* src = p.X + (size_t)(ok ? p0 + row : 0) * p.ldx + chunk * 4;
     float4 ra[8];
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(512, PL == 2 ? 2 : 4) void mlp_heads_kernel(const H
 #define S4G_HD_STRIP(PANEL, NRB, ROWOFF, WCUR, NKS, WNEXT)                                          \
   {                                                                                                 \
     const uint16_t* a_lane = (PANEL) + ((ROWOFF) + li) * astr + 8 * lh;                             \
-    uint4 afn[2][PL];                                                                               \
+    uint4 afn[NRBT][PL];                                                                            \
     _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb) _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) \
       afn[rb][pl] = *reinterpret_cast<const uint4*>(a_lane + pl * aplane + rb * 32 * astr);         \
     const char* wcur_ = (WCUR);                                                                     \
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(512, PL == 2 ? 2 : 4) void mlp_heads_kernel(const H
     _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) {                                            \
       const int d = ks % HD_RING;                                                                   \
       const int ksn = ks + 1 == NKS ? 0 : ks + 1;                                                   \
-      uint4 af[2][PL], bf[PL];                                                                      \
+      uint4 af[NRBT][PL], bf[PL];                                                                   \
       _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb) _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) { \
         af[rb][pl] = afn[rb][pl];                                                                   \
         afn[rb][pl] = *reinterpret_cast<const uint4*>(a_lane + pl * aplane + rb * 32 * astr + ksn * 16); \
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(512, PL == 2 ? 2 : 4) void mlp_heads_kernel(const H
   f32x16 zero16;
 #pragma unroll
   for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
-  f32x16 acc[2];
+  f32x16 acc[NRBT];
   float* epi_s = scr + wv * 64;
 
   // scale | bias of this wave's 32 channels, staged once per phase (read back as float4 per
@@ -230,45 +235,45 @@ __global__ __launch_bounds__(512, PL == 2 ? 2 : 4) void mlp_heads_kernel(const H
       }
     __syncthreads();
   };
-  using two = std::integral_constant<int, 2>;
-  using one = std::integral_constant<int, 1>;
+  using full = std::integral_constant<int, NRBT>;       // all of this workgroup's position blocks
+  using half = std::integral_constant<int, NRBT / 2>;
 
   for (int g = 0; g < 4; ++g) {
-    f32x16 acc1[2];   // heads.1 accumulated over the two halves of its 512 inputs, in units of 1 / w_scale
+    f32x16 acc1[NRBT];   // heads.1 accumulated over the two halves of its 512 inputs, in units of 1 / w_scale
     // ---- heads.0 half 0 -> B;  heads.1 over that half
     stage_sb(0, g * 512 + wv * 32, inv_sa);
-    S4G_HD_STRIP(PA, 2, 0, w0(g, 0), 16, w1(g, 0))
-    panel_epilogue(two{}, 0, wv * 32);
-    S4G_HD_STRIP(PB, 2, 0, w1(g, 0), 16, w0(g, 1))
+    S4G_HD_STRIP(PA, NRBT, 0, w0(g, 0), 16, w1(g, 0))
+    panel_epilogue(full{}, 0, wv * 32);
+    S4G_HD_STRIP(PB, NRBT, 0, w1(g, 0), 16, w0(g, 1))
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < NRBT; ++rb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[rb][r] = acc[rb][r] * inv_sh;
     // ---- heads.0 half 1 -> B;  heads.1 over that half, then its epilogue -> B
     stage_sb(0, g * 512 + 256 + wv * 32, inv_sa);
-    S4G_HD_STRIP(PA, 2, 0, w0(g, 1), 16, w1(g, 1))
-    panel_epilogue(two{}, 0, wv * 32);
-    S4G_HD_STRIP(PB, 2, 0, w1(g, 1), 16, w2(g))
+    S4G_HD_STRIP(PA, NRBT, 0, w0(g, 1), 16, w1(g, 1))
+    panel_epilogue(full{}, 0, wv * 32);
+    S4G_HD_STRIP(PB, NRBT, 0, w1(g, 1), 16, w2(g))
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < NRBT; ++rb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rb][r] = __fmaf_rn(acc[rb][r], inv_sh, acc1[rb][r]);
     stage_sb(1, g * 256 + wv * 32, 1.f);
-    panel_epilogue(two{}, 0, wv * 32);
+    panel_epilogue(full{}, 0, wv * 32);
     // ---- heads.2 -> B
     stage_sb(2, g * 256 + wv * 32, inv_sh);
-    S4G_HD_STRIP(PB, 2, 0, w2(g), 16, w3(g))
-    panel_epilogue(two{}, 0, wv * 32);
-    // ---- heads.3 (128 wide): wave = (32-position block wv >> 2) x (32-channel block wv & 3) -> B
+    S4G_HD_STRIP(PB, NRBT, 0, w2(g), 16, w3(g))
+    panel_epilogue(full{}, 0, wv * 32);
+    // ---- heads.3 (128 wide): wave = (half of the position blocks, wv >> 2) x (32-channel block wv & 3) -> B
     {
-      const int rbw = wv >> 2, cg = wv & 3;
+      const int row3 = (wv >> 2) * (BM / 2), cg = wv & 3;
       stage_sb(3, g * 128 + cg * 32, inv_sh);
-      const char* after = wv < 2 ? wl(g) : w0(g < 3 ? g + 1 : g, 0);
-      S4G_HD_STRIP(PB, 1, rbw * 32, w3(g), 16, after)
-      panel_epilogue(one{}, rbw * 32, cg * 32);
+      const char* after = wv < NRBT ? wl(g) : w0(g < 3 ? g + 1 : g, 0);
+      S4G_HD_STRIP(PB, NRBT / 2, row3, w3(g), 16, after)
+      panel_epilogue(half{}, row3, cg * 32);
     }
-    // ---- logits: waves 0 and 1, one 32-position block each; (B, c, N) channel-first stores
-    if (wv < 2) {
+    // ---- logits: waves 0 .. NRBT - 1, one 32-position block each; (B, c, N) channel-first stores
+    if (wv < NRBT) {
       stage_sb(4, g * 32, inv_sh);
       S4G_HD_STRIP(PB, 1, wv * 32, wl(g), 8, w0(g < 3 ? g + 1 : g, 0))
       const int row = p0 + wv * 32 + li;
@@ -295,20 +300,22 @@ __global__ __launch_bounds__(512, PL == 2 ? 2 : 4) void mlp_heads_kernel(const H
 #undef S4G_HD_TERM
 }
 
-template <int PL>
+template <int PL, int HD_RING, int NRBT>
 static int launch_heads(const HeadsParams& p, hipStream_t st) {
-  constexpr size_t lds = sizeof(uint16_t) * 2 * PL * 64 * (256 + 8) + sizeof(float) * (8 * 64 + 16);
+  constexpr int BM = 32 * NRBT;
+  constexpr size_t lds = sizeof(uint16_t) * 2 * PL * BM * (256 + 8) + sizeof(float) * (8 * 64 + 16);
+  static_assert(lds <= 160 * 1024, "one workgroup's panels must fit a CU's LDS");
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
   static bool done[64] = {};
   if (dev < 0 || dev >= 64 || !done[dev]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_heads_kernel<PL>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_heads_kernel<PL, HD_RING, NRBT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     if (dev >= 0 && dev < 64) done[dev] = true;
   }
-  hipLaunchKernelGGL((mlp_heads_kernel<PL>), dim3((unsigned)((p.P + 63) / 64)), dim3(512), lds, st, p);
+  hipLaunchKernelGGL((mlp_heads_kernel<PL, HD_RING, NRBT>), dim3((unsigned)((p.P + BM - 1) / BM)), dim3(512), lds, st, p);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }
@@ -344,5 +351,11 @@ extern "C" int s4g_heads_chain_f32(const s4g_heads_desc_t* d, s4g_stream_t strea
   if (d->precision == S4G_GEMM_F16X2 && !d->a_amax && !(d->a_amax_floor > 0.f)) return S4G_EINVAL;
   if (d->P == 0) return S4G_OK;
   hipStream_t st = (hipStream_t)stream;
-  return d->precision == S4G_GEMM_F16X2 ? launch_heads<2>(p, st) : launch_heads<1>(p, st);
+  // W fragment prefetch depth in 16-deep steps (S4G_HEADS_RING=2|4: tuning knob)
+  static const int ring = [] { const char* e = getenv("S4G_HEADS_RING"); return e ? atoi(e) : 4; }();
+  if (d->precision == S4G_GEMM_F16X2) return ring == 2 ? launch_heads<2, 2, 2>(p, st) : launch_heads<2, 4, 2>(p, st);
+  // single-plane bf16: 128 positions per workgroup (S4G_HEADS_BM=64: the 64-position form)
+  static const int bm = [] { const char* e = getenv("S4G_HEADS_BM"); return e ? atoi(e) : 128; }();
+  if (bm == 64) return ring == 2 ? launch_heads<1, 2, 2>(p, st) : launch_heads<1, 4, 2>(p, st);
+  return ring == 2 ? launch_heads<1, 2, 4>(p, st) : launch_heads<1, 4, 4>(p, st);
 }

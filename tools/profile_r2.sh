@@ -11,7 +11,7 @@ rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 CFG4="--points 51200 --batch 32 --precision bf16"
 NOPIPE="--steps 2 --warmup 1 --no-pipeline --no-extras --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d $O/stats_default -o run -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_default_profiled.json 2> $O/err_default.txt
+rocprofv3 --kernel-trace --stats -d $O/stats_default -o run -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_default_profiled.json 2> $O/err_default.txt
 rocprofv3 --kernel-trace --stats -d $O/stats_cfg4 -o run -- python3 $R/bench.py $CFG4 --steps 6 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_cfg4_profiled.json 2> $O/err_cfg4.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_default_$c -- python3 $R/bench.py $NOPIPE > /dev/null 2>&1
