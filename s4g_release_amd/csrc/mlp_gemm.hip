@@ -1230,7 +1230,12 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
 // ---------------------------------------------------------------------------
 // W fragment prefetch depth of the chain kernel: 2 measured equal to 4 (+0.5 %) with 32 registers
 // less -- no spills in the deep-first-layer and eight-wave forms
-constexpr int GF_RING = 2;
+constexpr int GF_RING_F16X2 = 2;
+// ring depth of the single-plane (bf16) form: 4 measured no faster than 2 (configs[4]: sa0
+// 2.67 vs 2.57 ms), so the W stream's latency is not what parks its waves
+#ifndef S4G_CHAIN_RING1
+#define S4G_CHAIN_RING1 2
+#endif
 
 // PL = planes per operand: 2 = the f16x2 split above (three fp16 products per step, power-of-two
 // scales), 1 = ONE bf16 plane and one product (S4G_GEMM_BF16, the reduced-precision roofline
@@ -1240,6 +1245,7 @@ template <int LOADER, int EPI2, int RW, int KC, int PL>
 __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) void mlp_chain_kernel(const GemmParams p) {
   // RW = 2: 128 positions, 128-wide layers, 4 waves; RW = 1: 64 positions, 256-wide layers, 4 waves;
   // RW = 8: 64 positions, 512-wide layers, EIGHT waves (one workgroup per CU: its 133 KB panel)
+  constexpr int GF_RING = PL == 2 ? GF_RING_F16X2 : S4G_CHAIN_RING1;
   constexpr int CW = RW == 8 ? 8 : 4 / RW, RWN = RW == 8 ? 1 : RW;
   constexpr int BM = 64 * RWN, K = 64 * CW, NW = RWN * CW;
   constexpr int RS = 8 * NW, RPT = BM / RS;   // loader: 8 lanes per row, RS rows per pass
