@@ -114,6 +114,21 @@ struct GemmParams {
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// scene b and centroid m of grouped row pos = p0 + r (rows are [scene][centroid][neighbour]):
+// ONE division per workgroup (p0 is uniform) instead of two per row -- the rows of a tile can only
+// step over a scene boundary a few times, and K is a power of two wherever the fast path groups
+__device__ __forceinline__ void gather_row_bm(int M, int K, int p0, int r, int& b, int& m) {
+  const int MK = M * K;
+  const int b0 = __builtin_amdgcn_readfirstlane(p0 / MK);
+  int rem = p0 - b0 * MK + r;
+  b = b0;
+  while (rem >= MK) {
+    rem -= MK;
+    ++b;
+  }
+  m = (K & (K - 1)) == 0 ? rem >> (31 - __clz(K)) : rem / K;
+}
+
 template <int LOADER, int RPT = 4, int RS = 32>
 struct ALoader {
   // per-thread: RPT rows (t>>3)+RS*s, one 4-float chunk (t&7)
@@ -136,9 +151,8 @@ struct ALoader {
       if constexpr (LOADER == LOAD_PLAIN) {
         src0[s] = p.A + (size_t)pp * p.lda + p.a_coff + g * p.a_gcol;
       } else if constexpr (LOADER == LOAD_GATHER_MLP1) {
-        const int MK = p.M * p.K;
-        const int b = pp / MK;
-        const int m = (pp - b * MK) / p.K;
+        int b = 0, m = 0;
+        if (ok[s]) gather_row_bm(p.M, p.K, p0, r, b, m);
         const int j = p.gidx[pp];
         const float* x = p.xyz + (size_t)b * 3 * p.N;
         const float* c = p.ctr + (size_t)b * 3 * p.M;
@@ -148,9 +162,8 @@ struct ALoader {
       } else if constexpr (LOADER == LOAD_GATHER_ADD) {
         // first SA layer applied to the level's features BEFORE the grouping (it is linear):
         // A[p][k] = relu(F[b*N + j][k] + w1[k] . (xyz_j - ctr_m, 1))
-        const int MK = p.M * p.K;
-        const int b = pp / MK;
-        const int m = (pp - b * MK) / p.K;
+        int b = 0, m = 0;
+        if (ok[s]) gather_row_bm(p.M, p.K, p0, r, b, m);
         const int j = p.gidx[pp];
         src0[s] = p.feat + ((size_t)b * p.N + j) * p.Cf;
         const float* x = p.xyz + (size_t)b * 3 * p.N;
@@ -159,9 +172,8 @@ struct ALoader {
         rel[s][1] = __fsub_rn(x[p.N + j], c[p.M + m]);
         rel[s][2] = __fsub_rn(x[2 * p.N + j], c[2 * p.M + m]);
       } else if constexpr (LOADER == LOAD_GATHER) {
-        const int MK = p.M * p.K;
-        const int b = pp / MK;
-        const int m = (pp - b * MK) / p.K;
+        int b = 0, m = 0;
+        if (ok[s]) gather_row_bm(p.M, p.K, p0, r, b, m);
         const int j = p.gidx[pp];
         src0[s] = p.feat ? p.feat + ((size_t)b * p.N + j) * p.Cf : nullptr;
         if ((t & 7) == ((p.Cf & 31) >> 2)) {   // the lane whose 4-float chunk holds the xyz columns
@@ -1375,7 +1387,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
 
   // one 128-deep strip: 8 steps of 12 MFMAs; W fragments through the ring, refilled RING
   // steps ahead from this strip (wcur) or the next one (wnext)
-#define S4G_F2_STRIP(SWAPPED, wcur, cbs_cur, wnext, cbs_next)                                                             \
+#define S4G_F2_STRIP(SWAPPED, ZFIRST, wcur, cbs_cur, wnext, cbs_next)                                                     \
   _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                  \
     const int d = ks % GF_RING;                                                                        \
     const int ksn = ks + 1 == KS ? 0 : ks + 1;                                                         \
@@ -1396,10 +1408,12 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
             src + ((size_t)cb * cbs + (size_t)(kk * PL + pl) * 1024) + wf_lane);                       \
     }                                                                                                  \
     if constexpr (PL == 2) {                                                                           \
-      S4G_F2_TERM(SWAPPED, 0, 1)                                                                       \
-      S4G_F2_TERM(SWAPPED, 1, 0)                                                                       \
+      S4G_F2_TERM(SWAPPED, 0, 1, (ZFIRST) && ks == 0)                                                  \
+      S4G_F2_TERM(SWAPPED, 1, 0, false)                                                                \
+      S4G_F2_TERM(SWAPPED, 0, 0, false)                                                                \
+    } else {                                                                                           \
+      S4G_F2_TERM(SWAPPED, 0, 0, (ZFIRST) && ks == 0)                                                  \
     }                                                                                                  \
-    S4G_F2_TERM(SWAPPED, 0, 0)                                                                         \
     _Pragma("unroll") for (int q = 0; q < 2 * PL; ++q) {                                               \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                               \
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
@@ -1409,18 +1423,23 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
     if constexpr (PL == 2) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                          \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
   }
-#define S4G_F2_TERM(SWAPPED, PA, PB)                                                                   \
+// Z: start from a literal zero accumulator (the MFMA's C operand as an inline constant: no
+// register zeroing); only ever true in a fully unrolled first step
+#define S4G_F2_TERM(SWAPPED, PA, PB, Z)                                                                \
   if constexpr (SWAPPED) {                                                                             \
-    acc[0][0] = chain_mfma<PL>(bf[0][PB], af[0][PA], acc[0][0]);                                       \
-    acc[0][1] = chain_mfma<PL>(bf[0][PB], af[1][PA], acc[0][1]);                                       \
-    acc[1][0] = chain_mfma<PL>(bf[1][PB], af[0][PA], acc[1][0]);                                       \
-    acc[1][1] = chain_mfma<PL>(bf[1][PB], af[1][PA], acc[1][1]);                                       \
+    acc[0][0] = chain_mfma<PL>(bf[0][PB], af[0][PA], (Z) ? zero16 : acc[0][0]);                        \
+    acc[0][1] = chain_mfma<PL>(bf[0][PB], af[1][PA], (Z) ? zero16 : acc[0][1]);                        \
+    acc[1][0] = chain_mfma<PL>(bf[1][PB], af[0][PA], (Z) ? zero16 : acc[1][0]);                        \
+    acc[1][1] = chain_mfma<PL>(bf[1][PB], af[1][PA], (Z) ? zero16 : acc[1][1]);                        \
   } else {                                                                                             \
-    acc[0][0] = chain_mfma<PL>(af[0][PA], bf[0][PB], acc[0][0]);                                       \
-    acc[0][1] = chain_mfma<PL>(af[0][PA], bf[1][PB], acc[0][1]);                                       \
-    acc[1][0] = chain_mfma<PL>(af[1][PA], bf[0][PB], acc[1][0]);                                       \
-    acc[1][1] = chain_mfma<PL>(af[1][PA], bf[1][PB], acc[1][1]);                                       \
+    acc[0][0] = chain_mfma<PL>(af[0][PA], bf[0][PB], (Z) ? zero16 : acc[0][0]);                        \
+    acc[0][1] = chain_mfma<PL>(af[0][PA], bf[1][PB], (Z) ? zero16 : acc[0][1]);                        \
+    acc[1][0] = chain_mfma<PL>(af[1][PA], bf[0][PB], (Z) ? zero16 : acc[1][0]);                        \
+    acc[1][1] = chain_mfma<PL>(af[1][PA], bf[1][PB], (Z) ? zero16 : acc[1][1]);                        \
   }
+  f32x16 zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 
   // ---- panel phases: H = relu(bn(W A)), C channels = one strip, operands swapped
   const char* wcur = w1;
@@ -1431,7 +1450,6 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
   const int npanel = tri ? 2 : 1;
   for (int ph = 0; ph < npanel; ++ph) {
   const char* wnxt = ph + 1 < npanel ? wmid : (active0 ? w2 : wcur);
-  zero_acc();
   prime_a();
   {
     const int n = wc * 64 + lane;   // channel whose scale / bias this lane stages for its wave
@@ -1440,6 +1458,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
   }
   if (KC > 1 && ph == 0) {
     // layer 1: every K-column chunk of the loader's rows through the same accumulators
+    zero_acc();
     for (int kc = 0; kc < kchunks; ++kc) {
       if (kc > 0) {
         __syncthreads();      // everybody is done reading the previous chunk's panel
@@ -1451,10 +1470,10 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
       const bool lastc = kc + 1 == kchunks;
       const char* wn1 = lastc ? wnxt : wc1 + cb_stride;
       const size_t cbsn = lastc ? cb_stride : cbs1;
-      S4G_F2_STRIP(true, wc1, cbs1, wn1, cbsn)
+      S4G_F2_STRIP(true, false, wc1, cbs1, wn1, cbsn)
     }
   } else {
-    S4G_F2_STRIP(true, wcur, cb_stride, wnxt, cb_stride)
+    S4G_F2_STRIP(true, true, wcur, cb_stride, wnxt, cb_stride)
   }
   float tmax = 0.f;
 #pragma unroll
@@ -1523,7 +1542,6 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
   GemmParams q = p;
   q.Cout = CoutF;
   q.relu = tri ? p.relu3 : p.relu2;
-  zero_acc();
   prime_a();
   const char* wstrip = w2;
   const float* __restrict__ bg2 = bgF;
@@ -1533,7 +1551,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
     const float e_sc = PL == 2 ? inv_sh * scF[n] : 1.f;
     const float e_bias = bg2[n];
     const char* wnext = ((strip + 1) * CW + wc_u) * 64 < CoutF ? wstrip + strip_stride : wstrip;
-    S4G_F2_STRIP(EPI2 == EPI_STORE, wstrip, cb_stride, wnext, cb_stride)
+    S4G_F2_STRIP(EPI2 == EPI_STORE, true, wstrip, cb_stride, wnext, cb_stride)
     const int n0 = (strip * CW + wc) * 64;
     float omax = 0.f;
     if constexpr (EPI2 == EPI_STORE) {
@@ -1569,6 +1587,30 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
         const uint32_t wm = wave_max_u32(__float_as_uint(omax));
         if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave + strip, p0, p_hi, p.rps);
       }
+    } else if (q.relu && p.K == 64) {
+      // max over the 64 neighbours FIRST, on the raw accumulators (the scales are positive powers
+      // of two, so max commutes with them exactly), then one scale + bias + ReLU per channel:
+      // 1 instead of 4 vector instructions per accumulator element
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const float sc = __shfl(e_sc, cb * 32 + li);
+        const float bias = __shfl(e_bias, cb * 32 + li);
+        float m = acc[0][cb][0];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[rb][cb][r]);
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const float v = fmaxf(m * sc + bias, 0.f);
+        omax = fmaxf(omax, v);
+        const int nn = n0 + cb * 32 + li;
+        if (nn < CoutF && lh == 0 && p0 + wr * 64 < p.P)
+          p.out[(size_t)((p0 + wr * 64) >> 6) * p.ldc + p.c_coff + nn] = v;
+      }
+      if (PL == 2 && p.out_amax) {
+        const uint32_t wm = wave_max_u32(__float_as_uint(omax));
+        if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave + strip, p0, p_hi, p.rps);
+      }
     } else {
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
@@ -1593,7 +1635,6 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
       }
       gemm_epilogue<EPI_MAX, 2>(q, acc, bg2, g, p0, n0, wave, wr, 0, li, lh, smemf);
     }
-    zero_acc();
   }
 #undef S4G_F2_STRIP
 #undef S4G_F2_TERM
