@@ -1104,10 +1104,8 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
 #define S4G_FPS_PRUNED(T, P)                                                                       \
   if (N <= (int64_t)T * P) {                                                                       \
     const size_t lds = sizeof(uint16_t) * T * P;                                                   \
-    static const hipError_t attr = hipFuncSetAttribute(                                            \
-        reinterpret_cast<const void*>(&fps_pruned_kernel<T, P, FMAD, IdxT>),                       \
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
-    if (attr != hipSuccess) return (int)attr;                                                      \
+    static LdsAttrCache lds_cache;                                                                 \
+    if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(&fps_pruned_kernel<T, P, FMAD, IdxT>), lds, lds_cache)) return rc;  \
     constexpr int G = (T / 64) * P;                                                                \
     hipLaunchKernelGGL(fps_group_box_kernel, dim3((G + 3) / 4, (unsigned)B), dim3(256), 0, stream, \
                        xyz, w.val_out, (int)N, G, w.gbox);                                         \

@@ -945,10 +945,8 @@ static int launch_gemm_f16x2_cfg(GemmParams p, int groups, hipStream_t st) {
   size_t lds = sizeof(uint16_t) * PL * (GM_BM + BN) * GH_STR;
   const size_t epi = sizeof(float) * 4 * 32 * (32 * NCB + 4);   // staged epilogue stores
   if (lds < epi) lds = epi;
-  static const hipError_t attr = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&mlp_gemm_f16x2_kernel<LOADER, EPI, NCB, PL>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (attr != hipSuccess) return (int)attr;
+  static LdsAttrCache lds_cache;
+  if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(&mlp_gemm_f16x2_kernel<LOADER, EPI, NCB, PL>), lds, lds_cache)) return rc;
   const dim3 grid((unsigned)(p.mtiles * p.ntiles), (unsigned)groups);
   hipLaunchKernelGGL((mlp_gemm_f16x2_kernel<LOADER, EPI, NCB, PL>), grid, dim3(256), lds, st, p);
   S4G_LAUNCH_CHECK();
@@ -1646,10 +1644,8 @@ static int launch_mlp_chain(const GemmParams& p, int groups, hipStream_t st) {
   constexpr int BM = 64 * RWN, K = 64 * CW, NW = RWN * CW;
   constexpr size_t lds = sizeof(uint16_t) * PL * BM * (size_t)(K + 8) + sizeof(float) * (NW * 128 + 16);
   static_assert(lds <= (RW == 8 ? 160 : 80) * 1024, "two workgroups per CU (one for the 8-wave form)");
-  static const hipError_t attr = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&mlp_chain_kernel<LOADER, EPI2, RW, KC, PL>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (attr != hipSuccess) return (int)attr;
+  static LdsAttrCache lds_cache;
+  if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(&mlp_chain_kernel<LOADER, EPI2, RW, KC, PL>), lds, lds_cache)) return rc;
   const dim3 grid((unsigned)((p.P + BM - 1) / BM), (unsigned)groups);
   hipLaunchKernelGGL((mlp_chain_kernel<LOADER, EPI2, RW, KC, PL>), grid, dim3(64 * NW), lds, st, p);
   S4G_LAUNCH_CHECK();
@@ -1661,10 +1657,8 @@ static int launch_gemm_f16x2_resident(const GemmParams& p, int groups, hipStream
   constexpr int BM = 64 * RW;
   constexpr size_t lds = sizeof(uint16_t) * 2 * BM * (size_t)(KT + 8) + sizeof(float) * 4 * 128;
   static_assert(lds <= 80 * 1024, "two workgroups per CU");
-  static const hipError_t attr = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&mlp_gemm_f16x2_resident_kernel<LOADER, EPI, RW, KT>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (attr != hipSuccess) return (int)attr;
+  static LdsAttrCache lds_cache;
+  if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(&mlp_gemm_f16x2_resident_kernel<LOADER, EPI, RW, KT>), lds, lds_cache)) return rc;
   const dim3 grid((unsigned)((p.P + BM - 1) / BM), (unsigned)groups);
   hipLaunchKernelGGL((mlp_gemm_f16x2_resident_kernel<LOADER, EPI, RW, KT>), grid, dim3(256), lds, st, p);
   S4G_LAUNCH_CHECK();
@@ -1710,10 +1704,8 @@ static int launch_gemm_bf16x3_cfg(const GemmParams& p, int groups, hipStream_t s
   const size_t epi = sizeof(float) * 4 * 32 * 68;   // staged epilogue stores (either layout)
   if (lds < epi) lds = epi;
   // one-time, thread-safe (C++11 magic static): allow > 64 KB of dynamic LDS
-  static const hipError_t attr = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&mlp_gemm_bf16x3_kernel<LOADER, EPI, NS, WAVES>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (attr != hipSuccess) return (int)attr;
+  static LdsAttrCache lds_cache;
+  if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(&mlp_gemm_bf16x3_kernel<LOADER, EPI, NS, WAVES>), lds, lds_cache)) return rc;
   const dim3 grid((unsigned)(p.mtiles * p.ntiles), (unsigned)groups);
   hipLaunchKernelGGL((mlp_gemm_bf16x3_kernel<LOADER, EPI, NS, WAVES>), grid, dim3(64 * WAVES), lds,
                      st, p);
@@ -1732,10 +1724,8 @@ static int launch_gemm_bf16x3(const GemmParams& p, int groups, hipStream_t st) {
 template <int LOADER, int EPI>
 static int launch_gemm(const GemmParams& p, int groups, hipStream_t st) {
   const size_t lds = sizeof(float) * 2 * (GM_BM + GM_BN) * GM_LDS;
-  static const hipError_t attr = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&mlp_gemm_kernel<LOADER, EPI>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (attr != hipSuccess) return (int)attr;
+  static LdsAttrCache lds_cache;
+  if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(&mlp_gemm_kernel<LOADER, EPI>), lds, lds_cache)) return rc;
   const dim3 grid((unsigned)(p.mtiles * p.ntiles), (unsigned)groups);
   hipLaunchKernelGGL((mlp_gemm_kernel<LOADER, EPI>), grid, dim3(GM_THREADS), lds, st, p);
   S4G_LAUNCH_CHECK();

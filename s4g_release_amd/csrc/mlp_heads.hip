@@ -305,16 +305,8 @@ static int launch_heads(const HeadsParams& p, hipStream_t st) {
   constexpr int BM = 32 * NRBT;
   constexpr size_t lds = sizeof(uint16_t) * 2 * PL * BM * (256 + 8) + sizeof(float) * (8 * 64 + 16);
   static_assert(lds <= 160 * 1024, "one workgroup's panels must fit a CU's LDS");
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return (int)e;
-  static bool done[64] = {};
-  if (dev < 0 || dev >= 64 || !done[dev]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_heads_kernel<PL, HD_RING, NRBT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    if (dev >= 0 && dev < 64) done[dev] = true;
-  }
+  static LdsAttrCache lds_cache;
+  if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(&mlp_heads_kernel<PL, HD_RING, NRBT>), lds, lds_cache)) return rc;
   hipLaunchKernelGGL((mlp_heads_kernel<PL, HD_RING, NRBT>), dim3((unsigned)((p.P + BM - 1) / BM)), dim3(512), lds, st, p);
   S4G_LAUNCH_CHECK();
   return S4G_OK;

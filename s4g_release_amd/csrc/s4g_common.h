@@ -14,7 +14,27 @@
     if (e_ != hipSuccess) return (int)e_;         \
   } while (0)
 
+#include <atomic>
+
 namespace s4g {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE setting: one slot per (call site,
+// device), set on the first launch there and again whenever a launch needs more than the slot
+// holds; a failure is returned to the caller and never memoised.
+struct LdsAttrCache {
+  std::atomic<int> bytes[64];
+};
+inline int allow_dynamic_lds(const void* func, size_t lds_bytes, LdsAttrCache& cache) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  const bool slot = dev >= 0 && dev < 64;
+  if (slot && cache.bytes[dev].load(std::memory_order_relaxed) >= (int)lds_bytes) return 0;
+  e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return (int)e;
+  if (slot) cache.bytes[dev].store((int)lds_bytes, std::memory_order_relaxed);
+  return 0;
+}
 
 // Squared distance with the arithmetic contract of include/s4g_ops.h.
 // The translation units are compiled with -ffp-contract=off, and the
