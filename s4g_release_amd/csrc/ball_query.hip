@@ -410,177 +410,6 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void bq_grid_query_kernel(
   }
 }
 
-// ---------------------------------------------------------------- GRID4 path
-// Same grid, same exactness argument and the same index-bitmap selection as the GRID query
-// above, rebuilt around the instruction count (the per-centre kernel is issue-bound: ~800 wave
-// instructions per centre, profiles/r01_pmc_counters.md):
-//   * the nine (dy, dz) rows are tested by FULL-WIDTH passes (lane = record of the row), all
-//     nine 16-byte record loads in flight before the first distance test; rows longer than 64
-//     records and the second piece of a row that wraps around the torus take a generic loop
-//     that is entered for ~6 % of the centres;
-//   * wave-uniform values travel by v_readlane (SGPRs), not by LDS permutes;
-//   * a lane owns 4 * NB128 CONSECUTIVE bitmap words stored as NB128 conflict-free 16-byte
-//     chunks ([chunk][lane][4]): the read-back is NB128 ds_read_b128, the clean-up NB128
-//     ds_write_b128;
-//   * eight centres per wave share the set-up, their coordinates and cells sit in lanes 0..7.
-
-template <int NB128>
-__device__ __forceinline__ int bq4_phys_word(int lw) {   // logical bitmap word -> LDS word
-  constexpr int LW = 4 * NB128;                          // logical words per lane (16 or 32)
-  return (((lw / 4) % NB128) << 8) | ((lw / LW) << 2) | (lw & 3);
-}
-
-template <bool FMAD, typename IdxT, bool GROUP, int NB128, int BQ4_CPW>
-__global__ __launch_bounds__(256) void bq_grid4_query_kernel(
-    const float* __restrict__ xyz, const float* __restrict__ ctr, int N, int M, float r2,
-    float inv_h, int K, GridWs ws, IdxT* __restrict__ idx, IdxT* __restrict__ cnt_out,
-    float* __restrict__ grouped) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  constexpr int BMW = NB128 * 256;   // bitmap words per wave: 32 768 (NB128 = 4) or 65 536 points
-  const int b = blockIdx.y;
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int Kp = (K + 3) & ~3;
-  uint32_t* __restrict__ bm = lds + wave * (BMW + Kp);
-  int* __restrict__ row = (int*)(bm + BMW);
-#pragma unroll
-  for (int i = 0; i < NB128; ++i)
-    *reinterpret_cast<uint4*>(bm + i * 256 + lane * 4) = make_uint4(0u, 0u, 0u, 0u);
-  const int m0 = (blockIdx.x * 4 + wave) * BQ4_CPW;
-  if (m0 >= M) return;
-  const int nc = min(BQ4_CPW, M - m0);
-
-  const float* __restrict__ px = xyz + (size_t)b * 3 * N;
-  const float* __restrict__ py = px + N;
-  const float* __restrict__ pz = py + N;
-  const float* __restrict__ c = ctr + (size_t)b * 3 * M;
-  const float ox = px[0], oy = py[0], oz = pz[0];
-  const bool scene_ok = ws.flags[b] == 0;
-  const float4* __restrict__ rec = ws.sorted + (size_t)b * GR_RANGES * N;
-  const int* __restrict__ starts_b = ws.starts + (size_t)b * GR_RANGES * GR_START_STRIDE;
-
-  // lane l holds centre m0 + l
-  const int ml = m0 + (lane < nc ? lane : 0);
-  const float lcx = c[ml], lcy = c[M + ml], lcz = c[2 * M + ml];
-  const int lix = grid_coord(lcx, ox, inv_h), liy = grid_coord(lcy, oy, inv_h),
-            liz = grid_coord(lcz, oz, inv_h);
-  const int lexact = (scene_ok && grid_coord_ok(lcx, ox, inv_h) && grid_coord_ok(lcy, oy, inv_h) &&
-                      grid_coord_ok(lcz, oz, inv_h)) ? 1 : 0;
-  // lanes 0..8: row (dy, dz), first piece; lanes 9..17: the same rows' wrapped second piece
-  const int rl = lane < 9 ? lane : (lane < 18 ? lane - 9 : 0);
-  const int rdz = rl / 3 - 1, rdy = rl % 3 - 1;
-  const size_t MK = (size_t)M * K;
-
-  for (int ci = 0; ci < nc; ++ci) {
-    const int m = m0 + ci;
-    const float cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lcx), ci));
-    const float cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lcy), ci));
-    const float cz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lcz), ci));
-    IdxT* __restrict__ out_row = idx + ((size_t)b * M + m) * K;
-    IdxT* __restrict__ out_cnt = cnt_out + (size_t)b * M + m;
-    bool in_lds = false;
-    if (!__builtin_amdgcn_readlane(lexact, ci)) {
-      // out of the grid's exactness range: index-order scan, straight to global
-      bq_scan_centroid<FMAD, IdxT>(px, py, pz, N, cx, cy, cz, r2, K, lane, out_row, out_cnt);
-      if constexpr (GROUP) __threadfence_block();  // the row is re-read below by other lanes
-    } else {
-      in_lds = true;
-      const int icx = __builtin_amdgcn_readlane(lix, ci), icy = __builtin_amdgcn_readlane(liy, ci),
-                icz = __builtin_amdgcn_readlane(liz, ci);
-      const int x0 = (icx - 1) & 31;          // wave-uniform
-      const bool wrap = x0 > GR_DIM - 3;      // the 3 cells wrap around the row
-      int beg = 0, len = 0;
-      if (lane < (wrap ? 18 : 9)) {
-        const int zz = (icz + rdz) & 31, yy = (icy + rdy) & 31;
-        const int* __restrict__ st = starts_b + grid_range(yy, zz) * GR_START_STRIDE + grid_local_row(yy, zz);
-        if (lane < 9) {
-          beg = st[x0];
-          len = st[wrap ? GR_DIM : x0 + 3] - beg;
-        } else {
-          beg = st[0];
-          len = st[(x0 + 3) & 31] - beg;
-        }
-      }
-      auto test = [&](const float4 p) {
-        if (dist2<FMAD>(cx, cy, cz, p.x, p.y, p.z) < r2) {
-          const int pi = __float_as_int(p.w);
-          atomicOr(&bm[bq4_phys_word<NB128>(pi >> 5)], 1u << (pi & 31));
-        }
-      };
-      // nine full-width passes, every load issued before the first test
-      float4 p[9];
-      int rbeg[9], rlen[9];
-#pragma unroll
-      for (int r = 0; r < 9; ++r) {
-        rbeg[r] = __builtin_amdgcn_readlane(beg, r);
-        rlen[r] = __builtin_amdgcn_readlane(len, r);
-        if (lane < rlen[r]) p[r] = rec[rbeg[r] + lane];
-      }
-#pragma unroll
-      for (int r = 0; r < 9; ++r)
-        if (lane < rlen[r]) test(p[r]);
-      // leftovers: rows longer than 64 records, wrapped second pieces
-      uint64_t more = __ballot(lane < 18 && len > (lane < 9 ? 64 : 0));
-      while (more) {
-        const int r = __ffsll((unsigned long long)more) - 1;
-        more &= more - 1;
-        const int rb = __builtin_amdgcn_readlane(beg, r), rn = __builtin_amdgcn_readlane(len, r);
-        for (int j = (r < 9 ? 64 : 0) + lane; j < rn; j += 64) test(rec[rb + j]);
-      }
-      // read the bitmap back in index order: lane l owns logical words [LW l, LW l + LW)
-      constexpr int LW = 4 * NB128;
-      int local = 0;
-      uint32_t nz = 0;
-#pragma unroll
-      for (int i = 0; i < NB128; ++i) {
-        const uint4 v = *reinterpret_cast<const uint4*>(bm + i * 256 + lane * 4);
-        const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          local += __popc(wv[j]);
-          nz |= (wv[j] != 0u ? 1u : 0u) << (4 * i + j);
-        }
-      }
-      const int incl = (int)wave_inclusive_scan_u32((uint32_t)local);
-      const int total = __builtin_amdgcn_readlane(incl, 63);
-      int pos = incl - local;
-      while (nz) {   // only the touched words
-        const int w = __ffs(nz) - 1;
-        nz &= nz - 1;
-        uint32_t bits = bm[((w >> 2) << 8) | (lane << 2) | (w & 3)];
-        while (bits && pos < K) {
-          const int bit = __ffs(bits) - 1;
-          row[pos++] = (lane * LW + w) * 32 + bit;
-          bits &= bits - 1;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < NB128; ++i)   // clean for the next centre (own words only)
-        *reinterpret_cast<uint4*>(bm + i * 256 + lane * 4) = make_uint4(0u, 0u, 0u, 0u);
-      const int cnt = total < K ? total : K;
-      const int first = cnt > 0 ? row[0] : 0;
-      for (int k = lane; k < K; k += 64) {
-        const int v = k < cnt ? row[k] : first;
-        out_row[k] = (IdxT)v;
-        if constexpr (GROUP) row[k] = v;
-      }
-      if (lane == 0) *out_cnt = (IdxT)cnt;
-    }
-    if constexpr (GROUP) {
-      // group_points(xyz, index) for this centre: out[b][c][m][k] = xyz[b][c][idx]
-      float* __restrict__ gx = grouped + (size_t)b * 3 * MK + (size_t)m * K;
-      const float4* __restrict__ p4 = ws.xyz4 + (size_t)b * N;
-      for (int k = lane; k < K; k += 64) {
-        const int v = in_lds ? row[k] : (int)out_row[k];
-        const float4 q = p4[v];   // one 16-byte gather instead of three 4-byte ones
-        gx[k] = q.x;
-        gx[MK + k] = q.y;
-        gx[2 * MK + k] = q.z;
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------- CELL path
 // Cell-centric query: the centres are binned into the same grid (build workgroups
 // 8..15) and ONE WORKGROUP TAKES ONE NON-EMPTY X-QUAD OF CENTRE CELLS (4 x-adjacent
@@ -904,12 +733,11 @@ int launch_grid_build_queries(const float* xyz, const float* ctr, int64_t B, int
   return S4G_OK;
 }
 
-enum { BQ_AUTO = 0, BQ_SCAN = 1, BQ_GRID = 2, BQ_CELL = 3, BQ_GRID4 = 4 };
+enum { BQ_AUTO = 0, BQ_SCAN = 1, BQ_GRID = 2, BQ_CELL = 3 };
 
 static int bq_mode() {  // S4G_BQ_MODE=scan|grid|cell|auto (tuning / test knob, read per call)
   const char* e = getenv("S4G_BQ_MODE");
   if (e && e[0] == 's') return BQ_SCAN;
-  if (e && e[0] == 'g' && e[1] == 'r' && e[2] == 'i' && e[3] == 'd' && e[4] == '4') return BQ_GRID4;
   if (e && e[0] == 'g') return BQ_GRID;
   if (e && e[0] == 'c') return BQ_CELL;
   return BQ_AUTO;
@@ -919,7 +747,7 @@ static bool bq_use_grid(int64_t N, int64_t K) {
   if (N > GR_MAX_POINTS || K > 1024) return false;
   const int mode = bq_mode();
   if (mode == BQ_SCAN) return false;
-  if (mode == BQ_GRID || mode == BQ_CELL || mode == BQ_GRID4) return true;
+  if (mode == BQ_GRID || mode == BQ_CELL) return true;
   return N >= 8192;
 }
 
@@ -1001,33 +829,6 @@ static int ball_query_dispatch(const float* xyz, const float* ctr, int64_t B,
     return S4G_OK;
   }
   if (int rc = launch_grid_build(xyz, B, N, inv_h, g, st, grouped != nullptr)) return rc;
-  if (bq_mode() != BQ_GRID) {   // default: the leaner per-centre kernel (S4G_BQ_MODE=grid: the first one)
-    const int nb128 = N <= 32768 ? 4 : 8;
-    const size_t lds4 = sizeof(uint32_t) * 4 * (size_t)(nb128 * 256 + ((K + 3) & ~3));
-    int cpw4 = 1;
-    if (const char* e = getenv("S4G_BQ4_CPW")) cpw4 = atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1);
-    const int cpb4 = 4 * cpw4;
-    const dim3 grid4((unsigned)((M + cpb4 - 1) / cpb4), (unsigned)B);
-#define S4G_BQ4_LAUNCH(F, G, NB, C)                                                                  \
-  hipLaunchKernelGGL((bq_grid4_query_kernel<F, IdxT, G, NB, C>), grid4, dim3(256), lds4, st, xyz, ctr, \
-                     (int)N, (int)M, r2, inv_h, (int)K, g, idx, cnt, grouped)
-#define S4G_BQ4_LAUNCH2(F, G)                                  \
-  do {                                                         \
-    if (nb128 == 4 && cpw4 == 1) S4G_BQ4_LAUNCH(F, G, 4, 1);   \
-    else if (nb128 == 4 && cpw4 == 2) S4G_BQ4_LAUNCH(F, G, 4, 2); \
-    else if (nb128 == 4) S4G_BQ4_LAUNCH(F, G, 4, 4);           \
-    else S4G_BQ4_LAUNCH(F, G, 8, 1);                           \
-  } while (0)
-    if (grouped) {
-      if (fmad) S4G_BQ4_LAUNCH2(true, true); else S4G_BQ4_LAUNCH2(false, true);
-    } else {
-      if (fmad) S4G_BQ4_LAUNCH2(true, false); else S4G_BQ4_LAUNCH2(false, false);
-    }
-#undef S4G_BQ4_LAUNCH2
-#undef S4G_BQ4_LAUNCH
-    S4G_LAUNCH_CHECK();
-    return S4G_OK;
-  }
   const size_t lds = sizeof(uint32_t) * BQ_WAVES_PER_BLOCK * (size_t)(64 * wpl + ((K + 3) & ~3));
 #define S4G_BQ_LAUNCH4(F, G, W, C)                                                        \
   hipLaunchKernelGGL((bq_grid_query_kernel<F, IdxT, G, W, C>), qgrid, block, lds, st, xyz, \

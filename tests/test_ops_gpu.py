@@ -150,7 +150,7 @@ def bq_mode(monkeypatch):
     return set_mode
 
 
-@pytest.mark.parametrize("mode", ["cell", "grid", "grid4", "scan"])
+@pytest.mark.parametrize("mode", ["cell", "grid", "scan"])
 @pytest.mark.parametrize("variant,N,M,r,K", [
     ("tabletop-v1", 25600, 5120, 0.02, 64),    # SA1
     ("tabletop-v1", 25600, 2000, 0.01, 32),    # scene wider than 32 cells: toroidal aliasing
@@ -172,7 +172,7 @@ def test_ball_query_grid_and_scan_paths(F, oracle, dev, bq_mode, mode, variant, 
     assert cnt[0, 0].item() == 0 and (idx[0, 0] == 0).all()
 
 
-@pytest.mark.parametrize("mode", ["cell", "grid", "grid4"])
+@pytest.mark.parametrize("mode", ["cell", "grid"])
 def test_ball_query_grid_out_of_range_scene_falls_back(F, oracle, dev, bq_mode, mode):
     """A scene spanning > 4096 cells trips the exactness flag: its centroids take
     the index-order scan inside the grid kernel; the other scene stays on the grid."""

@@ -38,7 +38,7 @@ def main():
         K = int(rng.choice([1, 5, 16, 64, 65, 128]))
         radius = float(rng.choice([0.005, 0.02, 0.05, 0.2, 1.5]))
         fps_mode = str(rng.choice(["", "dense", "pruned"]))
-        bq_mode = str(rng.choice(["", "grid", "grid4", "cell", "scan"]))
+        bq_mode = str(rng.choice(["", "grid", "cell", "scan"]))
         fmad = bool(rng.integers(4) == 0)
         for k, v in (("S4G_FPS_MODE", fps_mode), ("S4G_BQ_MODE", bq_mode)):
             if v:
