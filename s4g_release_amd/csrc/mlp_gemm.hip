@@ -1240,6 +1240,19 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
 // ---------------------------------------------------------------------------
 // W fragment prefetch depth of the chain kernel: 2 measured equal to 4 (+0.5 %) with 32 registers
 // less -- no spills in the deep-first-layer and eight-wave forms
+#ifdef S4G_CHAIN_STAMPS
+// debug build only (make HIPFLAGS_EXTRA=-DS4G_CHAIN_STAMPS): s_memtime stamps of wave 0 of the
+// 512 workgroups from the middle of the grid at the phase boundaries of mlp_chain_kernel, read back by tools/chain_stamps.py
+__device__ unsigned long long g_chain_stamps[512 * 16];
+#define S4G_STAMP(i)                                                                       \
+  do {                                                                                     \
+    const unsigned sb_ = blockIdx.x - gridDim.x / 2;   /* steady state: the middle of the grid */ \
+    if (threadIdx.x == 0 && sb_ < 512u && blockIdx.y == 0)                                 \
+      g_chain_stamps[sb_ * 16 + (i)] = __builtin_amdgcn_s_memtime();                      \
+  } while (0)
+#else
+#define S4G_STAMP(i)
+#endif
 constexpr int GF_RING_F16X2 = 2;
 // ring depth of the single-plane (bf16) form: 4 measured no faster than 2 (configs[4]: sa0
 // 2.67 vs 2.57 ms), so the W stream's latency is not what parks its waves
@@ -1326,8 +1339,10 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
 
   // (the loader's per-row state stays live through the first layer only when that layer is
   // more than one panel deep: KC > 1)
+  S4G_STAMP(0);
   ALoader<LOADER, RPT, RS> ld;
   ld.init(p, p0, g, t);
+  S4G_STAMP(1);
   // columns [kc * K, kc * K + K) of the loader's rows -> two fp16 planes.  DEPTH K-tiles of
   // loads are in flight at a time: the whole panel in the prologue (one round trip), two
   // tiles for the later chunks of a deep first layer (accumulators and ring are live then)
@@ -1361,7 +1376,9 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
     }
   };
   load_panel(0, std::integral_constant<int, K / 32>{});
+  S4G_STAMP(2);
   __syncthreads();
+  S4G_STAMP(3);
 
   const uint16_t* a_lane = Ah + (wr * 64 + li) * astr + 8 * lh;
   float* epi_s = scr + wave * 128;
@@ -1473,6 +1490,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
   } else {
     S4G_F2_STRIP(true, true, wcur, cb_stride, wnxt, cb_stride)
   }
+  S4G_STAMP(4 + 4 * ph);
   float tmax = 0.f;
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
@@ -1497,7 +1515,9 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
     const uint32_t wm = wave_max_u32(__float_as_uint(tmax));
     if (lane == 0) scr[NW * 128 + wave] = __uint_as_float(wm);
   }
+  S4G_STAMP(5 + 4 * ph);
   __syncthreads();   // every wave is done with the old panel; the four maxima are visible
+  S4G_STAMP(6 + 4 * ph);
   if constexpr (PL == 2) {
     float hmax = scr[NW * 128];
 #pragma unroll
@@ -1527,6 +1547,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
                                                       cvt_pk_bf16(acc[nb][pb][4 * j + 2], acc[nb][pb][4 * j + 3]));
         }
       }
+  S4G_STAMP(7 + 4 * ph);
   __syncthreads();
   // the next panel phase (three-layer chains) reads this panel through layer 2's weights
   inv_in = inv_sh;
@@ -1549,7 +1570,9 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
     const float e_sc = PL == 2 ? inv_sh * scF[n] : 1.f;
     const float e_bias = bg2[n];
     const char* wnext = ((strip + 1) * CW + wc_u) * 64 < CoutF ? wstrip + strip_stride : wstrip;
+    S4G_STAMP(12 + 2 * (strip & 1));
     S4G_F2_STRIP(EPI2 == EPI_STORE, true, wstrip, cb_stride, wnext, cb_stride)
+    S4G_STAMP(13 + 2 * (strip & 1));
     const int n0 = (strip * CW + wc) * 64;
     float omax = 0.f;
     if constexpr (EPI2 == EPI_STORE) {
@@ -1634,6 +1657,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
       gemm_epilogue<EPI_MAX, 2>(q, acc, bg2, g, p0, n0, wave, wr, 0, li, lh, smemf);
     }
   }
+  S4G_STAMP(11);
 #undef S4G_F2_STRIP
 #undef S4G_F2_TERM
 }
@@ -1752,6 +1776,12 @@ static int launch_gemm(const GemmParams& p, int groups, hipStream_t st) {
   X(LOAD_PLAIN, EPI_STORE, 8, 1)                                                                 \
   X(LOAD_INTERP_ADD, EPI_STORE, 2, 1)                                                            \
   X(LOAD_INTERP_ADD, EPI_STORE, 1, 1)
+
+#ifdef S4G_CHAIN_STAMPS
+extern "C" int s4g_debug_chain_stamps(unsigned long long* host_out_512x16) {
+  return (int)hipMemcpyFromSymbol(host_out_512x16, HIP_SYMBOL(s4g::g_chain_stamps), sizeof(unsigned long long) * 512 * 16);
+}
+#endif
 
 extern "C" int s4g_gemm_chain_supported(int loader, int epilogue, int C, int Kpad16) {
   using namespace s4g;
