@@ -225,12 +225,15 @@ def main():
             return sdist.all_gather_outputs(pred)   # one RCCL all-gather of (B,21,N)
         return pred
 
-    def run_steps(n, data=batch, pipe=pipelined, marks=None):
+    def run_steps(n, data=batch, pipe=pipelined, marks=None, gather=True):
         """n forward passes over the batch.  Pipelined mode keeps up to `--in-flight`
         batches submitted besides the one being collected: batch i+1's FPS chain
         starts on the geometry stream before batch i's outputs are collected; every
         batch is complete when the trailing fence returns.  `marks` collects one HIP
-        event per completed step (recorded on the collecting stream)."""
+        event per completed step (recorded on the collecting stream).  gather=False: no
+        collective (the probes after the timed region run on rank 0 alone)."""
+        fin = finish if gather else (lambda pred: pred)
+
         def mark():
             if marks is not None:
                 ev = torch.cuda.Event(enable_timing=True)
@@ -241,17 +244,17 @@ def main():
         with torch.no_grad():
             if not pipe:
                 for _ in range(n):
-                    finish(runner(data))
+                    fin(runner(data))
                     mark()
                 return
             pending = []
             for _ in range(n):
                 pending.append(runner.submit(data))
                 if len(pending) > args.in_flight:
-                    finish(pending.pop(0).result())
+                    fin(pending.pop(0).result())
                     mark()
             while pending:
-                finish(pending.pop(0).result())
+                fin(pending.pop(0).result())
                 mark()
 
     run_steps(args.warmup)
@@ -329,10 +332,10 @@ def main():
         latency = {"latency_ms_one_batch": round(timed_forward(batch, 5), 3), "batch": B,
                    "latency_ms_b1": round(timed_forward(one, 5), 3)}
         if pipelined:
-            run_steps(3, data=one)
+            run_steps(3, data=one, gather=False)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            run_steps(30, data=one)
+            run_steps(30, data=one, gather=False)
             torch.cuda.synchronize()
             latency["scenes_per_sec_b1"] = round(30 / (time.perf_counter() - t1), 2)
         latency["scenes_per_sec_one_batch_at_a_time"] = round(1e3 * B / latency["latency_ms_one_batch"], 2)

@@ -25,8 +25,14 @@ O = os.path.join(ROOT, "gpurun_out", "r2prof")
 CONTRACTION = ("mlp_chain_kernel", "mlp_heads_kernel", "mlp_gemm_")
 
 
+def newest(pattern):
+    """gpurun merges every call's files into the same local folders: keep the latest capture only"""
+    files = glob.glob(pattern, recursive=True)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 def per_kernel(tag, counter):
-    files = glob.glob(os.path.join(O, "pmc_%s_%s" % (tag, counter), "**", "*counter_collection.csv"), recursive=True)
+    files = newest(os.path.join(O, "pmc_%s_%s" % (tag, counter), "**", "*counter_collection.csv"))
     agg = collections.OrderedDict()
     for f in files:
         for r in csv.DictReader(open(f)):
@@ -87,7 +93,7 @@ def main():
             continue
         w = write.get(k, (n, 0.0))[1]
         md.append("| `%s` | %d | %.1f | %.1f |" % (k[:90], n, f / n / 1e6, w / n / 1e6))
-        if "13, 1>" in k or "bq_grid_build" in k or "group_xyz_aos" in k or "xyz_to_aos" in k:
+        if "long, false, 13, 1>" in k or "bq_grid_build" in k or "group_xyz_aos" in k or "xyz_to_aos" in k:
             pair += (f + w) / n
     if pair > 0:
         entries["ball_query+group_points[N=25600,M=5120,K=64,B=16]"] = {
@@ -98,7 +104,7 @@ def main():
         md += ["", "Pair (build + query + AoS copy + group): **%.1f MB** per launch set against 158.3 MB algorithmic." % (pair / 1e6), ""]
     # SQ counters of the dominant kernels
     for tag in ("default", "cfg4"):
-        files = glob.glob(os.path.join(O, "pmc_%s_SQ" % tag, "**", "*counter_collection.csv"), recursive=True)
+        files = newest(os.path.join(O, "pmc_%s_SQ" % tag, "**", "*counter_collection.csv"))
         agg = collections.OrderedDict()
         for f in files:
             for r in csv.DictReader(open(f)):
