@@ -23,19 +23,32 @@ __device__ __forceinline__ uint32_t pack_h2(float a, float b) {
   return __builtin_bit_cast(uint32_t, v);
 }
 
+// (x0 s, x1 s) as two packed fp16 pairs: h = RN16(x s), l = RN16(x s - h).  s is a power of two, so
+// x s and the residual are exact in fp32 and every half is rounded once; the mixed-precision FMA
+// forms convert on the way out and read h's halves directly (4 instructions per pair instead of
+// the 10 of multiply / convert / convert back / subtract / convert / pack).
+__device__ __forceinline__ void split_pair_h(float x0, float x1, float s, uint32_t& h, uint32_t& l) {
+  uint32_t hh, ll;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hh) : "v"(x0), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hh) : "v"(x1), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ll) : "v"(x0), "v"(s), "v"(hh));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ll) : "v"(x1), "v"(s), "v"(hh));
+  h = hh;
+  l = ll;
+}
+
 template <bool CLAMP>
 __device__ __forceinline__ void split2_h(const float4 v, float s, uint2& h, uint2& l) {
-  float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
-  float r[4];
+  if constexpr (CLAMP) {
+    float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    if constexpr (CLAMP) x[e] = __builtin_amdgcn_fmed3f(x[e], -65504.f, 65504.f);
-    r[e] = x[e] - (float)(_Float16)x[e];
+    for (int e = 0; e < 4; ++e) x[e] = __builtin_amdgcn_fmed3f(x[e], -65504.f, 65504.f);
+    split_pair_h(x[0], x[1], 1.0f, h.x, l.x);
+    split_pair_h(x[2], x[3], 1.0f, h.y, l.y);
+  } else {
+    split_pair_h(v.x, v.y, s, h.x, l.x);
+    split_pair_h(v.z, v.w, s, h.y, l.y);
   }
-  h.x = pack_h2(x[0], x[1]);
-  h.y = pack_h2(x[2], x[3]);
-  l.x = pack_h2(r[0], r[1]);
-  l.y = pack_h2(r[2], r[3]);
 }
 
 __device__ __forceinline__ float amax_slots(const float* __restrict__ slots, int lane) {
@@ -60,6 +73,21 @@ __device__ __forceinline__ void amax_publish(uint32_t* __restrict__ slots, uint3
   for (int sc = s0; sc <= s1; ++sc) atomicMax(slots + (size_t)sc * 64 + (slot & 63), wm);
 }
 
+
+// A position in a fragment-ordered W stream: buffer resource of the tensor + scalar byte offset.
+struct WRef {
+  __amdgpu_buffer_rsrc_t r;
+  uint32_t off;
+};
+__device__ __forceinline__ WRef wref(const void* base, size_t off) {
+  return WRef{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000), (uint32_t)off};
+}
+__device__ __forceinline__ WRef operator+(const WRef& w, size_t bytes) { return WRef{w.r, w.off + (uint32_t)bytes}; }
+// 16 bytes per lane at w + byte_off (scalar) + lane_off (vector; a constant part becomes the
+// instruction's immediate)
+__device__ __forceinline__ uint4 wref_load(const WRef& w, uint32_t lane_off, uint32_t byte_off) {
+  return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(w.r, (int)lane_off, (int)(w.off + byte_off), 0));
+}
 
 // One 32x32x16 matrix-core step on 16-byte operand registers: PL == 2 fp16 planes, PL == 1 bf16.
 template <int PL>

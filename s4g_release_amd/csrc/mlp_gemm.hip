@@ -1310,18 +1310,16 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
   // the accumulators run through all chunks before the first epilogue
   constexpr int kchunks = KC;   // Kpad16 / K
   const size_t cbs1 = (size_t)kchunks * cb_stride;              // layer 1's bytes between n32 blocks
-  const char* __restrict__ w1 = reinterpret_cast<const char*>(p.Wfrag + (size_t)g * p.Cout * p.Kpad16 * PL) +
-                                (size_t)(wc_u * 2) * cbs1;
+  // W streams go through buffer loads: descriptor and block offset are scalars, the lane offset
+  // one constant VGPR, so a fragment load costs no 64-bit address arithmetic on the vector pipe
+  const WRef w1 = wref(p.Wfrag + (size_t)g * p.Cout * p.Kpad16 * PL, (size_t)(wc_u * 2) * cbs1);
   // chain: layer 1 -> [layer 2 when a third layer follows] -> final layer (2 or 3)
   const bool tri = p.Wfrag3 != nullptr;
-  const char* __restrict__ wmid = reinterpret_cast<const char*>(p.Wfrag2 + (size_t)g * p.Cout2 * K * PL) +
-                                  (size_t)(wc_u * 2) * cb_stride;
+  const WRef wmid = wref(p.Wfrag2 + (size_t)g * p.Cout2 * K * PL, (size_t)(wc_u * 2) * cb_stride);
   const int CoutF = tri ? p.Cout3 : p.Cout2;
   const float* __restrict__ scF = PL == 2 ? (tri ? p.w_inv_scale3 : p.w_inv_scale2) + (size_t)g * CoutF : nullptr;
   const float* __restrict__ bgF = (tri ? p.bias3 : p.bias2) + (size_t)g * CoutF;
-  const char* __restrict__ w2 = tri ? reinterpret_cast<const char*>(p.Wfrag3 + (size_t)g * CoutF * K * PL) +
-                                          (size_t)(wc_u * 2) * cb_stride
-                                    : wmid;
+  const WRef w2 = tri ? wref(p.Wfrag3 + (size_t)g * CoutF * K * PL, (size_t)(wc_u * 2) * cb_stride) : wmid;
   const int nstrip2 = (CoutF + 64 * CW - 1) / (64 * CW);
   // a wave whose 64 channels lie past the final Cout (last, partial strip) sits the final phase
   // out; its ring must not prefetch fragments that do not exist
@@ -1334,8 +1332,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
       for (int pl = 0; pl < PL; ++pl)
-        ring[d][cb][pl] = *reinterpret_cast<const uint4*>(
-            w1 + ((size_t)cb * cbs1 + (size_t)(d * PL + pl) * 1024) + wf_lane);
+        ring[d][cb][pl] = wref_load(w1, wf_lane + pl * 1024, (uint32_t)(cb * cbs1 + (size_t)d * PL * 1024));
 
   // (the loader's per-row state stays live through the first layer only when that layer is
   // more than one panel deep: KC > 1)
@@ -1415,12 +1412,11 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
       bf[cb][pl] = ring[d][cb][pl];                                                                    \
     {                                                                                                  \
       const int kr = ks + GF_RING;                                                                     \
-      const char* src = kr < KS ? (wcur) : (wnext);                                                    \
+      const WRef src = kr < KS ? (wcur) : (wnext);                                                     \
       const size_t cbs = kr < KS ? (cbs_cur) : (cbs_next);                                             \
       const int kk = kr < KS ? kr : kr - KS;                                                           \
       _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) \
-        ring[d][cb][pl] = *reinterpret_cast<const uint4*>(                                             \
-            src + ((size_t)cb * cbs + (size_t)(kk * PL + pl) * 1024) + wf_lane);                       \
+        ring[d][cb][pl] = wref_load(src, wf_lane + pl * 1024, (uint32_t)(cb * cbs + (size_t)kk * PL * 1024)); \
     }                                                                                                  \
     if constexpr (PL == 2) {                                                                           \
       S4G_F2_TERM(SWAPPED, 0, 1, (ZFIRST) && ks == 0)                                                  \
@@ -1457,14 +1453,14 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
   for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 
   // ---- panel phases: H = relu(bn(W A)), C channels = one strip, operands swapped
-  const char* wcur = w1;
+  WRef wcur = w1;
   const float* __restrict__ scp = PL == 2 ? p.w_inv_scale + (size_t)g * p.b_gstride : nullptr;
   const float* __restrict__ bp = p.bias + (size_t)g * p.b_gstride;
   int relu_ph = p.relu;
   float inv_in = inv_sa, inv_sh = 1.f;
   const int npanel = tri ? 2 : 1;
   for (int ph = 0; ph < npanel; ++ph) {
-  const char* wnxt = ph + 1 < npanel ? wmid : (active0 ? w2 : wcur);
+  const WRef wnxt = ph + 1 < npanel ? wmid : (active0 ? w2 : wcur);
   prime_a();
   {
     const int n = wc * 64 + lane;   // channel whose scale / bias this lane stages for its wave
@@ -1481,9 +1477,9 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
         __syncthreads();
         prime_a();
       }
-      const char* wc1 = w1 + (size_t)kc * cb_stride;           // this chunk's 16 steps of each n32 block
+      const WRef wc1 = w1 + (size_t)kc * cb_stride;           // this chunk's 16 steps of each n32 block
       const bool lastc = kc + 1 == kchunks;
-      const char* wn1 = lastc ? wnxt : wc1 + cb_stride;
+      const WRef wn1 = lastc ? wnxt : wc1 + cb_stride;
       const size_t cbsn = lastc ? cb_stride : cbs1;
       S4G_F2_STRIP(true, false, wc1, cbs1, wn1, cbsn)
     }
@@ -1562,14 +1558,14 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
   q.Cout = CoutF;
   q.relu = tri ? p.relu3 : p.relu2;
   prime_a();
-  const char* wstrip = w2;
+  WRef wstrip = w2;
   const float* __restrict__ bg2 = bgF;
-  for (int strip = 0; strip < nstrip2; ++strip, wstrip += strip_stride) {
+  for (int strip = 0; strip < nstrip2; ++strip, wstrip = wstrip + strip_stride) {
     if ((strip * CW + wc_u) * 64 >= CoutF) break;
     const int n = (strip * CW + wc) * 64 + lane;
     const float e_sc = PL == 2 ? inv_sh * scF[n] : 1.f;
     const float e_bias = bg2[n];
-    const char* wnext = ((strip + 1) * CW + wc_u) * 64 < CoutF ? wstrip + strip_stride : wstrip;
+    const WRef wnext = ((strip + 1) * CW + wc_u) * 64 < CoutF ? wstrip + strip_stride : wstrip;
     S4G_STAMP(12 + 2 * (strip & 1));
     S4G_F2_STRIP(EPI2 == EPI_STORE, true, wstrip, cb_stride, wnext, cb_stride)
     S4G_STAMP(13 + 2 * (strip & 1));

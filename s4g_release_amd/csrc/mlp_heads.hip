@@ -76,24 +76,27 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
     inv_sa = __uint_as_float((ex - 14u) << 23);
   }
 
-  // fragment block (n32, ks) of layer L whose rows are nks blocks deep
-  auto wptr = [&](int L, int n32, int nks, int ks) {
-    return reinterpret_cast<const char*>(p.W[L]) + ((size_t)n32 * nks + ks) * FB;
-  };
-  auto w0 = [&](int g, int h) { return wptr(0, g * 16 + h * 8 + wv, 16, 0); };
-  auto w1 = [&](int g, int h) { return wptr(1, g * 8 + wv, 32, h * 16); };
-  auto w2 = [&](int g) { return wptr(2, g * 8 + wv, 16, 0); };
-  auto w3 = [&](int g) { return wptr(3, g * 4 + (wv & 3), 16, 0); };
-  auto wl = [&](int g) { return wptr(4, g, 8, 0); };
+  // fragment block (n32, ks) of layer L whose rows are nks blocks deep.  The W streams are read
+  // with buffer loads: resource descriptor and block offset are scalars, the lane offset is one
+  // constant VGPR -- no per-load 64-bit address arithmetic on the vector pipe.
+  WRef wrs[5];
+#pragma unroll
+  for (int L = 0; L < 5; ++L) wrs[L] = wref(p.W[L], 0);
+  auto woff = [&](int n32, int nks, int ks) { return (size_t)((n32 * nks + ks) * FB); };
+  auto w0 = [&](int g, int h) { return wrs[0] + woff(g * 16 + h * 8 + wv, 16, 0); };
+  auto w1 = [&](int g, int h) { return wrs[1] + woff(g * 8 + wv, 32, h * 16); };
+  auto w2 = [&](int g) { return wrs[2] + woff(g * 8 + wv, 16, 0); };
+  auto w3 = [&](int g) { return wrs[3] + woff(g * 4 + (wv & 3), 16, 0); };
+  auto wl = [&](int g) { return wrs[4] + woff(g, 8, 0); };
+  auto wload = [&](const WRef& w, uint32_t byte_off, int pl) { return wref_load(w, wf_lane + pl * 1024, byte_off); };
 
   uint4 ring[HD_RING][PL];
   {
-    const char* w = w0(0, 0);
+    const WRef w = w0(0, 0);
 #pragma unroll
     for (int d = 0; d < HD_RING; ++d)
 #pragma unroll
-      for (int pl = 0; pl < PL; ++pl)
-        ring[d][pl] = *reinterpret_cast<const uint4*>(w + d * FB + pl * 1024 + wf_lane);
+      for (int pl = 0; pl < PL; ++pl) ring[d][pl] = wload(w, d * FB, pl);
   }
 
   // ---- prologue: X -> panel A (one round trip per 64 rows: 8 x 16 bytes per thread in flight)
@@ -133,8 +136,8 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
     uint4 afn[NRBT][PL];                                                                            \
     _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb) _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) \
       afn[rb][pl] = *reinterpret_cast<const uint4*>(a_lane + pl * aplane + rb * 32 * astr);         \
-    const char* wcur_ = (WCUR);                                                                     \
-    const char* wnext_ = (WNEXT);                                                                   \
+    const WRef wcur_ = (WCUR);                                                                      \
+    const WRef wnext_ = (WNEXT);                                                                    \
     _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) {                                            \
       const int d = ks % HD_RING;                                                                   \
       const int ksn = ks + 1 == NKS ? 0 : ks + 1;                                                   \
@@ -146,9 +149,8 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
       _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) bf[pl] = ring[d][pl];                       \
       {                                                                                             \
         const int kr = ks + HD_RING;                                                                \
-        const char* src = kr < NKS ? wcur_ + kr * FB : wnext_ + (kr - NKS) * FB;                    \
         _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)                                           \
-          ring[d][pl] = *reinterpret_cast<const uint4*>(src + pl * 1024 + wf_lane);                 \
+          ring[d][pl] = kr < NKS ? wload(wcur_, kr * FB, pl) : wload(wnext_, (kr - NKS) * FB, pl);  \
       }                                                                                             \
       if constexpr (PL == 2) {                                                                      \
         S4G_HD_TERM(NRB, 0, 1, ks == 0)                                                             \
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
     {
       const int row3 = (wv >> 2) * (BM / 2), cg = wv & 3;
       stage_sb(3, g * 128 + cg * 32, inv_sh);
-      const char* after = wv < NRBT ? wl(g) : w0(g < 3 ? g + 1 : g, 0);
+      const WRef after = wv < NRBT ? wl(g) : w0(g < 3 ? g + 1 : g, 0);
       S4G_HD_STRIP(PB, NRBT / 2, row3, w3(g), 16, after)
       panel_epilogue(half{}, row3, cg * 32);
     }
