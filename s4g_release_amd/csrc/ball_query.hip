@@ -371,10 +371,11 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void bq_grid_query_kernel(
         const int je = grp < 9 ? __shfl(piece == 0 ? end0 : end1, src) : 0;
         if (grp >= 9) j = 0;
         while (__any(j < je)) {
+          // unconditional loads (record 0 for lanes past their row): a guarded load makes the
+          // compiler wait for each one before issuing the next
           float4 p[BQ_REC];
 #pragma unroll
-          for (int u = 0; u < BQ_REC; ++u)
-            if (j + 7 * u < je) p[u] = rec[j + 7 * u];
+          for (int u = 0; u < BQ_REC; ++u) p[u] = rec[j + 7 * u < je ? j + 7 * u : 0];
 #pragma unroll
           for (int u = 0; u < BQ_REC; ++u)
             if (j + 7 * u < je && dist2<FMAD>(cx, cy, cz, p[u].x, p[u].y, p[u].z) < r2) {
