@@ -101,6 +101,10 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void ball_query_scan_kerne
 
 // ---------------------------------------------------------------- GRID path
 // (grid layout, slot mapping and workspace carving: grid.h)
+// PPT > 0: the cloud fits PPT points per thread -- coordinates and slots stay in registers
+// between the counting and the scatter pass (one round trip to memory instead of
+// 2 * ceil(points per thread / GR_BUILD_U)); PPT == 0: any size, two streaming passes.
+template <int PPT>
 __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
     const float* __restrict__ xyz, int N, float inv_h, GridWs ws, int write_aos,
     const float* __restrict__ ctr, int M, CellWs cw, const float* __restrict__ inv_h_dev) {
@@ -126,6 +130,33 @@ __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
   // The point loops issue GR_BUILD_U independent plane loads per lane before
   // touching them: the slab workgroups are latency-, not bandwidth-bound.
   int bad = 0;
+  constexpr int RP = PPT > 0 ? PPT : 1;
+  float rx[RP], ry[RP], rz[RP];
+  if constexpr (PPT > 0) {
+    // buffer loads: one lane offset for all of them, the slot offset is an immediate / scalar
+    // and the range check returns 0 past the end (no per-load address registers)
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)px, 0, n * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)py, 0, n * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc((void*)pz, 0, n * 4, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      const int soff = u * GR_BUILD_THREADS * 4;
+      rx[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, t * 4, soff, 0));
+      ry[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yr, t * 4, soff, 0));
+      rz[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(zr, t * 4, soff, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      if (t + u * GR_BUILD_THREADS < n) {
+        if (!(grid_coord_ok(rx[u], ox, inv_h) && grid_coord_ok(ry[u], oy, inv_h) &&
+              grid_coord_ok(rz[u], oz, inv_h)))
+          bad = 1;
+        const int slot = grid_slot(grid_coord(rx[u], ox, inv_h), grid_coord(ry[u], oy, inv_h),
+                                   grid_coord(rz[u], oz, inv_h));
+        if ((slot >> 12) == g) atomicAdd(&hist[slot & (GR_RANGE_SLOTS - 1)], 1u);
+      }
+    }
+  } else {
   for (int j0 = t; j0 < n; j0 += GR_BUILD_THREADS * GR_BUILD_U) {
     float x[GR_BUILD_U], y[GR_BUILD_U], z[GR_BUILD_U];
 #pragma unroll
@@ -147,6 +178,7 @@ __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
         if ((slot >> 12) == g) atomicAdd(&hist[slot & (GR_RANGE_SLOTS - 1)], 1u);
       }
     }
+  }
   }
   bad = __syncthreads_or(bad);
   if (!queries && g == 0 && t == 0) ws.flags[b] = bad ? 1 : 0;
@@ -199,6 +231,22 @@ __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
 
   float4* __restrict__ rec = queries ? cw.sorted + (size_t)b * GR_RANGES * M
                                      : ws.sorted + (size_t)b * GR_RANGES * N;
+  if constexpr (PPT > 0) {
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      const int j = t + u * GR_BUILD_THREADS;
+      if (!queries && g == 0 && write_aos && j < n)
+        ws.xyz4[(size_t)b * N + j] = make_float4(rx[u], ry[u], rz[u], 0.f);
+      // (the slot is recomputed: keeping it would cost a register per point)
+      const int slot = grid_slot(grid_coord(rx[u], ox, inv_h), grid_coord(ry[u], oy, inv_h),
+                                 grid_coord(rz[u], oz, inv_h));
+      if (j < n && (slot >> 12) == g) {
+        const uint32_t pos = atomicAdd(&hist[slot & (GR_RANGE_SLOTS - 1)], 1u);
+        rec[pos] = make_float4(rx[u], ry[u], rz[u], __int_as_float(j));
+      }
+    }
+    return;
+  }
   for (int j0 = t; j0 < n; j0 += GR_BUILD_THREADS * GR_BUILD_U) {
     float x[GR_BUILD_U], y[GR_BUILD_U], z[GR_BUILD_U];
 #pragma unroll
@@ -717,9 +765,14 @@ __global__ __launch_bounds__(BQC_THREADS) void bq_cell_query_kernel(
 
 int launch_grid_build(const float* xyz, int64_t B, int64_t N, float inv_h, GridWs ws,
                       hipStream_t st, bool write_aos, const float* inv_h_dev) {
-  hipLaunchKernelGGL(bq_grid_build_kernel, dim3(GR_RANGES, (unsigned)B), dim3(GR_BUILD_THREADS),
-                     0, st, xyz, (int)N, inv_h, ws, write_aos ? 1 : 0, (const float*)nullptr, 0,
-                     CellWs{nullptr, nullptr, nullptr}, inv_h_dev);
+#define S4G_GB_LAUNCH(P)                                                                          \
+  hipLaunchKernelGGL(bq_grid_build_kernel<P>, dim3(GR_RANGES, (unsigned)B), dim3(GR_BUILD_THREADS), \
+                     0, st, xyz, (int)N, inv_h, ws, write_aos ? 1 : 0, (const float*)nullptr, 0, \
+                     CellWs{nullptr, nullptr, nullptr}, inv_h_dev)
+  if (N <= 8 * GR_BUILD_THREADS) S4G_GB_LAUNCH(8);
+  else if (N <= 25 * GR_BUILD_THREADS) S4G_GB_LAUNCH(25);
+  else S4G_GB_LAUNCH(0);
+#undef S4G_GB_LAUNCH
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }
@@ -727,9 +780,15 @@ int launch_grid_build(const float* xyz, int64_t B, int64_t N, float inv_h, GridW
 int launch_grid_build_queries(const float* xyz, const float* ctr, int64_t B, int64_t N,
                               int64_t M, float inv_h, GridWs ws, CellWs cw, hipStream_t st,
                               bool write_aos) {
-  hipLaunchKernelGGL(bq_grid_build_kernel, dim3(2 * GR_RANGES, (unsigned)B),
-                     dim3(GR_BUILD_THREADS), 0, st, xyz, (int)N, inv_h, ws, write_aos ? 1 : 0,
-                     ctr, (int)M, cw, (const float*)nullptr);
+  const int64_t big = N > M ? N : M;
+#define S4G_GB_LAUNCH(P)                                                                  \
+  hipLaunchKernelGGL(bq_grid_build_kernel<P>, dim3(2 * GR_RANGES, (unsigned)B),          \
+                     dim3(GR_BUILD_THREADS), 0, st, xyz, (int)N, inv_h, ws, write_aos ? 1 : 0, \
+                     ctr, (int)M, cw, (const float*)nullptr)
+  if (big <= 8 * GR_BUILD_THREADS) S4G_GB_LAUNCH(8);
+  else if (big <= 25 * GR_BUILD_THREADS) S4G_GB_LAUNCH(25);
+  else S4G_GB_LAUNCH(0);
+#undef S4G_GB_LAUNCH
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }
