@@ -39,8 +39,10 @@ extern "C" {
 
 /* 1: operators; 2: f16x2 contraction fields, crop / voxel / outlier / grid 3-NN / _ws entry points;
  * 3: fused layer chains (W2 / W3 fields), GATHER_ADD / INTERP_ADD loaders, s4g_interp_add_cl_f32,
- *    s4g_group_points_ws_f32, device-side cell choice of s4g_three_nn_grid_f32 (cell < 0). */
-#define S4G_ABI_VERSION 4
+ *    s4g_group_points_ws_f32, device-side cell choice of s4g_three_nn_grid_f32 (cell < 0).
+ * 4: per-scene activation maxima (rows_per_scene), bf16 chains, s4g_heads_chain_f32.
+ * 5: s4g_group_rel_xyz_i32 and the rel_xyz4 field of s4g_gemm_desc_t. */
+#define S4G_ABI_VERSION 5
 
 #define S4G_OK 0
 #define S4G_EINVAL (-1)     /* bad size / null pointer */
@@ -307,6 +309,11 @@ typedef struct s4g_gemm_desc {
    * scene's power-of-two scales -- and its results -- do not depend on the other scenes of the
    * batch (a tile that straddles scenes joins their rows); 0: one 64-slot row for all rows. */
   int32_t rows_per_scene;
+  /* ABI >= 5, optional, S4G_GEMM_LOAD_GATHER_MLP1: (P, 4) fp32 rows (xyz[b,:,gidx[p]] - ctr[b,:,m], 0)
+   * as s4g_group_rel_xyz_i32 writes them.  The loader then reads one coalesced 16-byte record per
+   * row instead of following gidx into the cloud (two dependent round trips at the head of every
+   * workgroup); gidx / xyz / ctr are not read.  Same values, same results. */
+  const float *rel_xyz4;
 } s4g_gemm_desc_t;
 
 int s4g_mlp_gemm_f32(const s4g_gemm_desc_t *desc, s4g_stream_t stream);
@@ -389,6 +396,14 @@ int s4g_query_group_f32(const float *xyz_b3n, const float *ctr_b3m, int64_t B,
                         int64_t N, int64_t M, float radius, int64_t K,
                         int64_t *idx_bmk, int64_t *cnt_bm, float *grouped_b3mk,
                         void *ws, size_t ws_bytes, int flags, s4g_stream_t stream);
+
+/* group_points(xyz, index) - centroid as one 16-byte record per neighbour (modules.py:42-44:
+ * group_xyz = group_points(xyz, index); group_xyz -= new_xyz.unsqueeze(-1)), for the first SA
+ * layer's loader (s4g_gemm_desc_t.rel_xyz4): out (B*M*K, 4) = (x - cx, y - cy, z - cz, 0), each
+ * difference one rounded fp32 subtraction. */
+int s4g_group_rel_xyz_i32(const float *xyz_b3n, const float *ctr_b3m, const int32_t *idx_bmk,
+                          int64_t B, int64_t N, int64_t M, int64_t K, float *rel_pk4,
+                          s4g_stream_t stream);
 
 /* FPS + centroid gather in one call: idx (B,M) int32 and ctr (B,3,M) planar. */
 int s4g_fps_gather_i32(const float *xyz_b3n, int64_t B, int64_t N, int64_t M,

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libs4g_hip.so")
 
-S4G_ABI_VERSION = 4
+S4G_ABI_VERSION = 5
 S4G_FLAG_FMAD = 1
 S4G_OP_FPS, S4G_OP_BALL_QUERY, S4G_OP_THREE_NN = 1, 2, 3
 
@@ -41,7 +41,7 @@ class GemmDesc(ctypes.Structure):
         ("a_amax_floor", _f32), ("out_amax", _vp), ("W_f16x2_frag", _vp),
         ("W2_f16x2_frag", _vp), ("w2_inv_scale", _vp), ("bias2", _vp), ("Cout2", _i32), ("relu2", _i32),
         ("W3_f16x2_frag", _vp), ("w3_inv_scale", _vp), ("bias3", _vp), ("Cout3", _i32), ("relu3", _i32),
-        ("loader_bias", _vp), ("rows_per_scene", _i32),
+        ("loader_bias", _vp), ("rows_per_scene", _i32), ("rel_xyz4", _vp),
     ]
 
 
@@ -74,6 +74,7 @@ SIGNATURES = {
     "s4g_group_points_ws_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "s4g_three_interpolate_ws_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _int, _vp]),
     "s4g_fps_gather_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _int, _vp]),
+    "s4g_group_rel_xyz_i32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "s4g_expected_score_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "s4g_decode_poses_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "s4g_collision_counts_f32": (_int, [_vp, _vp, _i64, _i64, _i64, ctypes.POINTER(ctypes.c_float),

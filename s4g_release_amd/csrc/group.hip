@@ -70,6 +70,24 @@ __global__ __launch_bounds__(GP_THREADS) void group_xyz_aos_kernel(const float4*
   *reinterpret_cast<float4*>(o + 2 * MK) = make_float4(p0.z, p1.z, p2.z, p3.z);
 }
 
+// (x_j - c_m, 0) per grouped row: the first SA layer's input as one 16-byte record per row
+__global__ __launch_bounds__(GP_THREADS) void group_rel_xyz_kernel(const float* __restrict__ xyz,
+                                                                   const float* __restrict__ ctr,
+                                                                   const int* __restrict__ idx, int N,
+                                                                   int M, int K,
+                                                                   float4* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int64_t MK = (int64_t)M * K;
+  const int64_t t = (int64_t)blockIdx.x * GP_THREADS + threadIdx.x;
+  if (t >= MK) return;
+  const int m = (int)(t / K);
+  const int j = idx[(size_t)b * MK + t];
+  const float* __restrict__ x = xyz + (size_t)b * 3 * N;
+  const float* __restrict__ c = ctr + (size_t)b * 3 * M;
+  out[(size_t)b * MK + t] = make_float4(__fsub_rn(x[j], c[m]), __fsub_rn(x[N + j], c[M + m]),
+                                        __fsub_rn(x[2 * (size_t)N + j], c[2 * (size_t)M + m]), 0.f);
+}
+
 __global__ __launch_bounds__(GP_THREADS) void group_points_scalar_kernel(
     const float* __restrict__ in, const int64_t* __restrict__ idx, int C, int N,
     int64_t MK, float* __restrict__ out) {
@@ -149,6 +167,23 @@ extern "C" int s4g_group_points_xyz_f32(const float* xyz_b3n, const int64_t* idx
   hipLaunchKernelGGL(s4g::group_xyz_aos_kernel,
                      dim3((unsigned)((MK / 4 + s4g::GP_THREADS - 1) / s4g::GP_THREADS), (unsigned)B),
                      dim3(s4g::GP_THREADS), 0, st, aos, idx_bmk, (int)N, MK, out_b3mk);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
+
+extern "C" int s4g_group_rel_xyz_i32(const float* xyz_b3n, const float* ctr_b3m, const int32_t* idx_bmk,
+                                     int64_t B, int64_t N, int64_t M, int64_t K, float* rel_pk4,
+                                     s4g_stream_t stream) {
+  if (B < 0 || N <= 0 || M < 0 || K < 0 || B > 65535 || N >= (1ll << 31) || M * K >= (1ll << 31))
+    return S4G_EINVAL;
+  const int64_t MK = M * K;
+  if (B == 0 || MK == 0) return S4G_OK;
+  if (!xyz_b3n || !ctr_b3m || !idx_bmk || !rel_pk4 || ((uintptr_t)rel_pk4 & 15)) return S4G_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(s4g::group_rel_xyz_kernel,
+                     dim3((unsigned)((MK + s4g::GP_THREADS - 1) / s4g::GP_THREADS), (unsigned)B),
+                     dim3(s4g::GP_THREADS), 0, st, xyz_b3n, ctr_b3m, idx_bmk, (int)N, (int)M, (int)K,
+                     reinterpret_cast<float4*>(rel_pk4));
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }

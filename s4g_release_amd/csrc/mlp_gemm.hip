@@ -37,6 +37,10 @@
 
 #include <type_traits>
 
+#ifndef S4G_CHAIN_ABLATE
+#define S4G_CHAIN_ABLATE 0
+#endif
+
 namespace s4g {
 
 
@@ -67,6 +71,7 @@ struct GemmParams {
   // GATHER_MLP1: first SA layer (xyz only) evaluated in the loader:
   // A[p][k] = relu(w1[k].x*rx + w1[k].y*ry + w1[k].z*rz + w1[k].w), k < Cin
   const float4* mlp1;
+  const float4* rel4;   // optional: the rows' (xyz_j - ctr_m, 0) records, read instead of following gidx
   // INTERP: sparse (B*N2, C2), dense (B*N1, C1), nidx/nw (B*N1, 3)
   const int* nidx;
   const float* nw;
@@ -151,6 +156,13 @@ struct ALoader {
       if constexpr (LOADER == LOAD_PLAIN) {
         src0[s] = p.A + (size_t)pp * p.lda + p.a_coff + g * p.a_gcol;
       } else if constexpr (LOADER == LOAD_GATHER_MLP1) {
+        if (p.rel4) {   // pre-gathered by s4g_group_rel_xyz_i32: one coalesced 16-byte read per row
+          const float4 r4 = p.rel4[pp];
+          rel[s][0] = r4.x;
+          rel[s][1] = r4.y;
+          rel[s][2] = r4.z;
+          continue;
+        }
         int b = 0, m = 0;
         if (ok[s]) gather_row_bm(p.M, p.K, p0, r, b, m);
         const int j = p.gidx[pp];
@@ -198,34 +210,41 @@ struct ALoader {
 
   // 4-float chunk of logical A row s at columns k0..k0+3
   __device__ __forceinline__ float4 load(const GemmParams& p, int s, int k0, int t) const {
-    if (!ok[s]) return f4zero();
-    if constexpr (LOADER == LOAD_PLAIN) {
-      if (k0 >= p.Cin) return f4zero();
-      return *reinterpret_cast<const float4*>(src0[s] + k0);
-    } else if constexpr (LOADER == LOAD_GATHER_MLP1) {
-      if (k0 >= p.Cin) return f4zero();
+    if constexpr (LOADER == LOAD_GATHER_MLP1) {
+      // the weight loads are unconditional (rows past the end and columns past Cin are zeroed by
+      // a select afterwards): the rows of a thread share them, and a guarded load is not merged
+      const bool live = ok[s] && k0 < p.Cin;
+      const int kk = k0 < p.Cin ? k0 : 0;
       float4 r;
       float* rp = reinterpret_cast<float*>(&r);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float4 w = p.mlp1[k0 + e];
+        const float4 w = p.mlp1[kk + e];
         const float v = __fmaf_rn(w.z, rel[s][2], __fmaf_rn(w.y, rel[s][1], __fmaf_rn(w.x, rel[s][0], w.w)));
-        rp[e] = fmaxf(v, 0.f);
+        rp[e] = live ? fmaxf(v, 0.f) : 0.f;
       }
       return r;
-    } else if constexpr (LOADER == LOAD_GATHER_ADD) {
-      if (k0 >= p.Cin) return f4zero();
-      const float4 f = *reinterpret_cast<const float4*>(src0[s] + k0);
+    }
+    if constexpr (LOADER == LOAD_GATHER_ADD) {
+      // (unconditional loads as above; a row past the end reads row 0's feature row)
+      const bool live = ok[s] && k0 < p.Cin;
+      const int kk = k0 < p.Cin ? k0 : 0;
+      const float4 f = *reinterpret_cast<const float4*>(src0[s] + kk);
       const float fv[4] = {f.x, f.y, f.z, f.w};
       float4 r;
       float* rp = reinterpret_cast<float*>(&r);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float4 w = p.mlp1[k0 + e];
+        const float4 w = p.mlp1[kk + e];
         const float v = __fmaf_rn(w.z, rel[s][2], __fmaf_rn(w.y, rel[s][1], __fmaf_rn(w.x, rel[s][0], w.w)));
-        rp[e] = fmaxf(__fadd_rn(fv[e], v), 0.f);
+        rp[e] = live ? fmaxf(__fadd_rn(fv[e], v), 0.f) : 0.f;
       }
       return r;
+    }
+    if (!ok[s]) return f4zero();
+    if constexpr (LOADER == LOAD_PLAIN) {
+      if (k0 >= p.Cin) return f4zero();
+      return *reinterpret_cast<const float4*>(src0[s] + k0);
     } else if constexpr (LOADER == LOAD_INTERP_ADD) {
       // first FP layer applied before the interpolation: A = relu(y + bias + sum_k w_k S[idx_k])
       if (k0 >= p.Cin) return f4zero();
@@ -1238,8 +1257,11 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const G
 // amax round trip through HBM (a per-tile scale is as exact as the per-tensor one: both
 // are powers of two undone in the epilogue).
 // ---------------------------------------------------------------------------
-// W fragment prefetch depth of the chain kernel: 2 measured equal to 4 (+0.5 %) with 32 registers
-// less -- no spills in the deep-first-layer and eight-wave forms
+// measurement builds only (make HIPFLAGS_EXTRA=-DS4G_CHAIN_ABLATE=bits, tools/ablate_kernels.sh): the chain
+// kernel with parts REMOVED, to see what each costs -- 1 no W refill, 2 no LDS operand reads in
+// the strips, 4 no panel epilogue, 8 no final epilogue, 16 no loader.  Results are garbage.
+__device__ __forceinline__ void chain_keep_alive(const f32x16& v) { asm volatile("" ::"v"(v)); }
+
 #ifdef S4G_CHAIN_STAMPS
 // debug build only (make HIPFLAGS_EXTRA=-DS4G_CHAIN_STAMPS): s_memtime stamps of wave 0 of the
 // 512 workgroups from the middle of the grid at the phase boundaries of mlp_chain_kernel, read back by tools/chain_stamps.py
@@ -1256,6 +1278,8 @@ __device__ unsigned long long g_chain_stamps[512 * 16];
 constexpr int GF_RING_F16X2 = 2;
 // ring depth of the single-plane (bf16) form: 4 measured no faster than 2 (configs[4]: sa0
 // 2.67 vs 2.57 ms), so the W stream's latency is not what parks its waves
+// W fragment prefetch depth of the chain kernel: 2 measured equal to 4 (+0.5 %) with 32 registers
+// less -- no spills in the deep-first-layer and eight-wave forms
 #ifndef S4G_CHAIN_RING1
 #define S4G_CHAIN_RING1 2
 #endif
@@ -1372,7 +1396,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
       if (DEPTH < NKT) __builtin_amdgcn_sched_barrier(0);
     }
   };
-  load_panel(0, std::integral_constant<int, K / 32>{});
+  if (!(S4G_CHAIN_ABLATE & 16)) load_panel(0, std::integral_constant<int, K / 32>{});
   S4G_STAMP(2);
   __syncthreads();
   S4G_STAMP(3);
@@ -1406,7 +1430,8 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
     uint4 af[2][PL], bf[2][PL];                                                                        \
     _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) { \
       af[rb][pl] = afn[rb][pl];                                                                        \
-      afn[rb][pl] = *reinterpret_cast<const uint4*>(a_lane + pl * aplane + rb * 32 * astr + ksn * 16); \
+      if (!(S4G_CHAIN_ABLATE & 2))                                                                     \
+        afn[rb][pl] = *reinterpret_cast<const uint4*>(a_lane + pl * aplane + rb * 32 * astr + ksn * 16); \
     }                                                                                                  \
     _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)  \
       bf[cb][pl] = ring[d][cb][pl];                                                                    \
@@ -1416,7 +1441,8 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
       const size_t cbs = kr < KS ? (cbs_cur) : (cbs_next);                                             \
       const int kk = kr < KS ? kr : kr - KS;                                                           \
       _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) \
-        ring[d][cb][pl] = wref_load(src, wf_lane + pl * 1024, (uint32_t)(cb * cbs + (size_t)kk * PL * 1024)); \
+        if (!(S4G_CHAIN_ABLATE & 1))                                                                   \
+          ring[d][cb][pl] = wref_load(src, wf_lane + pl * 1024, (uint32_t)(cb * cbs + (size_t)kk * PL * 1024)); \
     }                                                                                                  \
     if constexpr (PL == 2) {                                                                           \
       S4G_F2_TERM(SWAPPED, 0, 1, (ZFIRST) && ks == 0)                                                  \
@@ -1487,6 +1513,11 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
     S4G_F2_STRIP(true, true, wcur, cb_stride, wnxt, cb_stride)
   }
   S4G_STAMP(4 + 4 * ph);
+  if (S4G_CHAIN_ABLATE & 4) {
+    chain_keep_alive(acc[0][0]); chain_keep_alive(acc[0][1]); chain_keep_alive(acc[1][0]); chain_keep_alive(acc[1][1]);
+    __syncthreads();
+    __syncthreads();
+  } else {
   float tmax = 0.f;
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
@@ -1545,6 +1576,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
       }
   S4G_STAMP(7 + 4 * ph);
   __syncthreads();
+  }
   // the next panel phase (three-layer chains) reads this panel through layer 2's weights
   inv_in = inv_sh;
   wcur = wmid;
@@ -1569,6 +1601,10 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
     S4G_STAMP(12 + 2 * (strip & 1));
     S4G_F2_STRIP(EPI2 == EPI_STORE, true, wstrip, cb_stride, wnext, cb_stride)
     S4G_STAMP(13 + 2 * (strip & 1));
+    if (S4G_CHAIN_ABLATE & 8) {
+      chain_keep_alive(acc[0][0]); chain_keep_alive(acc[0][1]); chain_keep_alive(acc[1][0]); chain_keep_alive(acc[1][1]);
+      continue;
+    }
     const int n0 = (strip * CW + wc) * 64;
     float omax = 0.f;
     if constexpr (EPI2 == EPI_STORE) {
@@ -1815,6 +1851,7 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   p.gidx = d->gidx; p.feat = d->feat; p.xyz = d->xyz; p.ctr = d->ctr;
   p.Cf = d->Cf; p.N = d->N; p.M = d->M; p.K = d->K;
   p.mlp1 = (const float4*)d->mlp1_w;
+  p.rel4 = (const float4*)d->rel_xyz4;
   p.nidx = d->nidx; p.nw = d->nw; p.sparse = d->sparse; p.dense = d->dense;
   p.C2 = d->C2; p.C1 = d->C1; p.N2 = d->N2; p.N1 = d->N1;
   p.out = d->out; p.ldc = d->ldc; p.c_coff = d->c_coff; p.c_gcol = d->c_gcol;
@@ -1855,8 +1892,10 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
         d->K <= 0 || d->M <= 0 || d->N <= 0 || d->groups != 1)
       return S4G_EINVAL;
   } else if (d->loader == S4G_GEMM_LOAD_GATHER_MLP1) {
-    if (!d->gidx || !d->xyz || !d->ctr || !d->mlp1_w || (d->Cin & 3) || d->K <= 0 || d->M <= 0 ||
-        d->N <= 0 || d->groups != 1 || ((uintptr_t)d->mlp1_w & 15))
+    // (with rel_xyz4 the rows are pre-gathered: gidx / xyz / ctr are not read)
+    if ((!d->rel_xyz4 && (!d->gidx || !d->xyz || !d->ctr)) || ((uintptr_t)d->rel_xyz4 & 15) ||
+        !d->mlp1_w || (d->Cin & 3) || d->K <= 0 || d->M <= 0 || d->N <= 0 || d->groups != 1 ||
+        ((uintptr_t)d->mlp1_w & 15))
       return S4G_EINVAL;
   } else if (d->loader == S4G_GEMM_LOAD_GATHER_ADD) {
     if (!d->gidx || !d->xyz || !d->ctr || !d->mlp1_w || !d->feat || (d->Cin & 3) || d->Cf != d->Cin ||

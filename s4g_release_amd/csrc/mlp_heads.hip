@@ -26,7 +26,16 @@
 
 #include "mlp_common.h"
 
+// measurement builds only (make HIPFLAGS_EXTRA=-DS4G_HEADS_ABLATE=bits, tools/ablate_kernels.sh): the
+// kernel with parts REMOVED, to see what each costs -- 1 no W refill, 2 no LDS operand reads in
+// the strips, 4 no panel epilogue, 8 nor its barriers.  Results are garbage.
+#ifndef S4G_HEADS_ABLATE
+#define S4G_HEADS_ABLATE 0
+#endif
+
 namespace s4g {
+
+__device__ __forceinline__ void heads_keep_alive(const f32x16& v) { asm volatile("" ::"v"(v)); }
 
 struct HeadsParams {
   int P, N;                // positions (B * N), points per scene
@@ -144,13 +153,15 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
       uint4 af[NRBT][PL], bf[PL];                                                                   \
       _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb) _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) { \
         af[rb][pl] = afn[rb][pl];                                                                   \
-        afn[rb][pl] = *reinterpret_cast<const uint4*>(a_lane + pl * aplane + rb * 32 * astr + ksn * 16); \
+        if (!(S4G_HEADS_ABLATE & 2))                                                                \
+          afn[rb][pl] = *reinterpret_cast<const uint4*>(a_lane + pl * aplane + rb * 32 * astr + ksn * 16); \
       }                                                                                             \
       _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) bf[pl] = ring[d][pl];                       \
       {                                                                                             \
         const int kr = ks + HD_RING;                                                                \
         _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)                                           \
-          ring[d][pl] = kr < NKS ? wload(wcur_, kr * FB, pl) : wload(wnext_, (kr - NKS) * FB, pl);  \
+          if (!(S4G_HEADS_ABLATE & 1))                                                              \
+            ring[d][pl] = kr < NKS ? wload(wcur_, kr * FB, pl) : wload(wnext_, (kr - NKS) * FB, pl); \
       }                                                                                             \
       if constexpr (PL == 2) {                                                                      \
         S4G_HD_TERM(NRB, 0, 1, ks == 0)                                                             \
@@ -187,6 +198,15 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
   float inv_sh = 1.f;
   auto panel_epilogue = [&](auto nrb_tag, int rowoff, int pch0) {
     constexpr int NRB = decltype(nrb_tag)::value;
+    if (S4G_HEADS_ABLATE & 4) {
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) heads_keep_alive(acc[rb]);
+      if (!(S4G_HEADS_ABLATE & 8)) {
+        __syncthreads();
+        __syncthreads();
+      }
+      return;
+    }
     float tmax = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

@@ -155,6 +155,7 @@ class FusedPointNet2:
         v = os.environ.get("S4G_FP_LOADER_ADD", "auto")
         self.fp_loader_add = v if v in ("auto", "none") else set(int(t) for t in v.split(",") if t)
         self.geo_streams = max(1, int(os.environ.get("S4G_GEO_STREAMS", "2")))
+        self.rel_xyz = os.environ.get("S4G_REL_XYZ", "1") != "0"
         p = next(net.parameters())
         if not p.is_cuda:
             raise RuntimeError("FusedPointNet2 needs the model on a HIP device (no CPU fallback)")
@@ -366,6 +367,18 @@ class FusedPointNet2:
         _cabi.check(rc, "ball_query_i32")
         return idx, cnt
 
+    def _group_rel_xyz(self, xyz, ctr, gidx):
+        """(B*M*K, 4) rows (xyz_j - ctr_m, 0): the first SA layer's input, gathered on the geometry
+        stream so that the contraction's loader reads one coalesced record per row."""
+        B, _, N = xyz.shape
+        _, M, K = gidx.shape
+        rel = torch.empty((B * M * K, 4), dtype=torch.float32, device=xyz.device)
+        with _F._timed("group_rel_xyz[N=%d,M=%d,K=%d]" % (N, M, K), B * M * K * (4 + 12 + 16)):
+            rc = _cabi.lib().s4g_group_rel_xyz_i32(xyz.data_ptr(), ctr.data_ptr(), gidx.data_ptr(),
+                                                   B, N, M, K, rel.data_ptr(), _F._stream())
+        _cabi.check(rc, "group_rel_xyz_i32")
+        return rel
+
     def _three_nn(self, q, k, eps, cell=0.0):
         B, _, N1 = q.shape
         N2 = k.shape[2]
@@ -394,7 +407,7 @@ class FusedPointNet2:
         """Everything that depends on coordinates only: the FPS pyramid, the ball
         queries and the 3-NN searches + weights of all levels."""
         B, _, N0 = xyz.shape
-        geo = dict(level_xyz=[xyz], level_n=[N0], sa=[], fp=[], sa_events=[])
+        geo = dict(level_xyz=[xyz], level_n=[N0], sa=[], fp=[], sa_events=[], rel=[])
         n_cur = N0
         for sa in self.sa:
             M, K = sa["M"], sa["K"]
@@ -403,6 +416,10 @@ class FusedPointNet2:
             idx, ctr = self._fps_gather(geo["level_xyz"][-1], M)
             gidx, gcnt = self._ball_query(geo["level_xyz"][-1], ctr, sa["radius"], K)
             geo["sa"].append((idx, ctr, gidx, gcnt))
+            # the xyz-only first layer runs inside the next layer's loader: hand it its rows
+            # pre-gathered (S4G_REL_XYZ=0: the loader follows gidx itself)
+            geo["rel"].append(self._group_rel_xyz(geo["level_xyz"][-1], ctr, gidx)
+                              if sa["mlp1"] is not None and self.rel_xyz else None)
             # the contractions of this SA level only need its own sampling + grouping:
             # they may start while the deeper levels' FPS / 3-NN are still running
             geo["sa_events"].append(torch.cuda.current_stream().record_event())
@@ -473,6 +490,8 @@ class FusedPointNet2:
                 if l == 1 and sa["mlp1"] is not None:
                     kw.update(gidx=gidx, xyz=level_xyz[li], ctr=ctr, N=level_n[li], M=M,
                               mlp1_w=sa["mlp1"], a_amax_floor=sa["mlp1_bound"])
+                    if geo["rel"][li] is not None:
+                        kw.update(rel_xyz4=geo["rel"][li])
                     loader = LOAD_GATHER_MLP1
                 elif l == 1 and pre is not None:
                     kw.update(gidx=gidx, feat=fpre, Cf=layers[0].cout, xyz=level_xyz[li], ctr=ctr,
@@ -677,6 +696,9 @@ class FusedPointNet2:
             xyz.record_stream(ds)
             for idx, ctr, gidx, gcnt in geo["sa"]:
                 for t in (idx, ctr, gidx, gcnt):
+                    t.record_stream(ds)
+            for t in geo["rel"]:
+                if t is not None:
                     t.record_stream(ds)
             for nidx, nw in geo["fp"]:
                 nidx.record_stream(ds)

@@ -229,6 +229,58 @@ def test_gemm_gather_mlp1(dev, C1, Cout, epi, prec, gemm_variant):
     assert (out.double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
 
 
+def test_group_rel_xyz_and_pregathered_mlp1_loader(dev):
+    """s4g_group_rel_xyz_i32 = group_points(xyz, idx) - centroid as (P, 4) records, and the MLP1
+    loader reading them (rel_xyz4) gives bit-identical results to following gidx itself."""
+    from s4g_release_amd import _cabi
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B, N, M, K, C1, Cout = 3, 700, 37, 64, 128, 256
+    xyz = (torch.rand(B, 3, N, generator=g) * 0.3).to(dev)
+    cidx = torch.randint(0, N, (B, M), generator=g)
+    ctr = torch.stack([xyz[b][:, cidx[b]] for b in range(B)]).contiguous()
+    gidx = torch.randint(0, N, (B, M, K), generator=g).int().to(dev)
+    P = B * M * K
+    rel4 = torch.full((P, 4), float("nan"), device=dev)
+    rc = _cabi.lib().s4g_group_rel_xyz_i32(xyz.data_ptr(), ctr.data_ptr(), gidx.data_ptr(), B, N, M, K,
+                                           rel4.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _cabi.check(rc, "group_rel_xyz")
+    ref = torch.stack([xyz[bi][:, gidx[bi].long()] - ctr[bi][:, :, None] for bi in range(B)])   # (B,3,M,K)
+    assert torch.equal(rel4[:, :3], ref.permute(0, 2, 3, 1).reshape(P, 3))
+    assert (rel4[:, 3] == 0).all()
+    w1 = torch.randn(C1, 4, generator=g).to(dev)
+    W = (torch.randn(Cout, C1, generator=g) / C1 ** 0.5).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    Wp = _padk(W)
+    k16, w3 = _w3(W)
+    h2 = _h2(W, floor=float((w1[:, :3].abs().sum(1) * 0.6 + w1[:, 3].abs()).max()))
+    outs = []
+    for extra in (dict(gidx=gidx, xyz=xyz, ctr=ctr), dict(rel_xyz4=rel4)):
+        out = torch.full((B * M, Cout), float("nan"), device=dev)
+        _run(dict(loader=3, epilogue=1, groups=1, relu=1, P=P, Cin=C1, Kpad=Wp.shape[1], Cout=Cout,
+                  W=Wp, bias=b, N=N, M=M, K=K, mlp1_w=w1, out=out, ldc=Cout, precision=3, Kpad16=k16,
+                  W_bf16x3=w3, **h2, **extra), dev)
+        outs.append(out)
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
+def test_model_with_and_without_pregathered_rows(dev, monkeypatch):
+    """FusedPointNet2 hands the first SA level its rows pre-gathered (S4G_REL_XYZ, default on):
+    same outputs bit for bit as the loader following the indices itself."""
+    from s4g_release_amd import synth
+    from s4g_release_amd.fused import FusedPointNet2
+    from s4g_release_amd.model import S4GConfig, build_pointnet2_cls, randomize_bn_
+    torch.manual_seed(3)
+    net = build_pointnet2_cls(S4GConfig())
+    randomize_bn_(net, 4)
+    net = net.to(dev).eval()
+    pts = torch.from_numpy(synth.make_batch([5, 6], 25600)).to(dev)
+    a = FusedPointNet2(net)({"scene_points": pts})
+    monkeypatch.setenv("S4G_REL_XYZ", "0")
+    b = FusedPointNet2(net)({"scene_points": pts})
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 def _h2_second(W2):
     """W2_f16x2_frag / w2_inv_scale of the layer fused behind (groups leading)."""
     from s4g_release_amd.fused import fragment_order, split_f16x2

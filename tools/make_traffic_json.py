@@ -123,12 +123,38 @@ def main():
         for k, d in agg.items():
             waves = d["SQ_WAVES"]
             us = d["_us"] / max(d["_n"], 1)
-            simd_cycles = 1024.0 * d["_us"] * 1e-6 * 2.1e9          # ~2.1 GHz under MFMA load (r01 micro-benchmark)
+            simd_cycles = 1024.0 * d["_us"] * 1e-6 * 1.9e9          # ~1.9 GHz under MFMA load (see the clock table below)
             wc = max(d["SQ_WAVE_CYCLES"], 1.0)
             md.append("| `%s` | %.0f | %.0f | %.0f | %.0f | %.0f %% | %.0f / %.0f / %.0f %% |" % (
                 k[:60], us, waves / max(d["_n"], 1), (d["SQ_INSTS_VALU"] - d["SQ_INSTS_MFMA"]) / waves,
                 d["SQ_INSTS_MFMA"] / waves, 100.0 * d["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles,
                 100 * d["SQ_ACTIVE_INST_ANY"] / wc, 100 * d["SQ_WAIT_INST_ANY"] / wc, 100 * d["SQ_WAIT_ANY"] / wc))
+        md.append("")
+    # effective clock and matrix-pipe duty at that clock
+    for tag in ("default", "cfg4"):
+        files = newest(os.path.join(O, "pmc_%s_CLK" % tag, "**", "*counter_collection.csv"))
+        agg = collections.OrderedDict()
+        for f in files:
+            for r in csv.DictReader(open(f)):
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                if not any(c in k for c in ("mlp_chain_kernel", "mlp_heads_kernel", "mlp_gemm_f16x2", "fps_pruned", "fps_cluster")):
+                    continue
+                d = agg.setdefault(k, collections.defaultdict(float))
+                d[r["Counter_Name"]] += float(r["Counter_Value"])
+                if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                    d["_us"] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+                    d["_n"] += 1
+        if not agg:
+            continue
+        md += ["## Effective shader clock, %s (GRBM_GUI_ACTIVE summed over the 8 XCDs / 8 / wall time; "
+               "SQ_VALU_MFMA_BUSY_CYCLES / (128 SIMDs per XCD x GRBM_GUI_ACTIVE) = matrix-pipe duty at that clock)" % tag, "",
+               "| kernel | launches | avg us | effective clock MHz | matrix pipe busy | share of the 2.5 PFLOP/s peak the clock leaves |",
+               "|---|---:|---:|---:|---:|---:|"]
+        for k, d in agg.items():
+            mhz = d["GRBM_GUI_ACTIVE"] / 8.0 / max(d["_us"], 1e-9)
+            md.append("| `%s` | %d | %.0f | %.0f | %.1f %% | %.2f |" % (
+                k[:60], d["_n"], d["_us"] / max(d["_n"], 1), mhz,
+                100.0 * d["SQ_VALU_MFMA_BUSY_CYCLES"] / (128.0 * max(d["GRBM_GUI_ACTIVE"], 1.0)), mhz / 2400.0))
         md.append("")
     with open(os.path.join(ROOT, "profiles", "r02_traffic.json"), "w") as f:
         json.dump(entries, f, indent=1)

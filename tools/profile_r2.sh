@@ -20,6 +20,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_default_SQ -- python3 $R/bench.py $NOPIPE > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_cfg4_SQ -- python3 $R/bench.py $CFG4 $NOPIPE > /dev/null 2>&1
+# effective shader clock per kernel: GRBM_GUI_ACTIVE / wall time (MI355X_MICROARCH.md, "DVFS give-back")
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_default_CLK -- python3 $R/bench.py $NOPIPE > /dev/null 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_cfg4_CLK -- python3 $R/bench.py $CFG4 $NOPIPE > /dev/null 2>&1
 for d in default cfg4; do
   db=$(find $O/stats_$d -name "*.db" | head -1)
   [ -n "$db" ] && python3 $R/tools/rocpd_summary.py $db 45 > $O/${d}_kernel_stats.md
