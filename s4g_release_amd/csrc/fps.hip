@@ -38,7 +38,8 @@ struct FpsSlot {
   uint32_t d;
   uint32_t tie;
   float x, y, z;
-  uint32_t pad[3];
+  uint32_t d2;      // two-pick exchange: distance bits of the wave's runner-up (else 0)
+  uint32_t pad[2];
 };
 
 // Block-wide argmax exchange.  Input: this wave's (wmax, wtie) and the
@@ -57,7 +58,7 @@ __device__ __forceinline__ void fps_block_exchange(FpsSlot* slots, int wave,
     s.x = sx;
     s.y = sy;
     s.z = sz;
-    s.pad[0] = s.pad[1] = s.pad[2] = 0;
+    s.d2 = s.pad[0] = s.pad[1] = 0;
     slots[wave] = s;
   }
   __syncthreads();
@@ -79,6 +80,70 @@ __device__ __forceinline__ void fps_block_exchange(FpsSlot* slots, int wave,
   cx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.x), wl));
   cy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.y), wl));
   cz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.z), wl));
+}
+
+// Two picks per exchange.  Every wave also publishes the distance d2 of its RUNNER-UP (its best
+// point other than its candidate).  Let W be the winning wave and R the best candidate of the
+// other waves.  If d(R) > d2(W) strictly, every point except the winner is <= R in the
+// (distance, tie key) order: the other waves' points are below their own candidates, W's other
+// points are below d2(W).  The winner's update can only lower min-distances, so R is the next
+// pick provided R itself is out of the winner's reach -- dist2(winner, R) is not below R's
+// min-distance, evaluated with the update's own arithmetic.  Returns whether (rcur, rx, ry, rz)
+// is that second pick; everything is wave-uniform and every wave decides alike.
+template <int WAVES, bool FMAD>
+__device__ __forceinline__ bool fps_block_exchange2(FpsSlot* slots, int wave, int lane, uint32_t wmax,
+                                                    uint32_t wtie, uint32_t wd2, float sx, float sy,
+                                                    float sz, int& cur, float& cx, float& cy, float& cz,
+                                                    int& rcur, float& rx, float& ry, float& rz) {
+  if (lane == 0) {
+    FpsSlot s;
+    s.d = wmax;
+    s.tie = wtie;
+    s.x = sx;
+    s.y = sy;
+    s.z = sz;
+    s.d2 = wd2;
+    s.pad[0] = s.pad[1] = 0;
+    slots[wave] = s;
+  }
+  __syncthreads();
+  const FpsSlot s = slots[lane & (WAVES - 1)];
+  const uint64_t first = (1ull << WAVES) - 1ull;
+  const uint32_t bmax = row16_max_u32(s.d);
+  uint64_t win = __ballot(s.d == bmax) & first;
+  uint32_t btie;
+  if (__popcll(win) > 1) {
+    const uint32_t cand = (s.d == bmax) ? s.tie : 0xFFFFFFFFu;
+    btie = __builtin_amdgcn_readlane(row16_min_u32(cand), 0);
+    win = __ballot(s.d == bmax && s.tie == btie) & first;
+  } else {
+    btie = __builtin_amdgcn_readlane(s.tie, __ffsll((unsigned long long)win) - 1);
+  }
+  const int wl = __ffsll((unsigned long long)win) - 1;
+  cur = (int)(btie & FPS_JMASK);
+  cx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.x), wl));
+  cy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.y), wl));
+  cz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.z), wl));
+  // the best candidate of the other waves against the winner wave's runner-up
+  const uint32_t so = (lane & (WAVES - 1)) == wl ? 0u : s.d;
+  const uint32_t b2 = __builtin_amdgcn_readlane(row16_max_u32(so), 0);
+  const uint32_t d2w = __builtin_amdgcn_readlane(s.d2, wl);
+  if (b2 == 0u || b2 <= d2w) return false;
+  uint64_t win2 = __ballot(so == b2) & first;
+  uint32_t t2;
+  if (__popcll(win2) > 1) {
+    const uint32_t cand = (so == b2) ? s.tie : 0xFFFFFFFFu;
+    t2 = __builtin_amdgcn_readlane(row16_min_u32(cand), 0);
+    win2 = __ballot(so == b2 && s.tie == t2) & first;
+  } else {
+    t2 = __builtin_amdgcn_readlane(s.tie, __ffsll((unsigned long long)win2) - 1);
+  }
+  const int rl = __ffsll((unsigned long long)win2) - 1;
+  rcur = (int)(t2 & FPS_JMASK);
+  rx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.x), rl));
+  ry = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.y), rl));
+  rz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.z), rl));
+  return !(dist2<FMAD>(cx, cy, cz, rx, ry, rz) < __uint_as_float(b2));
 }
 
 // Read (x[pw], y[pw], z[pw]) of lane `wl` into wave-uniform values.  `pw` is
@@ -799,7 +864,7 @@ __device__ __forceinline__ void fps_update_slot(const float (&x)[PPT], const flo
   }
 }
 
-template <int THREADS, int PPT, bool FMAD, typename IdxT>
+template <int THREADS, int PPT, bool FMAD, typename IdxT, bool SPEC>
 __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __restrict__ xyz,
                                                              const int* __restrict__ perm,
                                                              const float* __restrict__ gbox,
@@ -875,17 +940,25 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
   }
 
   // ---- pruned phase ---------------------------------------------------------
-  for (int i = i0; i < M; ++i) {
-    uint32_t wmax, wtie;
+  // SPEC: an exchange may settle TWO picks (fps_block_exchange2); both centroids are then applied
+  // before the next candidates are taken (the updates commute: each is a running minimum).
+  int npend = 1;                       // centroids whose update is still due: (cx,cy,cz)[, (rx,ry,rz)]
+  int rcur = 0;
+  float rx = 0.f, ry = 0.f, rz = 0.f;
+  for (int i = i0; i < M;) {
+    uint32_t wmax, wtie, wd2 = 0u;
     float sx = cx, sy = cy, sz = cz;
-    // 1. groups the new centroid can still change
+    // 1. groups the new centroid(s) can still change
     uint32_t gbits[GPL];
+#pragma unroll 1
+    for (int q = 0; q < npend; ++q) {
+    const float ux = q ? rx : cx, uy = q ? ry : cy, uz = q ? rz : cz;
 #pragma unroll
     for (int r = 0; r < GPL; ++r) {
       const bool live = 64 * r + lane < PPT;
-      const float tx = cx < blx[r] ? __fsub_rn(blx[r], cx) : (cx > bhx[r] ? __fsub_rn(bhx[r], cx) : 0.f);
-      const float ty = cy < bly[r] ? __fsub_rn(bly[r], cy) : (cy > bhy[r] ? __fsub_rn(bhy[r], cy) : 0.f);
-      const float tz = cz < blz[r] ? __fsub_rn(blz[r], cz) : (cz > bhz[r] ? __fsub_rn(bhz[r], cz) : 0.f);
+      const float tx = ux < blx[r] ? __fsub_rn(blx[r], ux) : (ux > bhx[r] ? __fsub_rn(bhx[r], ux) : 0.f);
+      const float ty = uy < bly[r] ? __fsub_rn(bly[r], uy) : (uy > bhy[r] ? __fsub_rn(bhy[r], uy) : 0.f);
+      const float tz = uz < blz[r] ? __fsub_rn(blz[r], uz) : (uz > bhz[r] ? __fsub_rn(bhz[r], uz) : 0.f);
       float lb;
       if constexpr (FMAD) {
         lb = __fmaf_rn(tz, tz, __fmaf_rn(ty, ty, __fmul_rn(tx, tx)));
@@ -909,7 +982,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
                 if ((need >> (p8 + e)) & 1ull) {
                   float xl = x[p];
                   asm volatile("; fps slot" : "+v"(xl));
-                  const float d = dist2<FMAD>(cx, cy, cz, xl, y[p], z[p]);
+                  const float d = dist2<FMAD>(ux, uy, uz, xl, y[p], z[p]);
                   float m;
                   const float old = md[p];
                   asm volatile("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(d), "v"(old));
@@ -928,6 +1001,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
       }
       gbits[r] = live ? __float_as_uint(mg[r]) : 0u;
     }
+    }
     // 2. this wave's candidate: the group(s) holding the largest maximum
     uint32_t lmax = gbits[0];
 #pragma unroll
@@ -937,11 +1011,14 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
       wtie = wave_min_u32(rkey | (uint32_t)cur);   // every point of this wave is at distance 0
     } else {
       uint32_t best_key = 0xFFFFFFFFu;
+      int nbest = 0;                               // groups / lanes that hold the maximum
 #pragma unroll
       for (int r = 0; r < GPL; ++r) {
         uint64_t gmask = __ballot(gbits[r] == wmax);
+        if constexpr (SPEC) nbest += __popcll(gmask);
         while (gmask) {                          // one group unless maxima tie across groups
-          const int pw = 64 * r + __ffsll((unsigned long long)gmask) - 1;
+          const int gl = __ffsll((unsigned long long)gmask) - 1;
+          const int pw = 64 * r + gl;
           gmask &= gmask - 1;
           const int s = 64 * (WAVES * pw + wave) + lane;
           // every lane reads its original index early (the LDS read overlaps the tree walk)
@@ -960,6 +1037,20 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
             kmin = wave_min_u32(k);
             wl = __ffsll((unsigned long long)__ballot(k == kmin)) - 1;
           }
+          if constexpr (SPEC) {
+            // the wave's runner-up distance: the best of this group's other points and of the
+            // other groups' maxima (a second holder of the maximum makes it the maximum itself)
+            if (__popcll(eq) > 1) {
+              nbest = 2;
+            } else if (nbest == 1) {
+              const uint32_t in_group = wave_max_u32((s < N && lane != wl) ? __float_as_uint(vm) : 0u);
+              uint32_t others = 0u;
+#pragma unroll
+              for (int r2 = 0; r2 < GPL; ++r2)
+                others = max(others, (r2 == r && lane == gl) ? 0u : gbits[r2]);
+              wd2 = max(in_group, wave_max_u32(others));
+            }
+          }
           if (kmin < best_key) {
             best_key = kmin;
             sx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vx), wl));
@@ -968,9 +1059,35 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
           }
         }
       }
+      if constexpr (SPEC) {
+        if (nbest > 1) wd2 = wmax;
+      }
       wtie = best_key;
     }
-    publish(i, wmax, wtie, sx, sy, sz);
+    if constexpr (SPEC) {
+      const bool two = fps_block_exchange2<WAVES, FMAD>(slots[i & 1], wave, lane, wmax, wtie, wd2, sx, sy, sz,
+                                                        cur, cx, cy, cz, rcur, rx, ry, rz) && i + 1 < M;
+      if (t == 0) {
+        out[i] = (IdxT)cur;
+        if (two) out[i + 1] = (IdxT)rcur;
+        if (cout) {
+          cout[i] = cx;
+          cout[M + i] = cy;
+          cout[2 * M + i] = cz;
+          if (two) {
+            cout[i + 1] = rx;
+            cout[M + i + 1] = ry;
+            cout[2 * M + i + 1] = rz;
+          }
+        }
+      }
+      npend = two ? 2 : 1;
+      if (two) cur = rcur;
+      i += npend;
+    } else {
+      publish(i, wmax, wtie, sx, sy, sz);
+      ++i;
+    }
   }
 }
 
@@ -1101,17 +1218,23 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
   S4G_FPS_CASE(512, 50)
 #undef S4G_FPS_CASE
   if (launched && pruned) {
+  // two picks per exchange where the runner-up is out of the winner's reach (S4G_FPS_SPEC=0: one)
+  static const bool spec = [] { const char* e = getenv("S4G_FPS_SPEC"); return !(e && e[0] == '0'); }();
+#define S4G_FPS_PRUNED_LAUNCH(T, P, S)                                                             \
+  {                                                                                                \
+    static LdsAttrCache lds_cache;                                                                 \
+    if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(&fps_pruned_kernel<T, P, FMAD, IdxT, S>), lds, lds_cache)) return rc;  \
+    hipLaunchKernelGGL((fps_pruned_kernel<T, P, FMAD, IdxT, S>), grid, dim3(T), lds, stream, xyz,  \
+                       w.val_out, w.gbox, w.md, dense_steps, (int)N, (int)M, idx, ctr, lg);        \
+  }
 #define S4G_FPS_PRUNED(T, P)                                                                       \
   if (N <= (int64_t)T * P) {                                                                       \
     const size_t lds = sizeof(uint16_t) * T * P;                                                   \
-    static LdsAttrCache lds_cache;                                                                 \
-    if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(&fps_pruned_kernel<T, P, FMAD, IdxT>), lds, lds_cache)) return rc;  \
     constexpr int G = (T / 64) * P;                                                                \
     hipLaunchKernelGGL(fps_group_box_kernel, dim3((G + 3) / 4, (unsigned)B), dim3(256), 0, stream, \
                        xyz, w.val_out, (int)N, G, w.gbox);                                         \
     S4G_LAUNCH_CHECK();                                                                            \
-    hipLaunchKernelGGL((fps_pruned_kernel<T, P, FMAD, IdxT>), grid, dim3(T), lds, stream, xyz,     \
-                       w.val_out, w.gbox, w.md, dense_steps, (int)N, (int)M, idx, ctr, lg);            \
+    if (spec) S4G_FPS_PRUNED_LAUNCH(T, P, true) else S4G_FPS_PRUNED_LAUNCH(T, P, false)            \
     S4G_LAUNCH_CHECK();                                                                            \
     return S4G_OK;                                                                                 \
   }
@@ -1120,6 +1243,7 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
     S4G_FPS_PRUNED(512, 32)
     S4G_FPS_PRUNED(512, 50)
 #undef S4G_FPS_PRUNED
+#undef S4G_FPS_PRUNED_LAUNCH
   }
   if (launched) return S4G_OK;
   // two workgroups per scene, all points in registers, winners exchanged through L2 once per
