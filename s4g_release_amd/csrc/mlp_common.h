@@ -74,6 +74,13 @@ __device__ __forceinline__ void amax_publish(uint32_t* __restrict__ slots, uint3
 }
 
 
+// 16-byte load with the streaming hint (data read once: do not keep it in L2)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // A position in a fragment-ordered W stream: buffer resource of the tensor + scalar byte offset.
 struct WRef {
   __amdgpu_buffer_rsrc_t r;

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
     float4 ra[8];
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt)
-      ra[kt] = ok ? *reinterpret_cast<const float4*>(src + kt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[kt] = ok ? nt_load4(src + kt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);   // read once: do not displace the W set in L2
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
       uint16_t* dst = PA + row * astr + kt * 32 + chunk * 4;
