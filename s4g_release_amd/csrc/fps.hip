@@ -1091,6 +1091,227 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Pruned FPS for clouds whose COORDINATES do not fit one CU's registers (25 600 < N <= 51 200).
+// Same bookkeeping as fps_pruned_kernel -- Morton groups of 64 points, a box and an exact
+// maximum per group, a step only rescans the groups the new centroid can still change, two picks
+// per exchange where the runner-up is out of reach -- but only the running min-distances (100
+// per lane) stay resident.  The coordinates of a touched group are ONE coalesced 1 KB read of
+// the Morton-sorted (x, y, z, original index) records (L2-resident: 0.8 MB per scene), issued
+// for a block of eight slots at a time; the candidate's record is read the same way.  A step
+// costs two dependent L2 round trips more than the register-resident kernel, but it needs ONE CU
+// per scene where the full-scan cluster kernel holds two (3.1 us/step each): a 32-scene batch
+// of 51 200-point clouds took 30 % of the chip's CU time for FPS alone.  No dense first phase:
+// the min-distances start at +inf, so the first steps touch every group (13 blocks of loads per
+// step) and the count decays within a few dozen steps.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fps_sorted_aos_kernel(const float* __restrict__ xyz,
+                                                             const int* __restrict__ perm, int N, int cap,
+                                                             float4* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= cap) return;
+  const float* p = xyz + (size_t)b * 3 * N;
+  const int j = s < N ? perm[(size_t)b * N + s] : 0;
+  out[(size_t)b * cap + s] = make_float4(p[j], p[(size_t)N + j], p[2 * (size_t)N + j], __int_as_float(j));
+}
+
+template <int THREADS, int PPT, bool FMAD, typename IdxT>
+__global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __restrict__ xyz,
+                                                                const float4* __restrict__ sorted,
+                                                                const float* __restrict__ gbox, int N, int M,
+                                                                IdxT* __restrict__ idx, float* __restrict__ ctr,
+                                                                int lg_bs) {
+  constexpr int WAVES = THREADS / 64;
+  constexpr int GPL = (PPT + 63) / 64;
+  constexpr int G = WAVES * PPT;
+  __shared__ FpsSlot slots[2][FPS_MAX_WAVES];
+  const int b = blockIdx.x;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const float* __restrict__ px = xyz + (size_t)b * 3 * N;
+  const float4* __restrict__ srt = sorted + (size_t)b * THREADS * PPT;
+  IdxT* __restrict__ out = idx + (size_t)b * M;
+  float* __restrict__ cout = ctr ? ctr + (size_t)b * 3 * M : nullptr;
+  const uint32_t bs_mask = (1u << lg_bs) - 1u;
+  auto tie_key = [&](uint32_t j) { return ((__brev(j & bs_mask) >> (32 - lg_bs)) << 23) | j; };
+  // slot p of this lane = sorted position 64 * (WAVES * p + wave) + lane; its record through a
+  // buffer load: one lane offset for every slot, the slot's offset is a scalar
+  auto spos = [&](int p) { return 64 * (WAVES * p + wave) + lane; };
+  const __amdgpu_buffer_rsrc_t srt_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)srt, 0, THREADS * PPT * 16, 0x00020000);
+  const int lane_off = (64 * wave + lane) * 16;
+  auto record = [&](int p) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(srt_rsrc, lane_off, p * THREADS * 16, 0));
+  };
+
+  float md[PPT];
+  float blx[GPL], bly[GPL], blz[GPL], bhx[GPL], bhy[GPL], bhz[GPL], mg[GPL];
+#pragma unroll
+  for (int r = 0; r < GPL; ++r) {
+    const int slot = 64 * r + lane;
+    const int g = slot < PPT ? WAVES * slot + wave : 0;
+    const float* gb = gbox + ((size_t)b * G + g) * 6;
+    blx[r] = gb[0]; bly[r] = gb[1]; blz[r] = gb[2];
+    bhx[r] = gb[3]; bhy[r] = gb[4]; bhz[r] = gb[5];
+    mg[r] = (slot < PPT && 64 * g < N) ? __builtin_inff() : 0.f;   // groups of padding only never lead
+  }
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) md[p] = spos(p) < N ? __builtin_inff() : 0.0f;
+  const uint32_t rkey = (__brev((uint32_t)t & bs_mask) >> (32 - lg_bs)) << 23;   // all-zero case only
+
+  int cur = 0;
+  float cx = px[0], cy = px[(size_t)N], cz = px[2 * (size_t)N];
+  if (t == 0) {
+    out[0] = 0;
+    if (cout) {
+      cout[0] = cx;
+      cout[M] = cy;
+      cout[2 * M] = cz;
+    }
+  }
+
+  int npend = 1;
+  int rcur = 0;
+  float rx = 0.f, ry = 0.f, rz = 0.f;
+  for (int i = 1; i < M;) {
+    uint32_t wmax, wtie, wd2 = 0u;
+    float sx = cx, sy = cy, sz = cz;
+    uint32_t gbits[GPL];
+#pragma unroll 1
+    for (int q = 0; q < npend; ++q) {
+      const float ux = q ? rx : cx, uy = q ? ry : cy, uz = q ? rz : cz;
+#pragma unroll
+      for (int r = 0; r < GPL; ++r) {
+        const bool live = 64 * r + lane < PPT;
+        const float tx = ux < blx[r] ? __fsub_rn(blx[r], ux) : (ux > bhx[r] ? __fsub_rn(bhx[r], ux) : 0.f);
+        const float ty = uy < bly[r] ? __fsub_rn(bly[r], uy) : (uy > bhy[r] ? __fsub_rn(bhy[r], uy) : 0.f);
+        const float tz = uz < blz[r] ? __fsub_rn(blz[r], uz) : (uz > bhz[r] ? __fsub_rn(bhz[r], uz) : 0.f);
+        float lb;
+        if constexpr (FMAD) {
+          lb = __fmaf_rn(tz, tz, __fmaf_rn(ty, ty, __fmul_rn(tx, tx)));
+        } else {
+          lb = __fadd_rn(__fadd_rn(__fmul_rn(tx, tx), __fmul_rn(ty, ty)), __fmul_rn(tz, tz));
+        }
+        const uint64_t need = __ballot(live && lb < mg[r]);
+        if (need) {
+#pragma unroll
+          for (int p8 = 0; p8 < 64 && 64 * r + p8 < PPT; p8 += 8) {
+            if (__builtin_expect(((need >> p8) & 0xFFull) != 0ull, 0)) {
+              // the touched slots' records first (all in flight together), then the updates
+              float4 rec[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const int p = 64 * r + p8 + e;
+                if (p < PPT) {
+                  if ((need >> (p8 + e)) & 1ull) rec[e] = record(p);
+                }
+              }
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const int p = 64 * r + p8 + e;
+                if (p < PPT) {
+                  if ((need >> (p8 + e)) & 1ull) {
+                    const float d = dist2<FMAD>(ux, uy, uz, rec[e].x, rec[e].y, rec[e].z);
+                    float m;
+                    const float old = md[p];
+                    asm volatile("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(d), "v"(old));
+                    md[p] = m;
+                    // the group maximum only moves if a point that held it came closer
+                    const uint32_t gm = __builtin_amdgcn_readlane(__float_as_uint(mg[r]), p8 + e);
+                    if (__ballot(__float_as_uint(old) == gm && m < old)) {
+                      const uint32_t g = wave_max_u32(__float_as_uint(m));
+                      if (lane == p8 + e) mg[r] = __uint_as_float(g);
+                    }
+                  }
+                }
+              }
+            }
+          }
+        }
+        gbits[r] = live ? __float_as_uint(mg[r]) : 0u;
+      }
+    }
+    // this wave's candidate and the distance of its runner-up
+    uint32_t lmax = gbits[0];
+#pragma unroll
+    for (int r = 1; r < GPL; ++r) lmax = max(lmax, gbits[r]);
+    wmax = wave_max_u32(lmax);
+    if (wmax == 0u) {
+      wtie = wave_min_u32(rkey | (uint32_t)cur);   // every point of this wave is at distance 0
+    } else {
+      uint32_t best_key = 0xFFFFFFFFu;
+      int nbest = 0;
+#pragma unroll
+      for (int r = 0; r < GPL; ++r) {
+        uint64_t gmask = __ballot(gbits[r] == wmax);
+        nbest += __popcll(gmask);
+        while (gmask) {
+          const int gl = __ffsll((unsigned long long)gmask) - 1;
+          const int pw = 64 * r + gl;
+          gmask &= gmask - 1;
+          const int s = 64 * (WAVES * pw + wave) + lane;
+          const float4 me = record(pw);                         // this lane's point of the group (zeros past the end)
+          const float vm = fps_pick_md<PPT, 0, PPT>(md, pw);
+          const uint32_t kk = tie_key((uint32_t)__float_as_int(me.w));
+          const bool hit = s < N && __float_as_uint(vm) == wmax;
+          const uint64_t eq = __ballot(hit);
+          const uint32_t k = hit ? kk : 0xFFFFFFFFu;
+          uint32_t kmin;
+          int wl;
+          if (__popcll(eq) == 1) {
+            wl = __ffsll((unsigned long long)eq) - 1;
+            kmin = __builtin_amdgcn_readlane(k, wl);
+          } else {
+            kmin = wave_min_u32(k);
+            wl = __ffsll((unsigned long long)__ballot(k == kmin)) - 1;
+          }
+          if (__popcll(eq) > 1) {
+            nbest = 2;
+          } else if (nbest == 1) {
+            const uint32_t in_group = wave_max_u32((s < N && lane != wl) ? __float_as_uint(vm) : 0u);
+            uint32_t others = 0u;
+#pragma unroll
+            for (int r2 = 0; r2 < GPL; ++r2) others = max(others, (r2 == r && lane == gl) ? 0u : gbits[r2]);
+            wd2 = max(in_group, wave_max_u32(others));
+          }
+          if (kmin < best_key) {
+            best_key = kmin;
+            sx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.x), wl));
+            sy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.y), wl));
+            sz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.z), wl));
+          }
+        }
+      }
+      if (nbest > 1) wd2 = wmax;
+      wtie = best_key;
+    }
+    const bool two = fps_block_exchange2<WAVES, FMAD>(slots[i & 1], wave, lane, wmax, wtie, wd2, sx, sy, sz, cur,
+                                                      cx, cy, cz, rcur, rx, ry, rz) && i + 1 < M;
+    if (t == 0) {
+      out[i] = (IdxT)cur;
+      if (two) out[i + 1] = (IdxT)rcur;
+      if (cout) {
+        cout[i] = cx;
+        cout[M + i] = cy;
+        cout[2 * M + i] = cz;
+        if (two) {
+          cout[i + 1] = rx;
+          cout[M + i + 1] = ry;
+          cout[2 * M + i + 1] = rz;
+        }
+      }
+    }
+    npend = two ? 2 : 1;
+    if (two) cur = rcur;
+    i += npend;
+  }
+}
+
+constexpr int FPS_L2_CAP = 512 * 100;   // points per scene of fps_pruned_l2_kernel<512, 100>
+
 struct FpsSortWs {
   float* bbox;
   float* gbox;
@@ -1098,6 +1319,7 @@ struct FpsSortWs {
   uint64_t *key_in, *key_out;
   int *val_in, *val_out;
   void* tmp;
+  float4* aos;      // Morton-sorted (x, y, z, index) records: fps_pruned_l2_kernel only (N > 25 600)
   size_t tmp_bytes, total;
 };
 
@@ -1123,8 +1345,17 @@ static FpsSortWs fps_sort_ws(void* base, int64_t B, int64_t N) {
   w.val_in = (int*)take(sizeof(int) * n);
   w.val_out = (int*)take(sizeof(int) * n);
   w.tmp = take(w.tmp_bytes);
+  w.aos = N > (int64_t)512 * 50 ? (float4*)take(sizeof(float4) * (size_t)B * FPS_L2_CAP) : nullptr;
   w.total = off;
   return w;
+}
+
+// 25 600 < N <= 51 200: the one-CU pruned kernel with coordinates in L2 (default),
+// S4G_FPS_MODE=cluster the two-CU full scan, =hybrid the one-CU full scan
+static bool fps_use_pruned_l2(int64_t N, int64_t M) {
+  if (N <= (int64_t)512 * 50 || N > FPS_L2_CAP || M < 64) return false;
+  const char* e = getenv("S4G_FPS_MODE");
+  return !(e && (e[0] == 'c' || e[0] == 'h' || e[0] == 'd'));
 }
 
 static bool fps_use_pruned(int64_t N) {
@@ -1246,6 +1477,33 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
 #undef S4G_FPS_PRUNED_LAUNCH
   }
   if (launched) return S4G_OK;
+  if (fps_use_pruned_l2(N, M) && B < (1 << 16)) {
+    const FpsSortWs w2 = fps_sort_ws(ws, B, N);
+    if (ws && ws_bytes >= w2.total) {
+      hipLaunchKernelGGL(fps_bbox_kernel, dim3((unsigned)B), dim3(1024), 0, stream, xyz, (int)N, w2.bbox);
+      S4G_LAUNCH_CHECK();
+      hipLaunchKernelGGL(fps_morton_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0,
+                         stream, xyz, (int)N, (int)B, w2.bbox, w2.key_in, w2.val_in);
+      S4G_LAUNCH_CHECK();
+      int bits = 30;
+      while ((1ll << (bits - 30)) < B) ++bits;
+      size_t tb = w2.tmp_bytes;
+      const hipError_t e = rocprim::radix_sort_pairs(w2.tmp, tb, w2.key_in, w2.key_out, w2.val_in,
+                                                     w2.val_out, (size_t)B * (size_t)N, 0, bits, stream);
+      if (e != hipSuccess) return (int)e;
+      constexpr int G = 8 * 100;
+      hipLaunchKernelGGL(fps_group_box_kernel, dim3((G + 3) / 4, (unsigned)B), dim3(256), 0, stream, xyz,
+                         w2.val_out, (int)N, G, w2.gbox);
+      S4G_LAUNCH_CHECK();
+      hipLaunchKernelGGL(fps_sorted_aos_kernel, dim3((FPS_L2_CAP + 255) / 256, (unsigned)B), dim3(256), 0,
+                         stream, xyz, w2.val_out, (int)N, FPS_L2_CAP, w2.aos);
+      S4G_LAUNCH_CHECK();
+      hipLaunchKernelGGL((fps_pruned_l2_kernel<512, 100, FMAD, IdxT>), grid, dim3(512), 0, stream, xyz,
+                         w2.aos, w2.gbox, (int)N, (int)M, idx, ctr, lg);
+      S4G_LAUNCH_CHECK();
+      return S4G_OK;
+    }
+  }
   // two workgroups per scene, all points in registers, winners exchanged through L2 once per
   // step (S4G_FPS_MODE=hybrid keeps the single-CU kernel below)
   if (N <= (int64_t)512 * 100 && fps_use_cluster() && ws && ws_bytes >= fps_cluster_ws_bytes(B)) {
@@ -1275,7 +1533,11 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
 size_t fps_workspace_bytes(int64_t B, int64_t N) {
   if (N <= 0 || B <= 0) return 0;
   if (N <= (int64_t)512 * 50) return fps_use_pruned(N) ? fps_sort_ws(nullptr, B, N).total : 0;
-  if (N <= (int64_t)512 * 100) return fps_cluster_ws_bytes(B);   // cluster kernel's exchange slots
+  if (N <= (int64_t)512 * 100) {   // sort buffers + sorted records of the pruned kernel / the cluster kernel's exchange slots
+    const size_t c = fps_cluster_ws_bytes(B);
+    const size_t l2 = fps_sort_ws(nullptr, B, N).total;
+    return l2 > c ? l2 : c;
+  }
   return (size_t)B * (size_t)N * sizeof(float);
 }
 

@@ -60,11 +60,13 @@ def test_fps_pruned_variant_is_exact(F, oracle, dev, monkeypatch, N, M, variant)
     assert np.array_equal(F.farthest_point_sample(_t(pts, dev), M).cpu().numpy(), got)
 
 
-@pytest.mark.parametrize("mode", ["cluster", "hybrid"])
+@pytest.mark.parametrize("mode", ["auto", "cluster", "hybrid"])
 def test_fps_hybrid_kernel_large_cloud(F, oracle, dev, monkeypatch, mode):
-    """25 600 < N <= 51 200.  cluster (default): two workgroups per scene, each with half of the
-    points in registers, the local winners exchanged through L2 every step; hybrid
-    (S4G_FPS_MODE=hybrid): one workgroup, x + min-distance in registers, y / z re-read from L2."""
+    """25 600 < N <= 51 200.  auto (default): one workgroup per scene, pruned, min-distances in
+    registers and the coordinates of touched groups read from the Morton-sorted records in L2;
+    cluster: two workgroups per scene, each with half of the points in registers, the local
+    winners exchanged through L2 every step; hybrid: one workgroup, full scan, x + min-distance
+    in registers, y / z re-read from L2."""
     monkeypatch.setenv("S4G_FPS_MODE", mode)
     pts = synth.make_batch([2], 51200)
     got = F.farthest_point_sample(_t(pts, dev), 300).cpu().numpy()
@@ -75,11 +77,13 @@ def test_fps_hybrid_kernel_large_cloud(F, oracle, dev, monkeypatch, mode):
         assert np.array_equal(got, oracle.fps(pts, 200)), (n, variant)
 
 
+@pytest.mark.parametrize("mode", ["auto", "cluster"])
 @pytest.mark.parametrize("variant", ["tabletop-v1", "dup-heavy"])
-def test_fps_cluster_full_size_batch_ties_and_fmad(F, oracle, dev, variant):
-    """configs[4] geometry: FPS 51 200 -> 5 120 with ALL 5 119 steps, three scenes (six cooperating
-    workgroups), exact ties that straddle the two halves (duplicate-heavy cloud), both arithmetic
-    contracts; the int32 + centroid-gather entry point of the fast path agrees."""
+def test_fps_cluster_full_size_batch_ties_and_fmad(F, oracle, dev, monkeypatch, variant, mode):
+    """configs[4] geometry: FPS 51 200 -> 5 120 with ALL 5 119 steps, three scenes, exact ties
+    (duplicate-heavy cloud; in cluster mode they straddle the two cooperating workgroups), both
+    arithmetic contracts; the int32 + centroid-gather entry point of the fast path agrees."""
+    monkeypatch.setenv("S4G_FPS_MODE", mode)
     pts = synth.make_batch([0, 1, 7], 51200, variant=variant)
     got = F.farthest_point_sample(_t(pts, dev), 5120).cpu().numpy()
     assert np.array_equal(got, oracle.fps(pts, 5120))
