@@ -769,7 +769,13 @@ int launch_grid_build(const float* xyz, int64_t B, int64_t N, float inv_h, GridW
   hipLaunchKernelGGL(bq_grid_build_kernel<P>, dim3(GR_RANGES, (unsigned)B), dim3(GR_BUILD_THREADS), \
                      0, st, xyz, (int)N, inv_h, ws, write_aos ? 1 : 0, (const float*)nullptr, 0, \
                      CellWs{nullptr, nullptr, nullptr}, inv_h_dev)
-  if (N <= 8 * GR_BUILD_THREADS) S4G_GB_LAUNCH(8);
+  // S4G_GRID_BUILD=loop: the streaming variant for every size.  The register-resident workgroups
+  // (1024 threads x up to 128 registers) need a whole free CU: alone they are faster (36 -> 20 us at
+  // 16 x 25 600 points), underneath a saturating contraction stream they wait longer for one
+  // (ball query 0.19 -> 0.42 ms per batch; the step time does not move, geometry has slack there).
+  static const bool loop = [] { const char* e = getenv("S4G_GRID_BUILD"); return e && e[0] == 'l'; }();
+  if (loop) S4G_GB_LAUNCH(0);
+  else if (N <= 8 * GR_BUILD_THREADS) S4G_GB_LAUNCH(8);
   else if (N <= 25 * GR_BUILD_THREADS) S4G_GB_LAUNCH(25);
   else S4G_GB_LAUNCH(0);
 #undef S4G_GB_LAUNCH
