@@ -1746,9 +1746,13 @@ static int launch_gemm_f16x2(const GemmParams& p, int groups, hipStream_t st) {
   }
   // the INTERP / GATHER loaders hold too much per-row state for the wide tile's
   // 128 accumulator registers (they would spill)
+  // ... and 256-wide tiles only pay when they still fill the chip twice over: measured on the
+  // nine single-layer launches of a step, the 128-wide tile is 7-28 % faster below 512 workgroups
+  // and for Cout <= 256, the 256-wide one 12-16 % faster above
+  const int64_t wide_wgs = (int64_t)((p.P + GM_BM - 1) / GM_BM) * ((p.Cout + 255) / 256) * groups;
   const bool wide = force ? force == 4
-                          : p.Cout > 128 && (LOADER == LOAD_PLAIN || LOADER == LOAD_GATHER_MLP1 ||
-                                             LOADER == LOAD_GATHER_ADD);
+                          : p.Cout > 256 && wide_wgs >= 512 &&
+                                (LOADER == LOAD_PLAIN || LOADER == LOAD_GATHER_MLP1 || LOADER == LOAD_GATHER_ADD);
   if (wide) return launch_gemm_f16x2_cfg<LOADER, EPI, 4, PL>(p, groups, st);
   return launch_gemm_f16x2_cfg<LOADER, EPI, 2, PL>(p, groups, st);
 }
