@@ -55,8 +55,10 @@ TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    # defaults: a timed region of ~0.5 s (long enough for an external GPU-busy sampler to see it,
+    # and for the one pipeline fill inside it to stop mattering)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="scenes per GPU per step")
     ap.add_argument("--points", type=int, default=25600)
     ap.add_argument("--impl", default="auto", choices=["auto", "fused", "modules"])

@@ -28,8 +28,8 @@ for d in default cfg4; do
   [ -n "$db" ] && python3 $R/tools/rocpd_summary.py $db 45 > $O/${d}_kernel_stats.md
 done
 # un-profiled lines of the same build, for the record
-python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_default.json 2>/dev/null
-python3 $R/bench.py $CFG4 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_cfg4.json 2>/dev/null
+python3 $R/bench.py > $O/bench_default.json 2>/dev/null
+python3 $R/bench.py $CFG4 --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_cfg4.json 2>/dev/null
 # keep only what the summaries need (the raw trace databases are large)
 find $O -name "*.db" -delete
 find $O -name "*kernel_trace.csv" -delete
