@@ -3,22 +3,29 @@
 // Replaces FarthestPointSampleKernel (reference
 // pointnet2_utils/csrc/sampling_kernel.cu:49-119, host :128-172).
 //
-// Design (MI355X-first, not the reference's shape):
-//   * one 1024-thread workgroup (16 waves, one CU) per scene; the scene's xyz
-//     AND the running min-distance live in VGPRs for the whole kernel
-//     (N <= 25600: 25 points x 4 floats per thread), so a step touches no
-//     memory except one 8-byte index store;
-//   * a step = 25 distance updates per lane, a DPP wave-argmax, ONE
-//     workgroup barrier with a double-buffered 16-slot LDS exchange that also
-//     carries the winner's coordinates (no dependent global load per step);
-//   * the reference's tie rule is reproduced exactly through a composite key:
-//     maximise d, then minimise (bitrev_{log2 bs}(j mod bs) << 23 | j), where
-//     bs = clamp(pow2ceil(N),16,512) is the REFERENCE's block size
-//     (sampling_kernel.cu:34-42,148-167) -- see SURVEY.md Appendix A.1.
-//     Thread t owns points j = t + 1024 p, so all its points share j mod bs
-//     and an ascending-p strict '>' scan resolves ties inside a thread.
-//   * larger clouds fall back to a streaming kernel (xyz from L2, min-distance
-//     in a global workspace).
+// Design (MI355X-first, not the reference's shape).  FPS is a chain of M dependent steps; what a
+// step costs is latency, so every variant keeps the state of a scene on ONE CU (or two) and
+// touches memory as little as possible:
+//   * fps_reg_kernel        N <= 25 600: one 512-thread workgroup per scene, xyz AND the running
+//                           min-distances in VGPRs (50 points x 4 floats per lane); a step = the
+//                           distance updates, a DPP wave-argmax and ONE barrier with a
+//                           double-buffered LDS exchange that also carries the winner's
+//                           coordinates (no dependent global load);
+//   * fps_pruned_kernel     10 240 < N <= 25 600 (default there): the scene in Morton order, 64-point
+//                           groups with a box and an exact maximum each; a step rescans only the
+//                           groups the new centroid can still change (exact: the bound uses the
+//                           distance contract's own monotone arithmetic); two picks per exchange
+//                           where the runner-up is out of the winner's reach;
+//   * fps_pruned_l2_kernel  25 600 < N <= 51 200 (default there): the same, with only the
+//                           min-distances resident and the coordinates of a touched group read
+//                           from the Morton-sorted records in L2 -- one CU per scene;
+//   * fps_cluster_kernel / fps_hybrid_kernel: full scans for that size on two CUs / one CU
+//                           (S4G_FPS_MODE=cluster|hybrid), fps_stream_kernel beyond 51 200.
+// The reference's tie rule is reproduced exactly through a composite key: maximise d, then
+// minimise (bitrev_{log2 bs}(j mod bs) << 23 | j), where bs = clamp(pow2ceil(N),16,512) is the
+// REFERENCE's block size (sampling_kernel.cu:34-42,148-167) -- see SURVEY.md Appendix A.1.  In
+// the full-scan kernels thread t owns points j = t + THREADS p, so all its points share j mod bs
+// and an ascending-p strict '>' scan resolves ties inside a thread.
 #include <stdlib.h>
 #include <string.h>
 
