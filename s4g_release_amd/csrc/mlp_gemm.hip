@@ -1,4 +1,4 @@
-// Shared-MLP contraction on the fp32 matrix cores of gfx950.
+// Shared-MLP contraction on the matrix cores of gfx950.
 //
 // Replaces, for inference, what the reference spreads over cuDNN/cuBLAS and
 // ATen kernels per layer (reference nn_utils/conv.py:28-34,68-74: 1x1 conv ->
@@ -20,7 +20,20 @@
 //           (modules.py:42-50; K order is [feat, xyz] -- W is permuted to match)
 //   INTERP  feature propagation: row = [sum_k w_k * sparse[idx_k] | dense[p]]
 //           (modules.py:118-127, interpolate_kernel.cu:160-174)
-// Arithmetic: v_mfma_f32_32x32x2_f32 -- exact fp32 products, fp32 accumulate
+//   GATHER_MLP1 / GATHER_ADD / INTERP_ADD  the level's (linear) first layer applied before the
+//           grouping / interpolation and finished inside this loader (see ALoader)
+//
+// Kernels in this file, oldest first (each has its own header further down):
+//   mlp_gemm_kernel                  fp32 MFMA (v_mfma_f32_32x32x2_f32), the exact mode described here
+//   mlp_gemm_bf16x3_kernel           three bf16 planes, six products: exact-class alternative
+//   mlp_gemm_f16x2_kernel            two fp16 planes, three products (fp32-class; PL = 1: one bf16
+//                                    plane): the tiled single-layer form, both operands through LDS
+//   mlp_gemm_f16x2_resident_kernel   short contractions with the A panel resident in LDS
+//   mlp_chain_kernel                 two or three layers per launch, intermediates in LDS, W streamed
+//                                    in MFMA-fragment order: the kernels the shipped network runs on
+// (the four heads as one launch live in mlp_heads.hip, helpers shared by both in mlp_common.h).
+//
+// Arithmetic of the fp32 kernel: v_mfma_f32_32x32x2_f32 -- exact fp32 products, fp32 accumulate
 // (bit-for-bit a k-ordered fmaf chain), so results stay within fp32 round-off
 // of the reference's fp32 convolution (tested to 1e-4 abs on the outputs).
 //
