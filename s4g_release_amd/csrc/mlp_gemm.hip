@@ -160,12 +160,29 @@ struct ALoader {
   size_t drow[RPT];
 
   __device__ __forceinline__ void init(const GemmParams& p, int p0, int g, int t) {
+    constexpr bool GATHERS = LOADER == LOAD_GATHER_MLP1 || LOADER == LOAD_GATHER_ADD || LOADER == LOAD_GATHER;
+    // Pass 1: every row's position and -- for the gathering loaders -- its neighbour index.  The
+    // index loads are unconditional (a row past the end reads row 0's) and all issued before the
+    // first dependent gather: one round trip for the thread's rows instead of one per row (a
+    // load behind a per-row guard is not hoisted over the previous row's wait).
+    int pp_[RPT], j_[RPT], b_[RPT], m_[RPT];
 #pragma unroll
     for (int s = 0; s < RPT; ++s) {
       const int r = (t >> 3) + RS * s;
       const int pos = p0 + r;
       ok[s] = pos < p.P;
-      const int pp = ok[s] ? pos : 0;
+      pp_[s] = ok[s] ? pos : 0;
+      j_[s] = b_[s] = m_[s] = 0;
+      if constexpr (GATHERS) {
+        if (!(LOADER == LOAD_GATHER_MLP1 && p.rel4)) {
+          gather_row_bm(p.M, p.K, p0, ok[s] ? r : 0, b_[s], m_[s]);   // (a row past the end: the tile's first row)
+          j_[s] = p.gidx[pp_[s]];
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < RPT; ++s) {
+      const int pp = pp_[s], j = j_[s], b = b_[s], m = m_[s];
       if constexpr (LOADER == LOAD_PLAIN) {
         src0[s] = p.A + (size_t)pp * p.lda + p.a_coff + g * p.a_gcol;
       } else if constexpr (LOADER == LOAD_GATHER_MLP1) {
@@ -176,9 +193,6 @@ struct ALoader {
           rel[s][2] = r4.z;
           continue;
         }
-        int b = 0, m = 0;
-        if (ok[s]) gather_row_bm(p.M, p.K, p0, r, b, m);
-        const int j = p.gidx[pp];
         const float* x = p.xyz + (size_t)b * 3 * p.N;
         const float* c = p.ctr + (size_t)b * 3 * p.M;
         rel[s][0] = __fsub_rn(x[j], c[m]);
@@ -187,9 +201,6 @@ struct ALoader {
       } else if constexpr (LOADER == LOAD_GATHER_ADD) {
         // first SA layer applied to the level's features BEFORE the grouping (it is linear):
         // A[p][k] = relu(F[b*N + j][k] + w1[k] . (xyz_j - ctr_m, 1))
-        int b = 0, m = 0;
-        if (ok[s]) gather_row_bm(p.M, p.K, p0, r, b, m);
-        const int j = p.gidx[pp];
         src0[s] = p.feat + ((size_t)b * p.N + j) * p.Cf;
         const float* x = p.xyz + (size_t)b * 3 * p.N;
         const float* c = p.ctr + (size_t)b * 3 * p.M;
@@ -197,9 +208,6 @@ struct ALoader {
         rel[s][1] = __fsub_rn(x[p.N + j], c[p.M + m]);
         rel[s][2] = __fsub_rn(x[2 * p.N + j], c[2 * p.M + m]);
       } else if constexpr (LOADER == LOAD_GATHER) {
-        int b = 0, m = 0;
-        if (ok[s]) gather_row_bm(p.M, p.K, p0, r, b, m);
-        const int j = p.gidx[pp];
         src0[s] = p.feat ? p.feat + ((size_t)b * p.N + j) * p.Cf : nullptr;
         if ((t & 7) == ((p.Cf & 31) >> 2)) {   // the lane whose 4-float chunk holds the xyz columns
           const float* x = p.xyz + (size_t)b * 3 * p.N;
@@ -210,10 +218,10 @@ struct ALoader {
           rel[s][2] = __fsub_rn(x[2 * p.N + j], c[2 * p.M + m]);
         }
       } else {   // INTERP, INTERP_ADD
-        const int b = pp / p.N1;
+        const int bq = pp / p.N1;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          i3[s][k] = b * p.N2 + p.nidx[(size_t)pp * 3 + k];
+          i3[s][k] = bq * p.N2 + p.nidx[(size_t)pp * 3 + k];
           w3[s][k] = p.nw[(size_t)pp * 3 + k];
         }
         drow[s] = (size_t)pp;
@@ -1320,22 +1328,15 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
   const int wave = t >> 6;
   const int p0 = blockIdx.x * BM;
 
-  float amax = PL == 2 ? p.a_amax_floor : 1.f;
   constexpr bool ADD_BOUNDS = LOADER == LOAD_GATHER_ADD || LOADER == LOAD_INTERP_ADD;   // the loader SUMS its inputs
   const int p_hi = min(p0 + BM, p.P) - 1;   // rows of this tile: [p0, p_hi]
-  if (PL == 2 && p.a_amax) {
-    const float m = amax_rows(p.a_amax, lane, p0, p_hi, p.rps);
-    amax = ADD_BOUNDS ? amax + m : fmaxf(amax, m);
-  }
-  if (PL == 2 && p.a_amax2) {
-    const float m = amax_rows(p.a_amax2, lane, p0, p_hi, p.rps);
-    amax = ADD_BOUNDS ? amax + m : fmaxf(amax, m);
-  }
-  uint32_t ex = __float_as_uint(amax) >> 23;
-  ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
-  ex = __builtin_amdgcn_readfirstlane(ex);
-  const float sa = PL == 2 ? __uint_as_float((268u - ex) << 23) : 1.f;
-  const float inv_sa = PL == 2 ? __uint_as_float((ex - 14u) << 23) : 1.f;
+  // The input maxima of this tile's scene are REQUESTED here and reduced after the W prefetch and
+  // the loader's own loads have been issued (vector loads return in order: asked for first, they
+  // cost no round trip of their own; reduced first, each was one before anything else started).
+  const int am_s0 = p.rps > 0 ? p0 / p.rps : 0, am_s1 = p.rps > 0 ? p_hi / p.rps : 0;
+  float am_v1 = 0.f, am_v2 = 0.f;
+  if (PL == 2 && p.a_amax) am_v1 = p.a_amax[(size_t)am_s0 * 64 + lane];
+  if (PL == 2 && p.a_amax2) am_v2 = p.a_amax2[(size_t)am_s0 * 64 + lane];
 
   const int wr = wave / CW, wc = wave % CW;
   const int li = lane & 31, lh = lane >> 5;
@@ -1377,6 +1378,23 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
   ALoader<LOADER, RPT, RS> ld;
   ld.init(p, p0, g, t);
   S4G_STAMP(1);
+  // activation scale of the loader's rows (per scene; a tile that straddles scenes joins their rows)
+  float amax = PL == 2 ? p.a_amax_floor : 1.f;
+  if (PL == 2 && p.a_amax) {
+    float m = __uint_as_float(wave_max_u32(__float_as_uint(am_v1)));
+    for (int sc = am_s0 + 1; sc <= am_s1; ++sc) m = fmaxf(m, amax_slots(p.a_amax + (size_t)sc * 64, lane));
+    amax = ADD_BOUNDS ? amax + m : fmaxf(amax, m);
+  }
+  if (PL == 2 && p.a_amax2) {
+    float m = __uint_as_float(wave_max_u32(__float_as_uint(am_v2)));
+    for (int sc = am_s0 + 1; sc <= am_s1; ++sc) m = fmaxf(m, amax_slots(p.a_amax2 + (size_t)sc * 64, lane));
+    amax = ADD_BOUNDS ? amax + m : fmaxf(amax, m);
+  }
+  uint32_t ex = __float_as_uint(amax) >> 23;
+  ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
+  ex = __builtin_amdgcn_readfirstlane(ex);
+  const float sa = PL == 2 ? __uint_as_float((268u - ex) << 23) : 1.f;
+  const float inv_sa = PL == 2 ? __uint_as_float((ex - 14u) << 23) : 1.f;
   // columns [kc * K, kc * K + K) of the loader's rows -> two fp16 planes.  DEPTH K-tiles of
   // loads are in flight at a time: the whole panel in the prologue (one round trip), two
   // tiles for the later chunks of a deep first layer (accumulators and ring are live then)
