@@ -422,7 +422,10 @@ def main():
                               "fp32_equivalent_TFLOPs": round(dense_tf, 2),
                               "fp32_equivalent_vs_fp32_mfma_peak": round(dense_tf / FP32_MFMA_PEAK_TF, 4),
                               "GFLOP_per_step_fp32_equivalent": round(gemm_flops / 1e9, 1),
-                              "ms_per_step": round(gemm_ms, 3)}
+                              "ms_per_step": round(gemm_ms, 3),
+                              "peak_note": "peak is the nominal 2.4 GHz figure; PMC (GRBM_GUI_ACTIVE / wall time, "
+                                           "profiles/r02_pmc_counters.md) shows these kernels clocked at 1.6-2.1 GHz "
+                                           "under the power budget, i.e. 0.67-0.87 of that peak is all the clock leaves"}
         else:
             roofline_dense = {"kernel": "mlp_gemm_kernel (v_mfma_f32_32x32x2_f32), all launches of one step",
                               "bound": "mfma", "achieved": round(dense_tf, 2),
