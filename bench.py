@@ -456,9 +456,11 @@ def main():
         # torch's CPU convolutions do not scale to hundreds of threads on these short layers (256
         # threads measured 13x SLOWER than 8): time the scene at a few team sizes, report the best
         best = None
+        from oracle import oracle as _oracle
         for nt in sorted({min(ncores, 16), min(ncores, 64)}):
-            torch.set_num_threads(nt)
-            os.environ["OMP_NUM_THREADS"] = str(nt)
+            torch.set_num_threads(nt)        # torch's own conv / BN thread pool
+            _oracle.set_threads(nt)          # the C operators' OpenMP team (the environment variable is
+                                             # only read when the OpenMP runtime starts)
             t1 = time.perf_counter()
             ref = pn2_forward.forward(sd, one, cfg.num_centroids, cfg.radius, cfg.num_neighbours)
             dt = time.perf_counter() - t1

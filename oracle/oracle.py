@@ -49,6 +49,8 @@ def lib():
         build()
         _lib = ctypes.CDLL(_LIB_PATH)
         L = _lib
+        L.s4g_oracle_set_threads.argtypes = [ctypes.c_int]
+        L.s4g_oracle_set_threads.restype = ctypes.c_int
         for name in ("s4g_oracle_fps", "s4g_oracle_fps_literal"):
             getattr(L, name).argtypes = [_f32p, _i64, _i64, _i64, _i64p, ctypes.c_int]
         L.s4g_oracle_ball_query.argtypes = [_f32p, _f32p, _i64, _i64, _i64, ctypes.c_float,
@@ -182,3 +184,9 @@ def three_interpolate_backward(grad_out, index, weight, num_inst):
                                                        B, C, num_inst, N1, _fp(gin)),
            "three_interpolate_backward")
     return gin
+
+
+def set_threads(n):
+    """Team size of the C operators' OpenMP loops from now on (OMP_NUM_THREADS is only read when
+    the OpenMP runtime starts); returns the size in effect."""
+    return int(lib().s4g_oracle_set_threads(int(n)))

@@ -8,7 +8,10 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libs4g_hip.so")
+# S4G_HIP_LIB: another build of the SAME sources (measurement builds with parts compiled out,
+# tools/ablate_kernels.sh); never a different implementation -- the ABI version and every
+# declared symbol are checked either way
+LIB_PATH = os.environ.get("S4G_HIP_LIB") or os.path.join(_HERE, "libs4g_hip.so")
 
 S4G_ABI_VERSION = 5
 S4G_FLAG_FMAD = 1

@@ -616,7 +616,7 @@ __global__ __launch_bounds__(THREADS) void fps_cluster_kernel(
       dead = gsl.d != 0u;
     }
     if (t == 0 && h == 0) {
-      out[i] = (IdxT)cur;
+      out[i] = dead ? (IdxT)-1 : (IdxT)cur;   // a scene whose partner never answered is marked, not guessed
       if (cout) {
         cout[i] = cx;
         cout[M + i] = cy;
@@ -950,6 +950,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
   // SPEC: an exchange may settle TWO picks (fps_block_exchange2); both centroids are then applied
   // before the next candidates are taken (the updates commute: each is a running minimum).
   int npend = 1;                       // centroids whose update is still due: (cx,cy,cz)[, (rx,ry,rz)]
+  int xpar = 0;                        // LDS exchange buffer of the next exchange
   int rcur = 0;
   float rx = 0.f, ry = 0.f, rz = 0.f;
   for (int i = i0; i < M;) {
@@ -1072,8 +1073,11 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
       wtie = best_key;
     }
     if constexpr (SPEC) {
-      const bool two = fps_block_exchange2<WAVES, FMAD>(slots[i & 1], wave, lane, wmax, wtie, wd2, sx, sy, sz,
+      // buffer parity per EXCHANGE, not per step: a double pick advances i by two, and slots[i & 1]
+      // would then be rewritten by a fast wave while a slow one still reads the previous exchange
+      const bool two = fps_block_exchange2<WAVES, FMAD>(slots[xpar], wave, lane, wmax, wtie, wd2, sx, sy, sz,
                                                         cur, cx, cy, cz, rcur, rx, ry, rz) && i + 1 < M;
+      xpar ^= 1;
       if (t == 0) {
         out[i] = (IdxT)cur;
         if (two) out[i + 1] = (IdxT)rcur;
@@ -1181,6 +1185,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
   }
 
   int npend = 1;
+  int xpar = 0;
   int rcur = 0;
   float rx = 0.f, ry = 0.f, rz = 0.f;
   for (int i = 1; i < M;) {
@@ -1295,8 +1300,9 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
       if (nbest > 1) wd2 = wmax;
       wtie = best_key;
     }
-    const bool two = fps_block_exchange2<WAVES, FMAD>(slots[i & 1], wave, lane, wmax, wtie, wd2, sx, sy, sz, cur,
+    const bool two = fps_block_exchange2<WAVES, FMAD>(slots[xpar], wave, lane, wmax, wtie, wd2, sx, sy, sz, cur,
                                                       cx, cy, cz, rcur, rx, ry, rz) && i + 1 < M;
+    xpar ^= 1;   // per exchange (a double pick advances i by two)
     if (t == 0) {
       out[i] = (IdxT)cur;
       if (two) out[i + 1] = (IdxT)rcur;
@@ -1345,7 +1351,10 @@ static FpsSortWs fps_sort_ws(void* base, int64_t B, int64_t N) {
     return r;
   };
   w.bbox = (float*)take(sizeof(float) * 6 * B);
-  w.gbox = (float*)take(sizeof(float) * 6 * B * ((N + 63) / 64 + 256));
+  // fps_pruned_l2_kernel's box pass always writes 8 * 100 groups per scene (fewer real groups for
+  // 25 600 < N < 34 816): size for whichever is larger
+  const int64_t gbox_groups = (N + 63) / 64 + 256 > 800 ? (N + 63) / 64 + 256 : 800;
+  w.gbox = (float*)take(sizeof(float) * 6 * B * gbox_groups);
   w.md = (float*)take(sizeof(float) * n);
   w.key_in = (uint64_t*)take(sizeof(uint64_t) * n);
   w.key_out = (uint64_t*)take(sizeof(uint64_t) * n);
@@ -1358,7 +1367,7 @@ static FpsSortWs fps_sort_ws(void* base, int64_t B, int64_t N) {
 }
 
 // 25 600 < N <= 51 200: the one-CU pruned kernel with coordinates in L2 (default),
-// S4G_FPS_MODE=cluster the two-CU full scan, =hybrid the one-CU full scan
+// S4G_FPS_MODE=cluster the two-CU full scan (opt-in, B <= 128), =hybrid the one-CU full scan
 static bool fps_use_pruned_l2(int64_t N, int64_t M) {
   if (N <= (int64_t)512 * 50 || N > FPS_L2_CAP || M < 64) return false;
   const char* e = getenv("S4G_FPS_MODE");
@@ -1389,9 +1398,16 @@ static int ref_block_lg(int64_t n) {
   return cnt;
 }
 
-static bool fps_use_cluster() {   // S4G_FPS_MODE=hybrid: the single-CU kernel for 25 600 < N <= 51 200
+// The two-CU kernel is OPT-IN (S4G_FPS_MODE=cluster) and only taken when both workgroups of every
+// scene can be resident at once (2 B workgroups of 512 threads, one per CU, on 256 CUs): its two
+// halves spin on each other, and HIP guarantees no co-residency beyond what fits the chip.  A
+// partner that never answers sets the error word AND turns every later index of that scene into
+// -1 (the caller sees an impossible index instead of a plausible wrong one).  Everything else in
+// this size range that cannot take the pruned kernel (M < 64, workspace too small) runs the
+// single-CU hybrid kernel, which has no such requirement.
+static bool fps_use_cluster(int64_t B) {
   const char* e = getenv("S4G_FPS_MODE");
-  return !(e && e[0] == 'h');
+  return e && e[0] == 'c' && 2 * B <= 256;
 }
 static size_t fps_cluster_ws_bytes(int64_t B) { return (size_t)B * 4 * sizeof(FpsXch) + 64; }
 
@@ -1511,9 +1527,9 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
       return S4G_OK;
     }
   }
-  // two workgroups per scene, all points in registers, winners exchanged through L2 once per
-  // step (S4G_FPS_MODE=hybrid keeps the single-CU kernel below)
-  if (N <= (int64_t)512 * 100 && fps_use_cluster() && ws && ws_bytes >= fps_cluster_ws_bytes(B)) {
+  // opt-in: two workgroups per scene, all points in registers, winners exchanged through L2 once
+  // per step (see fps_use_cluster for the co-residency requirement)
+  if (N <= (int64_t)512 * 100 && fps_use_cluster(B) && ws && ws_bytes >= fps_cluster_ws_bytes(B)) {
     FpsXch* xch = (FpsXch*)ws;
     int* err = (int*)((char*)ws + (size_t)B * 4 * sizeof(FpsXch));
     const hipError_t e = hipMemsetAsync(ws, 0, fps_cluster_ws_bytes(B), stream);

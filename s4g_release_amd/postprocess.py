@@ -62,9 +62,71 @@ REAL2TRAIN = ((0., 1., 0., 0.), (1., 0., 0., 0.), (0., 0., -1., 0.), (0., 0., 0.
 TRAIN2REAL = REAL2TRAIN                               # :27 (the matrix is its own inverse)
 
 
+def _detect_poses_as_written(predictions, scene_points, score_threshold, verticalness_threshold,
+                             direction_matrix, vertical_direction, frame, max_poses):
+    """`GraspDetector.post_processing` with the reference's indexing EXACTLY as written
+    (grasp_detector.py:149-167), on the device.  Two quirks of those lines are reproduced:
+      * :150-153 `index_high2low` (positions inside `high_score_index`, best score first) indexes
+        the POINT axis of `frame_R`;
+      * :154 `rotation.transpose(0, 1)` is a numpy call, i.e. the identity permutation, so the
+        (9, n) array is reshaped row-major into n 3x3 blocks: block m, entry e is the flat element
+        f = 9 m + e of the (9, n) array = frame_R[f // n, index_high2low[f % n]].
+    Block m is then paired with point high_score_index[m] (:160-167); survivors of the verticalness
+    test keep ASCENDING point order.  The expected score is formed like the reference's (fp32
+    softmax, float64 weighted sum) so that thresholding and ordering see the same numbers."""
+    xyz = _F._f32c(scene_points, "scene_points")
+    B, _, N = xyz.shape
+    dev = xyz.device
+    K = min(int(max_poses), N)
+    dm = torch.eye(3, dtype=torch.float64, device=dev) if direction_matrix is None else \
+        torch.as_tensor(direction_matrix, dtype=torch.float64, device=dev)
+    v = torch.as_tensor(vertical_direction, dtype=torch.float32, device=dev).double()
+    vals = torch.linspace(0, 1, predictions["score"].shape[1] + 1, dtype=torch.float64, device=dev)[1:]
+    bins = torch.tensor(T_BINS[:predictions["frame_t"].shape[1]], dtype=torch.float32, device=dev)
+    fr = torch.as_tensor(frame, dtype=torch.float32, device=dev)
+    H = torch.zeros((B, K, 4, 4), dtype=torch.float32, device=dev)
+    top = torch.zeros((B, K), dtype=torch.float32, device=dev)
+    sel = torch.full((B, K), -1, dtype=torch.int64, device=dev)
+    count = torch.zeros((B,), dtype=torch.int64, device=dev)
+    for b in range(B):       # ragged per scene (the reference itself only accepts B == 1, :49)
+        prob = torch.softmax(predictions["score"][b].float(), dim=0)                  # :143
+        score = (vals.view(-1, 1) * prob.double()).sum(dim=0)                          # :145-146
+        high = torch.nonzero(score > score_threshold).flatten()                        # :149
+        n = int(high.numel())
+        if n == 0:
+            continue
+        h2l = torch.argsort(score[high], descending=True)                              # :150
+        flat = predictions["frame_R"][b].float()[:, h2l].reshape(-1)                   # :153, (9 n,)
+        rot = flat.view(n, 3, 3)                                                       # :154
+        xdir = -(dm @ rot[:, :, 0].double().t())                                       # :155, (3, n)
+        vertical = (xdir.t() * v.view(1, 3)).sum(dim=1)                                # :156
+        good = torch.nonzero(vertical > verticalness_threshold).flatten()              # :157
+        valid = high[good][:K]                                                         # :160
+        good = good[:K]
+        m = int(valid.numel())
+        if m == 0:
+            continue
+        # the decode kernel works on (9, m) / (tc, m) / (3, m) columns: hand it the blocks as columns
+        Rm = rot[good].reshape(m, 9).t().contiguous().unsqueeze(0)                     # :164
+        tm = predictions["frame_t"][b].float()[:, valid].contiguous().unsqueeze(0)     # :165
+        pm = xyz[b][:, valid].contiguous().unsqueeze(0)                                # :163
+        ar = torch.arange(m, dtype=torch.int64, device=dev).unsqueeze(0)
+        Hb = torch.empty((1, m, 4, 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _cabi.lib().s4g_decode_poses_f32(pm.data_ptr(), Rm.data_ptr(), tm.data_ptr(),
+                                                  ar.data_ptr(), 1, m, m, tm.shape[1], bins.data_ptr(),
+                                                  Hb.data_ptr(), _F._stream())
+        _cabi.check(rc, "decode_poses")
+        H[b, :m] = torch.matmul(fr.view(1, 4, 4), Hb[0])                               # :180
+        top[b, :m] = score[valid].float()                                              # :167
+        sel[b, :m] = valid
+        count[b] = m
+    return H, top, sel, count
+
+
 def detect_poses(predictions, scene_points, score_threshold=0.7, verticalness_threshold=0.2,
                  direction_matrix=None, vertical_direction=(0.0, 0.0, 1.0), frame=TRAIN2REAL,
-                 max_poses=1024):
+                 max_poses=1024, reference_indexing=False):
     """`GraspDetector.post_processing` (grasp_detector.py:137-185) for a whole batch, on the device
     and without a host round trip: expected score with the detector's class values (:145-146),
     score threshold (:149), survivors in descending score order (:150-151), verticalness filter
@@ -74,8 +136,16 @@ def detect_poses(predictions, scene_points, score_threshold=0.7, verticalness_th
 
     Returns (H (B, max_poses, 4, 4) fp32, score (B, max_poses), index (B, max_poses) int64,
     count (B,) int64): per scene the first count[b] rows are the detections, best first; rows past
-    the count are zero / -1.  Every pose is paired with its own point's rotation and translation
-    (the reference mixes up two index lists there, see oracle/postprocess.py)."""
+    the count are zero / -1.
+
+    Default: every pose is built from its OWN point's rotation and translation, best score first --
+    what the reference's comments describe.  `reference_indexing=True` reproduces what its lines
+    :149-167 actually compute (a position list used as point indices and a numpy transpose that is
+    a no-op; see `_detect_poses_as_written`): same poses, scores and order as the reference, pinned
+    by tests/golden/post_detector.npz which the reference's own function generated."""
+    if reference_indexing:
+        return _detect_poses_as_written(predictions, scene_points, score_threshold, verticalness_threshold,
+                                        direction_matrix, vertical_direction, frame, max_poses)
     xyz = _F._f32c(scene_points, "scene_points")
     R = _F._f32c(predictions["frame_R"], "frame_R")
     t = _F._f32c(predictions["frame_t"], "frame_t")
@@ -146,17 +216,32 @@ class GripperConfig:
         return self.half_bottom_width - self.finger_width
 
 
-def view_non_collision(poses, scene_points, gripper=None):
+def se3_inverse(poses):
+    """`torch_batch_transformation_inv` (utils/math_utils.py:26-40) for (..., 4, 4) fp32 poses:
+    [R^T | -R^T t], the form `GraspDetector.detect` feeds the collision check (grasp_detector.py:219)."""
+    T = poses.float()
+    Rt = T[..., :3, :3].transpose(-1, -2)
+    out = torch.zeros_like(T)
+    out[..., :3, :3] = Rt
+    out[..., :3, 3:] = torch.matmul(-Rt, T[..., :3, 3:])
+    out[..., 3, 3] = 1.0
+    return out.contiguous()
+
+
+def view_non_collision(poses, scene_points, gripper=None, inverse="general"):
     """Batched `CloudCollisionChecker.view_non_collision`
     (cloud_processor/view_collision_checker.py:37-65) for all poses of all scenes
     in one launch.  poses (B,K,4,4) gripper->global frames; returns
-    (ok (B,K) bool, counts (B,K,2) int32).  The inverse is taken in float64 and
-    rounded to fp32 like the reference's caller (file_logger_cls.py:223-224)."""
+    (ok (B,K) bool, counts (B,K,2) int32).  inverse="general": the inverse is taken in float64 and
+    rounded to fp32 like the demo's caller (file_logger_cls.py:223-224); inverse="se3": the fp32
+    analytic SE(3) inverse the detector uses (grasp_detector.py:219, `se3_inverse`)."""
     gripper = gripper or GripperConfig()
     xyz = _F._f32c(scene_points, "scene_points")
     B, _, N = xyz.shape
     K = poses.shape[1]
-    g2l = torch.linalg.inv(poses.double()).float().contiguous()
+    if inverse not in ("general", "se3"):
+        raise ValueError("inverse must be 'general' or 'se3'")
+    g2l = se3_inverse(poses) if inverse == "se3" else torch.linalg.inv(poses.double()).float().contiguous()
     counts = torch.empty((B, K, 2), dtype=torch.int32, device=xyz.device)
     params = (ctypes.c_float * 6)(gripper.finger_length, gripper.bottom_length,
                                   gripper.half_hand_thickness, gripper.half_bottom_width,

@@ -116,3 +116,14 @@ def test_random_preprocessing_matches_oracle(dev, seed):
     nb = int(rng.choice([1, 4, 16, 32]))
     gm = PP.radius_outlier_mask(torch.from_numpy(ref).to(dev), nb, radius).cpu().numpy()
     assert np.array_equal(gm, OP.remove_radius_outlier(ref, nb, radius)), (n, nb, radius, variant)
+
+
+def test_crop_equals_the_reference(dev):
+    """`filter_work_space` against the mask `CloudPreProcessor.filter_work_space`
+    (cloud_processor/cloud_processor.py:12-27) itself produced (tools/gen_golden_post.py)."""
+    import os
+    from s4g_release_amd import preprocess as PP
+    px = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "post_crop.npz"))
+    got = PP.filter_work_space(torch.from_numpy(px["cloud"]).to(dev), tuple(px["workspace"])).cpu().numpy()
+    assert np.array_equal(got, np.nonzero(px["valid"])[0])
+    assert 0 < got.size < px["cloud"].shape[1]
