@@ -29,6 +29,9 @@ Extra objects on the line:
   latency       one batch alone (no pipelining) and the one-scene (B = 1) figures
   io            H2D of the clouds / D2H of the outputs, measured apart (never in `value`)
   kernels       every native launch: mean ms, algorithmic bytes / flops, GB/s / TFLOP/s
+  configs4      BASELINE.json configs[4] (bf16 path, 32 x 51 200-point clouds): scenes/s, ms/step and
+                its own MFMA roofline object, 5 warm + 10 timed steps after the headline region
+  collective    the per-batch all-gather: payload (--gather heads | poses), bytes, the stream it ran on
   cpu_baseline  the CPU oracle forward (oracle/pn2_forward.py) on ONE scene,
                 rank 0 at N == 1 only -- a reported baseline, not the target
 """
@@ -70,6 +73,17 @@ def parse(argv=None):
     ap.add_argument("--no-pipeline", action="store_true",
                     help="collect each batch before submitting the next")
     ap.add_argument("--variant", default="tabletop-v1")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="total scenes per step over all GPUs instead of --batch per GPU; must divide "
+                         "evenly over the ranks (exit code 2 otherwise)")
+    ap.add_argument("--gather", default="heads", choices=["heads", "poses"],
+                    help="payload of the per-batch all-gather (N > 1): the 21 per-point head channels, or "
+                         "the --num-poses best decoded grasp frames per scene (3.6 KB instead of 2.15 MB)")
+    ap.add_argument("--num-poses", type=int, default=50)
+    ap.add_argument("--timer-every", type=int, default=int(os.environ.get("S4G_BENCH_TIMER_EVERY", "1")),
+                    help="HIP event pairs around the native launches of every k-th forward pass only")
+    ap.add_argument("--no-configs4", action="store_true",
+                    help="skip the configs[4] (bf16, 51 200 points, 32 scenes) leg after the timed region")
     ap.add_argument("--precision", default=None, choices=["f16x2", "bf16x3", "fp32", "bf16"],
                     help="contraction arithmetic of the fast path (default f16x2 = fp32-class); "
                          "'bf16' is the reduced-precision roofline configuration (configs[4]), "
@@ -164,6 +178,52 @@ def percentile(xs, q):
     return xs[lo] + (xs[hi] - xs[lo]) * (pos - lo)
 
 
+def dense_roofline(summary, steps_timed, precision, world_note=""):
+    """(`roofline` object of the MFMA contraction launches, `kernels` table) from an OpTimer summary
+    whose launches were timed in `steps_timed` forward passes."""
+    kernels = {}
+    gemm_ms = gemm_flops = 0.0
+    gemm_launches = 0
+    for name, (n, ms, nbytes, flops) in sorted(summary.items()):
+        if flops > 0:
+            kernels[name] = {"launches": n, "ms": round(ms, 5), "GFLOP": round(flops / 1e9, 3),
+                             "TFLOPs": round(flops / ms / 1e9, 2) if ms > 0 else None}
+            gemm_ms += ms * n / steps_timed
+            gemm_flops += flops * n / steps_timed
+            gemm_launches += n
+        else:
+            kernels[name] = {"launches": n, "ms": round(ms, 5), "bytes": int(nbytes),
+                             "GBps": round(nbytes / ms / 1e6, 2) if ms > 0 else None}
+    if gemm_ms <= 0:
+        return None, kernels
+    dense_tf = gemm_flops / gemm_ms / 1e9
+    products = {"bf16": 1, "f16x2": 3, "bf16x3": 6}.get(precision)
+    if products is None:
+        return {"kernel": "mlp_gemm_kernel (v_mfma_f32_32x32x2_f32), all launches of one step",
+                "bound": "mfma", "achieved": round(dense_tf, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(dense_tf / FP32_MFMA_PEAK_TF, 4), "GFLOP_per_step": round(gemm_flops / 1e9, 1),
+                "ms_per_step": round(gemm_ms, 3)}, kernels
+    kname = {"bf16": "mlp_chain_kernel<PL=1> (fused layer chains, one bf16 plane) + mlp_heads_kernel<PL=1> + "
+                     "mlp_gemm_f16x2_kernel<PL=1> (v_mfma_f32_32x32x16_bf16, ONE product per MAC: REDUCED "
+                     "PRECISION, the configs[4] roofline configuration)",
+             "f16x2": "mlp_chain_kernel<PL=2> (fused layer chains) + mlp_heads_kernel<PL=2> + mlp_gemm_f16x2_kernel "
+                      "(v_mfma_f32_32x32x16_f16, 3 products per fp32-equivalent product)",
+             "bf16x3": "mlp_gemm_bf16x3_kernel (v_mfma_f32_32x32x16_bf16, 6 products per "
+                       "fp32-equivalent product)"}[precision]
+    return {"kernel": kname + ", all %d contraction launches of one step; flops = those executed after "
+                              "moving the linear first SA / FP layers in front of the grouping / "
+                              "interpolation" % (gemm_launches // max(steps_timed, 1)),
+            "bound": "mfma", "achieved": round(products * dense_tf, 1), "peak": BF16_MFMA_PEAK_TF,
+            "unit": "TFLOP/s", "frac": round(products * dense_tf / BF16_MFMA_PEAK_TF, 4),
+            "mfma_products_per_mac": products, "fp32_equivalent_TFLOPs": round(dense_tf, 2),
+            "fp32_equivalent_vs_fp32_mfma_peak": round(dense_tf / FP32_MFMA_PEAK_TF, 4),
+            "GFLOP_per_step_fp32_equivalent": round(gemm_flops / 1e9, 1), "ms_per_step": round(gemm_ms, 3),
+            "timed_passes": steps_timed,
+            "peak_note": "peak is the nominal 2.4 GHz figure; measured (profiles/r03_power_clock.md: hwmon power / "
+                         "clock sensors while each kernel runs back to back) these kernels draw 1.24-1.40 kW of the "
+                         "1.40 kW board cap and are clocked at 1.8-2.2 GHz"}, kernels
+
+
 def main():
     argv = sys.argv[1:]
     args = parse(argv)
@@ -180,6 +240,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.global_batch is not None:
+        try:
+            args.batch = sdist.scenes_per_rank(args.global_batch, world)
+        except ValueError as e:
+            print("bench.py: --global-batch: %s" % e, file=sys.stderr)
+            sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -212,6 +278,8 @@ def main():
         runner = net
         impl = "modules"
     precision = getattr(runner, "precision", "library")
+    if impl != "fused":
+        args.timer_every = 1      # only the fast path announces its passes to the timers
 
     B = args.batch
     scene_ids = [rank * B + i for i in range(B)]
@@ -222,19 +290,28 @@ def main():
 
     pipelined = impl == "fused" and not args.no_pipeline
 
-    def finish(pred):
-        if use_dist:
-            return sdist.all_gather_outputs(pred)   # one RCCL all-gather of (B,21,N)
-        return pred
+    # the per-batch collective: packed head outputs (21 channels per point) or, with --gather poses,
+    # the K best decoded grasp frames per scene, on its own stream
+    gather = None
+    if use_dist:
+        decode = None
+        if args.gather == "poses":
+            from s4g_release_amd import postprocess as PP
+            decode = lambda pred, xyz: PP.decode_top_poses(pred, xyz, args.num_poses, "detector")
+        gather = sdist.OutputGather(args.gather, decode=decode, device=dev)
 
-    def run_steps(n, data=batch, pipe=pipelined, marks=None, gather=True):
+    def run_steps(n, run=None, data=None, pipe=None, marks=None, gathered=True):
         """n forward passes over the batch.  Pipelined mode keeps up to `--in-flight`
         batches submitted besides the one being collected: batch i+1's FPS chain
         starts on the geometry stream before batch i's outputs are collected; every
         batch is complete when the trailing fence returns.  `marks` collects one HIP
-        event per completed step (recorded on the collecting stream).  gather=False: no
+        event per completed step (recorded on the collecting stream).  gathered=False: no
         collective (the probes after the timed region run on rank 0 alone)."""
-        fin = finish if gather else (lambda pred: pred)
+        run = runner if run is None else run
+        data = batch if data is None else data
+        pipe = pipelined if pipe is None else pipe
+        fin = (lambda pred: gather(pred, data["scene_points"])) if (gathered and gather is not None) \
+            else (lambda pred: pred)
 
         def mark():
             if marks is not None:
@@ -246,12 +323,12 @@ def main():
         with torch.no_grad():
             if not pipe:
                 for _ in range(n):
-                    fin(runner(data))
+                    fin(run(data))
                     mark()
                 return
             pending = []
             for _ in range(n):
-                pending.append(runner.submit(data))
+                pending.append(run.submit(data))
                 if len(pending) > args.in_flight:
                     fin(pending.pop(0).result())
                     mark()
@@ -259,24 +336,37 @@ def main():
                 fin(pending.pop(0).result())
                 mark()
 
-    run_steps(args.warmup)
-
     def fence():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
-    F.OpTimer.reset(enabled=True)
-    fence()
-    marks = []
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    t0 = time.perf_counter()
-    run_steps(args.steps, marks=marks)
-    fence()
-    elapsed = time.perf_counter() - t0
-    F.OpTimer.enabled = False
+    def timed_region(steps, warmup, **kw):
+        """`warmup` untimed + EXACTLY `steps` timed passes between fences -> (seconds, step_ms, summary,
+        passes whose launches carried event pairs)."""
+        run_steps(warmup, **kw)
+        F.OpTimer.reset(enabled=True, every=args.timer_every)
+        fence()
+        marks = []
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        t0 = time.perf_counter()
+        run_steps(steps, marks=marks, **kw)
+        fence()
+        elapsed = time.perf_counter() - t0
+        F.OpTimer.enabled = False
+        stamps = [ev0.elapsed_time(m) for m in marks]
+        deltas = [b - a for a, b in zip([0.0] + stamps[:-1], stamps)]
+        steady = deltas[1:] if len(deltas) > 1 else deltas
+        step_ms = {"median": round(percentile(steady, 0.5), 3), "p10": round(percentile(steady, 0.1), 3),
+                   "p90": round(percentile(steady, 0.9), 3), "first_step_incl_pipeline_fill": round(deltas[0], 3),
+                   "pipeline_fill": round(max(0.0, deltas[0] - percentile(steady, 0.5)), 3) if len(deltas) > 1 else None,
+                   "n": len(steady), "source": "HIP events after each collected batch"}
+        timed_passes = (steps + args.timer_every - 1) // args.timer_every
+        return elapsed, step_ms, F.OpTimer.summary(), timed_passes
+
+    elapsed, step_ms, summary, timed_passes = timed_region(args.steps, args.warmup)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -290,34 +380,10 @@ def main():
     scenes = world * B * args.steps
     value = scenes / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
-
-    # per-step completion intervals (HIP events on the collecting stream): the first
-    # one contains the pipeline fill (the first batch's geometry runs in front of its
-    # own contractions), the rest is the steady state
-    stamps = [ev0.elapsed_time(m) for m in marks]
-    deltas = [b - a for a, b in zip([0.0] + stamps[:-1], stamps)]
-    steady = deltas[1:] if len(deltas) > 1 else deltas
-    step_ms = {"median": round(percentile(steady, 0.5), 3), "p10": round(percentile(steady, 0.1), 3),
-               "p90": round(percentile(steady, 0.9), 3), "first_step_incl_pipeline_fill": round(deltas[0], 3),
-               "pipeline_fill": round(max(0.0, deltas[0] - percentile(steady, 0.5)), 3) if len(deltas) > 1 else None,
-               "n": len(steady), "source": "HIP events after each collected batch"}
-
-    kernels = {}
-    gemm_ms = gemm_flops = 0.0
-    gemm_launches = 0
-    for name, (n, ms, nbytes, flops) in sorted(F.OpTimer.summary().items()):
-        if flops > 0:
-            kernels[name] = {"launches": n, "ms": round(ms, 5), "GFLOP": round(flops / 1e9, 3),
-                             "TFLOPs": round(flops / ms / 1e9, 2) if ms > 0 else None}
-            gemm_ms += ms * n / args.steps
-            gemm_flops += flops * n / args.steps
-            gemm_launches += n
-        else:
-            kernels[name] = {"launches": n, "ms": round(ms, 5), "bytes": int(nbytes),
-                             "GBps": round(nbytes / ms / 1e6, 2) if ms > 0 else None}
+    roofline_dense, kernels = dense_roofline(summary, timed_passes, precision)
 
     N, M, K = args.points, cfg.num_centroids[0], cfg.num_neighbours[0]
-    roofline = latency = io = None
+    roofline = latency = io = configs4 = None
     if not args.no_extras:
         # ---- one batch alone / one scene: the figures the pipeline hides
         def timed_forward(data, reps):
@@ -334,10 +400,10 @@ def main():
         latency = {"latency_ms_one_batch": round(timed_forward(batch, 5), 3), "batch": B,
                    "latency_ms_b1": round(timed_forward(one, 5), 3)}
         if pipelined:
-            run_steps(3, data=one, gather=False)
+            run_steps(3, data=one, gathered=False)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            run_steps(30, data=one, gather=False)
+            run_steps(30, data=one, gathered=False)
             torch.cuda.synchronize()
             latency["scenes_per_sec_b1"] = round(30 / (time.perf_counter() - t1), 2)
         latency["scenes_per_sec_one_batch_at_a_time"] = round(1e3 * B / latency["latency_ms_one_batch"], 2)
@@ -400,46 +466,34 @@ def main():
             roofline["fused_pair_achieved"] = round(fq[2] / fq[1] / 1e6, 2)
             roofline["fused_pair_frac"] = round(fq[2] / fq[1] / 1e6 / HBM_PEAK_GBS, 4)
 
-    # ---- dominant kernel: every MFMA contraction launch of one step
-    if gemm_ms > 0:
-        dense_tf = gemm_flops / gemm_ms / 1e9
-        products = {"bf16": 1, "f16x2": 3, "bf16x3": 6}.get(precision)
-        if products is not None:
-            kname = {"bf16": "mlp_chain_kernel<PL=1> (fused layer chains, one bf16 plane) + mlp_gemm_bf16x3_kernel in "
-                             "single-product mode (v_mfma_f32_32x32x16_bf16, ONE product per MAC: REDUCED "
-                             "PRECISION, the configs[4] roofline configuration)",
-                     "f16x2": "mlp_chain_kernel<PL=2> (fused layer chains) + mlp_gemm_f16x2_kernel "
-                              "(v_mfma_f32_32x32x16_f16, 3 products per fp32-equivalent product)",
-                     "bf16x3": "mlp_gemm_bf16x3_kernel (v_mfma_f32_32x32x16_bf16, 6 products per "
-                               "fp32-equivalent product)"}[precision]
-            roofline_dense = {"kernel": kname + ", all %d contraction launches of one step; flops = those "
-                                        "executed after moving the linear first SA / FP layers in front of the "
-                                        "grouping / interpolation" % (gemm_launches // args.steps),
-                              "bound": "mfma", "achieved": round(products * dense_tf, 1),
-                              "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                              "frac": round(products * dense_tf / BF16_MFMA_PEAK_TF, 4),
-                              "mfma_products_per_mac": products,
-                              "fp32_equivalent_TFLOPs": round(dense_tf, 2),
-                              "fp32_equivalent_vs_fp32_mfma_peak": round(dense_tf / FP32_MFMA_PEAK_TF, 4),
-                              "GFLOP_per_step_fp32_equivalent": round(gemm_flops / 1e9, 1),
-                              "ms_per_step": round(gemm_ms, 3),
-                              "peak_note": "peak is the nominal 2.4 GHz figure; PMC (GRBM_GUI_ACTIVE / wall time, "
-                                           "profiles/r02_pmc_counters.md) shows these kernels clocked at 1.6-2.1 GHz "
-                                           "under the power budget, i.e. 0.67-0.87 of that peak is all the clock leaves"}
-        else:
-            roofline_dense = {"kernel": "mlp_gemm_kernel (v_mfma_f32_32x32x2_f32), all launches of one step",
-                              "bound": "mfma", "achieved": round(dense_tf, 2),
-                              "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                              "frac": round(dense_tf / FP32_MFMA_PEAK_TF, 4),
-                              "GFLOP_per_step": round(gemm_flops / 1e9, 1),
-                              "ms_per_step": round(gemm_ms, 3)}
-    else:
+        # ---- BASELINE.json configs[4] on the same line: bf16 grouped-MLP path, 51 200-point clouds,
+        # 32 scenes per step, achieved vs the bf16 MFMA peak (rank 0 alone, no collective)
+        if impl == "fused" and not args.no_configs4 and not (args.points == 51200 and precision == "bf16"):
+            c4_runner = fused_cls(net, precision="bf16")
+            c4_pts = torch.from_numpy(synth.make_batch(list(range(32)), 51200, variant=args.variant)).to(dev)
+            c4_batch = {"scene_points": c4_pts}
+            c4_steps, c4_warm = 10, 5
+            c4_el, c4_step, c4_sum, c4_tp = timed_region(c4_steps, c4_warm, run=c4_runner, data=c4_batch,
+                                                         gathered=False)
+            c4_roof, _ = dense_roofline(c4_sum, c4_tp, "bf16")
+            tb, src, why = load_traffic("contractions[step,B=32,N=51200,precision=bf16]")
+            c4_roof["traffic"] = tb
+            c4_roof["traffic_source" if tb is not None else "traffic_note"] = src if tb is not None else why
+            configs4 = {"workload": "BASELINE.json configs[4]: bf16 grouped-MLP MFMA path, 32 scenes x 51 200-pt "
+                                    "tabletop-v1 clouds per step, single-plane bf16 contraction (fp32 accumulate), "
+                                    "indices bit-exact, pipelined like the headline run",
+                        "value": round(32 * c4_steps / c4_el, 2), "unit": "scenes/sec", "dtype": "bf16",
+                        "ms_per_step": round(1e3 * c4_el / c4_steps, 3), "steps": c4_steps, "warmup": c4_warm,
+                        "step_ms_median": c4_step["median"], "roofline": c4_roof}
+            del c4_runner, c4_pts, c4_batch
+
+    tb, src, why = load_traffic("contractions[step,B=%d,N=%d,precision=%s]" % (B, N, precision))
+    if roofline_dense is None:
         dense_tf = GFLOP_PER_SCENE * value / world / 1e3
         roofline_dense = {"kernel": "whole forward (library GEMMs), dense flops / wall time",
                           "bound": "mfma", "achieved": round(dense_tf, 2),
                           "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                           "frac": round(dense_tf / FP32_MFMA_PEAK_TF, 4)}
-    tb, src, why = load_traffic("contractions[step,B=%d,N=%d,precision=%s]" % (B, N, precision))
     roofline_dense["traffic"] = tb
     if tb is not None:
         roofline_dense["traffic_source"] = src
@@ -449,6 +503,7 @@ def main():
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as _oracle
         from oracle import pn2_forward
         ncores = os.cpu_count() or 1
         sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
@@ -456,16 +511,15 @@ def main():
         # torch's CPU convolutions do not scale to hundreds of threads on these short layers (256
         # threads measured 13x SLOWER than 8): time the scene at a few team sizes, report the best
         best = None
-        from oracle import oracle as _oracle
         for nt in sorted({min(ncores, 16), min(ncores, 64)}):
             torch.set_num_threads(nt)        # torch's own conv / BN thread pool
-            _oracle.set_threads(nt)          # the C operators' OpenMP team (the environment variable is
-                                             # only read when the OpenMP runtime starts)
+            used = _oracle.set_threads(nt)   # the C operators' OpenMP team (OMP_NUM_THREADS is only read
+                                             # when the OpenMP runtime starts)
             t1 = time.perf_counter()
             ref = pn2_forward.forward(sd, one, cfg.num_centroids, cfg.radius, cfg.num_neighbours)
             dt = time.perf_counter() - t1
             if best is None or dt < best[0]:
-                best = (dt, nt)
+                best = (dt, used)
         cpu_s, nt = best
         with torch.no_grad():
             got = runner({"scene_points": pts[:1]})
@@ -485,6 +539,16 @@ def main():
              "fp32": "fp32 MFMA"}.get(precision, "library GEMM")
     pipe_label = (", pipelined: up to %d batches submitted besides the one being collected" % args.in_flight
                   if pipelined else ", one batch at a time")
+    if gather is None:
+        collective = {"op": None, "note": "single process: no collective"}
+    else:
+        collective = {"op": "all_gather_into_tensor (RCCL)", "payload": args.gather,
+                      "payload_bytes_per_rank_per_step": int(gather.payload_bytes),
+                      "stream": gather.last_stream,
+                      "note": "issued on a side stream behind an event of the collecting stream; the next batch's "
+                              "contractions run on their own stream meanwhile"}
+    payload = ("all-gather of 21 ch/point" if args.gather == "heads" else
+               "all-gather of the %d best decoded grasp frames per scene" % args.num_poses)
     line = {
         "metric": "scenes/sec (25.6k-pt clouds) end-to-end grasp inference",
         "value": round(value, 3), "unit": "scenes/sec", "n_gpus": world, "steps": args.steps,
@@ -496,10 +560,13 @@ def main():
                                                                    impl, pipe_label),
                    "scenes_per_gpu": B, "num_points": args.points, "global_batch": world * B,
                    "in_flight": args.in_flight if pipelined else 0,
-                   "parallelism": "scenes sharded over %d GPU(s), all-gather of 21 ch/point" % world},
+                   "kernel_timers": "HIP event pairs around every native launch of every %s forward pass of the "
+                                    "timed region" % ("" if args.timer_every == 1 else "%d-th" % args.timer_every),
+                   "parallelism": "scenes sharded over %d GPU(s), %s" % (world, payload)},
         # `roofline`: the dominant kernel of the step (the MFMA contraction, >90 % of GPU time);
         # `roofline_ball_query_group_points`: the HBM-bound operator pair the north star names.
         "roofline": roofline_dense, "roofline_ball_query_group_points": roofline,
+        "configs4": configs4, "collective": collective,
         "step_ms": step_ms, "latency": latency, "io": io, "kernels": kernels,
         "cpu_baseline": cpu_baseline,
     }

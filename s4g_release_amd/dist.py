@@ -77,8 +77,7 @@ def sharded_forward(runner, scene_points, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     total = scene_points.shape[0]
-    if total % world != 0:
-        raise ValueError("batch of %d scenes does not divide over %d ranks" % (total, world))
+    scenes_per_rank(total, world)        # raises for an uneven split
     lo, hi = shard_range(total, rank, world)
     pred = runner({"scene_points": scene_points[lo:hi]})
     return all_gather_outputs(pred, group)
@@ -92,9 +91,69 @@ def all_gather_poses(H, score, index, group=None):
     B, K = score.shape
     packed = torch.cat([H.reshape(B, K, 16), score.unsqueeze(-1), index.to(H.dtype).unsqueeze(-1)],
                        dim=2).contiguous()
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world > 1:
+    if dist.is_initialized():            # a 1-rank group still takes the collective
+        world = dist.get_world_size(group)
         out = torch.empty((world * B, K, 18), dtype=packed.dtype, device=packed.device)
         dist.all_gather_into_tensor(out, packed, group=group)
         packed = out
     return (packed[..., :16].reshape(-1, K, 4, 4), packed[..., 16], packed[..., 17].long())
+
+
+class OutputGather:
+    """The per-batch collective of the multi-GPU path, issued on its OWN stream.
+
+    mode "heads": one `all_gather_into_tensor` of the packed (B_local, 21, N) head outputs (34 MB per
+    rank at 16 scenes of 25 600 points); mode "poses": the K best grasp frames per scene are decoded
+    on the device first (`decode`, e.g. `postprocess.decode_top_poses`) and one collective moves the
+    packed (B_local, K, 18) tensor instead -- 3.6 KB per scene at K = 50.
+
+    On a HIP device the collective is enqueued on a side stream that waits for the producer's
+    current stream through an event; the caller's stream then waits for the gather's event, so the
+    next batch's contractions (other streams) overlap it by construction and not by accident of the
+    collective library's internal stream.  `last_stream` names where the last gather ran (bench.py
+    records it).  On CPU tensors (gloo functional tests) there are no streams and the call is the
+    plain collective."""
+
+    def __init__(self, mode="heads", decode=None, group=None, device=None):
+        if mode not in ("heads", "poses"):
+            raise ValueError("mode must be 'heads' or 'poses'")
+        if mode == "poses" and decode is None:
+            raise ValueError("mode 'poses' needs a decode(pred, scene_points) -> (H, score, index)")
+        self.mode, self.decode, self.group = mode, decode, group
+        self.stream = torch.cuda.Stream(device=device) if device is not None and device.type == "cuda" else None
+        self.last_stream = "caller"
+        self.payload_bytes = 0
+
+    def _collect(self, pred, scene_points):
+        if self.mode == "poses":
+            H, score, index = self.decode(pred, scene_points)
+            self.payload_bytes = H.shape[0] * H.shape[1] * 18 * 4
+            return all_gather_poses(H, score, index, self.group)
+        self.payload_bytes = sum(v.numel() * v.element_size() for v in pred.values())
+        return all_gather_outputs(pred, self.group)
+
+    def __call__(self, pred, scene_points=None):
+        if self.stream is None:
+            return self._collect(pred, scene_points)
+        cur = torch.cuda.current_stream(self.stream.device)
+        self.stream.wait_event(cur.record_event())
+        with torch.cuda.stream(self.stream):
+            out = self._collect(pred, scene_points)
+            done = self.stream.record_event()
+        for t in list(pred.values()) + ([scene_points] if scene_points is not None else []):
+            t.record_stream(self.stream)
+        cur.wait_event(done)
+        for t in (out.values() if isinstance(out, dict) else out):
+            t.record_stream(cur)
+        self.last_stream = "side stream %#x" % self.stream.cuda_stream
+        return out
+
+
+def scenes_per_rank(global_batch, world):
+    """Scenes each rank runs when a GLOBAL batch is given: it must divide evenly (the gather is one
+    fixed-size collective); bench.py's --global-batch goes through here."""
+    if global_batch <= 0 or world <= 0:
+        raise ValueError("global batch and world size must be positive")
+    if global_batch % world != 0:
+        raise ValueError("batch of %d scenes does not divide over %d ranks" % (global_batch, world))
+    return global_batch // world

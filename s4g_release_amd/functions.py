@@ -65,11 +65,27 @@ class OpTimer:
     current stream), immediately before and after the launch."""
     enabled = False
     records = []   # (op name, start event, end event, algorithmic bytes, flops)
+    every = 1      # time the launches of every `every`-th forward pass only (bench.py: the event
+    _pass = 0      # pairs are barrier packets in the queues they time; sampling keeps them out of
+    _armed = True  # most steps of the timed region)
 
     @classmethod
-    def reset(cls, enabled):
+    def reset(cls, enabled, every=1):
         cls.enabled = enabled
         cls.records = []
+        cls.every = max(1, int(every))
+        cls._pass = 0
+        cls._armed = True
+
+    @classmethod
+    def begin_pass(cls):
+        """Called once per submitted forward pass: arms the timers for one pass in `every`."""
+        cls._armed = cls._pass % cls.every == 0
+        cls._pass += 1
+
+    @classmethod
+    def active(cls):
+        return cls.enabled and cls._armed
 
     @classmethod
     def summary(cls):
@@ -86,14 +102,15 @@ class _timed:
         self.name, self.nbytes, self.flops = name, nbytes, flops
 
     def __enter__(self):
-        if OpTimer.enabled:
+        self.on = OpTimer.active()
+        if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
         return self
 
     def __exit__(self, *exc):
-        if OpTimer.enabled:
+        if self.on:
             self.e1.record()
             OpTimer.records.append((self.name, self.e0, self.e1, self.nbytes, self.flops))
         return False

@@ -666,6 +666,7 @@ class FusedPointNet2:
         if xyz.dim() != 3 or xyz.size(1) != 3:
             raise RuntimeError("scene_points must be (B, 3, N)")
         dev = xyz.device
+        _F.OpTimer.begin_pass()
         if self._streams is None or self._streams[0][0].device != dev:
             # high-priority geometry streams: FPS is a latency chain on one CU per
             # scene, so S4G_GEO_STREAMS (default 2) consecutive batches may run

@@ -47,7 +47,8 @@ def test_b16_full_size_every_scene_equals_itself_alone_and_the_oracle(dev):
             one, i1 = run({"scene_points": pts[s:s + 1].contiguous()}, return_intermediates=True)
             for k in HEADS:
                 worst = max(worst, float((one[k][0] - full[k][s]).abs().max()))
-            for k in ("fps0", "fps1", "fps2", "ball0", "ball2", "nn0", "nn2"):
+            for k in ("fps0", "fps1", "fps2", "ball0", "ball1", "ball2", "cnt0", "cnt1", "cnt2",
+                      "nn0", "nn1", "nn2", "nnw0", "nnw1", "nnw2"):
                 assert torch.equal(i1[k][0], inter[k][s]), (k, s)
     assert worst <= 1e-6, worst
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}

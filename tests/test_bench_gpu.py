@@ -42,6 +42,12 @@ def test_bench_prints_one_contract_line():
     assert lat["latency_ms_one_batch"] > 0 and lat["latency_ms_b1"] > 0 and lat["scenes_per_sec_b1"] > 0
     assert d["io"]["h2d_bytes"] == 16 * 3 * 25600 * 4 and d["io"]["d2h_bytes"] == 16 * 21 * 25600 * 4
     assert "besides the one being collected" in d["config"]["workload"] and d["config"]["in_flight"] == 2
+    # BASELINE.json configs[4] rides on the same line: bf16, 32 x 51 200 points, its own roofline
+    c4 = d["configs4"]
+    assert c4["dtype"] == "bf16" and c4["unit"] == "scenes/sec" and c4["value"] > 0 and c4["steps"] == 10
+    assert "51 200" in c4["workload"] and c4["roofline"]["bound"] == "mfma" and 0 < c4["roofline"]["frac"] < 1
+    assert c4["roofline"]["mfma_products_per_mac"] == 1
+    assert d["collective"]["op"] is None
 
 
 def test_bench_under_torchrun_takes_the_rccl_path():
@@ -58,4 +64,25 @@ def test_bench_under_torchrun_takes_the_rccl_path():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0
+    c = d["collective"]
+    assert c["payload"] == "heads" and c["payload_bytes_per_rank_per_step"] == 16 * 21 * 25600 * 4
+    assert c["stream"].startswith("side stream")
+
+
+def test_bench_gather_poses_over_rccl():
+    """`--gather poses`: the K best frames per scene are decoded on the device and ONE all-gather of
+    (B, K, 18) fp32 replaces the 21-channel one -- through RCCL with one rank."""
+    env = dict(os.environ, S4G_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
+                          "29519", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
+                          "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--gather", "poses"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    c = d["collective"]
+    assert c["payload"] == "poses" and c["payload_bytes_per_rank_per_step"] == 16 * 50 * 18 * 4
+    assert "decoded grasp frames" in d["config"]["parallelism"] and d["value"] > 0
     assert "all-gather" in d["config"]["parallelism"]

@@ -63,21 +63,91 @@ def test_pack_unpack_roundtrip():
     assert all(torch.equal(single[k], pred[k]) for k in pred)
 
 
-@pytest.mark.parametrize("world", [2])
-def test_sharded_forward_all_gather_gloo(world):
+def _run_world(target, world, *args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 6, q)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in procs]
+    results = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok, shapes in results:
+    return sorted(results)
+
+
+@pytest.mark.parametrize("world,total", [(2, 6), (4, 8)])
+def test_sharded_forward_all_gather_gloo(world, total):
+    for rank, ok, shapes in _run_world(_worker, world, total):
         assert ok, rank
-        assert shapes["score"] == (6, 3, 50) and shapes["movable_logits"] == (6, 5, 50)
+        assert shapes["score"] == (total, 3, 50) and shapes["movable_logits"] == (total, 5, 50)
+
+
+def _fake_decode(pred, xyz, K=5):
+    """Shapes and dtypes of postprocess.decode_top_poses: (B,K,4,4) fp32, (B,K) fp32, (B,K) int64 --
+    a deterministic function of the scene so that every rank can check every other rank's rows."""
+    B, _, N = xyz.shape
+    score, index = torch.topk(pred["score"][:, 0], K, dim=1)
+    H = torch.eye(4).repeat(B, K, 1, 1)
+    H[:, :, :3, 3] = torch.gather(xyz, 2, index.unsqueeze(1).expand(B, 3, K)).transpose(1, 2)
+    return H, score, index
+
+
+def _gather_worker(rank, world, port, mode, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sdist.init_from_env(backend="gloo")
+    per = 3
+    g = torch.Generator().manual_seed(1)
+    pts = torch.randn(world * per, 3, 40, generator=g)
+    lo, hi = sdist.shard_range(world * per, rank, world)
+    mine = pts[lo:hi]
+    gather = sdist.OutputGather(mode, decode=_fake_decode if mode == "poses" else None, device=mine.device)
+    out = gather(_fake_runner({"scene_points": mine}), mine)
+    if mode == "poses":
+        H, s, i = out
+        rH, rs, ri = _fake_decode(_fake_runner({"scene_points": pts}), pts)
+        ok = torch.equal(H, rH) and torch.equal(s, rs) and torch.equal(i, ri) and i.dtype == torch.int64
+        nbytes = gather.payload_bytes == per * 5 * 18 * 4
+    else:
+        ref = _fake_runner({"scene_points": pts})
+        ok = all(torch.equal(out[k], ref[k]) for k in sdist.HEADS)
+        nbytes = gather.payload_bytes == per * 21 * 40 * 4
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok and nbytes), gather.last_stream))
+
+
+@pytest.mark.parametrize("mode", ["heads", "poses"])
+def test_output_gather_modes_gloo_world2(mode):
+    """bench.py's collective object: packed heads, or decoded top-K poses (the payload reduction of
+    SURVEY 8e / 8f1) with a real decode-shaped payload; on CPU tensors it runs on the caller."""
+    for rank, ok, where in _run_world(_gather_worker, 2, mode):
+        assert ok, rank
+        assert where == "caller"
+
+
+def test_output_gather_argument_errors():
+    with pytest.raises(ValueError):
+        sdist.OutputGather("poses")              # no decode function
+    with pytest.raises(ValueError):
+        sdist.OutputGather("everything")
+    assert sdist.scenes_per_rank(128, 8) == 16
+    with pytest.raises(ValueError):
+        sdist.scenes_per_rank(6, 4)
+
+
+def test_bench_rejects_an_uneven_global_batch_before_touching_a_gpu():
+    """`bench.py --global-batch` through the script's own argument path: 6 scenes over 4 ranks must
+    stop with exit code 2 and a message (no GPU is needed to get there)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--global-batch", "6"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode == 2 and "does not divide" in out.stderr and out.stdout.strip() == ""
 
 
 def test_all_gather_poses_single_process_roundtrip():
