@@ -80,8 +80,11 @@ def parse(argv=None):
                     help="payload of the per-batch all-gather (N > 1): the 21 per-point head channels, or "
                          "the --num-poses best decoded grasp frames per scene (3.6 KB instead of 2.15 MB)")
     ap.add_argument("--num-poses", type=int, default=50)
-    ap.add_argument("--timer-every", type=int, default=int(os.environ.get("S4G_BENCH_TIMER_EVERY", "1")),
-                    help="HIP event pairs around the native launches of every k-th forward pass only")
+    ap.add_argument("--timer-every", type=int, default=int(os.environ.get("S4G_BENCH_TIMER_EVERY", "4")),
+                    help="HIP event pairs around the native launches of every k-th forward pass of the timed "
+                         "region (default 4: the pairs are barrier packets in the queues they time -- with a "
+                         "pair around EVERY launch the step measured 9.04 ms against 8.85 ms at k = 4 and "
+                         "8.84 ms with none, profiles/r03_timer_sampling.md)")
     ap.add_argument("--no-configs4", action="store_true",
                     help="skip the configs[4] (bf16, 51 200 points, 32 scenes) leg after the timed region")
     ap.add_argument("--precision", default=None, choices=["f16x2", "bf16x3", "fp32", "bf16"],
