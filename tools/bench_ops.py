@@ -47,8 +47,9 @@ def main():
         big = torch.from_numpy(synth.make_batch(list(range(B)), 51200, variant=a.variant)).to(dev)
         ms = timeit(lambda: F.farthest_point_sample(big, 5120), reps=2, warm=1)
         print("%-28s B=%d  %9.3f ms   %.3f us/step" % ("fps 51200->5120", B, ms, 1e3 * ms / 5119))
-    if "ball" in ops:
-        for name, x, c, r in (("ball 25600/5120 r.02", pts, c1, 0.02), ("ball 5120/1024 r.08", c1, c2, 0.08)):
+    if "ball" in ops or "ball1" in ops:
+        sizes = (("ball 25600/5120 r.02", pts, c1, 0.02), ("ball 5120/1024 r.08", c1, c2, 0.08))
+        for name, x, c, r in (sizes if "ball" in ops else sizes[:1]):
             ms = timeit(lambda: F.ball_query(x, c, r, 64))
             N, M = x.shape[2], c.shape[2]
             nb = B * (12 * N + 12 * M + 8 * M * 64 + 8 * M)
