@@ -42,7 +42,7 @@ extern "C" {
  *    s4g_group_points_ws_f32, device-side cell choice of s4g_three_nn_grid_f32 (cell < 0).
  * 4: per-scene activation maxima (rows_per_scene), bf16 chains, s4g_heads_chain_f32.
  * 5: s4g_group_rel_xyz_i32 and the rel_xyz4 field of s4g_gemm_desc_t. */
-#define S4G_ABI_VERSION 5
+#define S4G_ABI_VERSION 6
 
 #define S4G_OK 0
 #define S4G_EINVAL (-1)     /* bad size / null pointer */
@@ -347,6 +347,25 @@ typedef struct s4g_heads_desc {
   const float *a_amax;
   float a_amax_floor;
   int32_t rows_per_scene;
+  /* ABI >= 6, optional (pre_W_frag[0] != NULL): the tail of the LAST feature-propagation level in
+   * front of the heads, in the same launch -- PointnetFPModule.forward (pointnet2_utils/modules.py:
+   * 498-507) of fp_modules[2] with its first layer already applied to the sparse features
+   * (S4G_GEMM_LOAD_INTERP_ADD's algebra): the workgroup's input panel is formed as
+   *     X0[p] = relu(sum_k pre_nw[p][k] * pre_sparse[b N2 + pre_nidx[p][k]] (+ pre_dense[p]) + pre_lbias)
+   * and two C -> C layers (pre_W_frag / pre_bias / pre_w_inv_scale [0..1], ReLU each) run on it
+   * inside LDS before the heads read it; X / ldx are then unused and a_amax / pre_a_amax2 bound
+   * |pre_sparse| / |pre_dense| per scene (a_amax_floor: the bias bound, summed with them).  The
+   * (P, C) feature tensor between fp_modules[2] and the heads never exists in HBM. */
+  const void *pre_W_frag[2];
+  const float *pre_bias[2];
+  const float *pre_w_inv_scale[2];
+  const int32_t *pre_nidx;   /* (P, 3) */
+  const float *pre_nw;       /* (P, 3) */
+  const float *pre_sparse;   /* (B N2, C) channels-last */
+  const float *pre_dense;    /* (P, C) or NULL */
+  const float *pre_lbias;    /* C */
+  const float *pre_a_amax2;  /* per-scene maxima of pre_dense or NULL */
+  int32_t pre_N2;
 } s4g_heads_desc_t;
 
 int s4g_heads_chain_f32(const s4g_heads_desc_t *desc, s4g_stream_t stream);

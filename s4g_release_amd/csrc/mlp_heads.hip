@@ -48,16 +48,28 @@ struct HeadsParams {
   float* out[4];
   int ch[4];
   int sigmoid_head;
-  const float* a_amax;     // per-scene maxima of X (PL == 2)
+  const float* a_amax;     // per-scene maxima of X (PL == 2); PRE: of the sparse features
   float a_floor;
   int rps;
+  // PRE: the last feature-propagation level's tail in front of the heads (see s4g_heads_desc_t):
+  // panel A = relu(interp(sparse) (+ dense) + lbias), then two 256 -> 256 layers A -> B -> A
+  const uint16_t* Wp[2];
+  const float* bias_p[2];
+  const float* wsc_p[2];
+  const int* nidx;
+  const float* nw;
+  const float* sparse;
+  const float* dense;
+  const float* lbias;
+  const float* a_amax2;
+  int N2;
 };
 
 // NRBT = 32-position blocks per workgroup: 2 (64 positions; the f16x2 panels fill the LDS) or 4
 // (128 positions, single-plane bf16 only: every W fragment then feeds four MFMAs instead of two,
 // which halves the W bytes streamed per position -- the single product makes that stream three
 // times as heavy per MFMA as in the f16x2 form).
-template <int PL, int HD_RING, int NRBT>
+template <int PL, int HD_RING, int NRBT, bool PRE>
 __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) {
   constexpr int BM = 32 * NRBT, C = 256, NW = 8, astr = C + 8, aplane = BM * astr;
   constexpr int FB = PL * 1024;            // bytes of one (32 channels x 16 k) fragment block
@@ -77,7 +89,12 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
   float sa = 1.f, inv_sa = 1.f;
   if constexpr (PL == 2) {
     float amax = p.a_floor;
-    if (p.a_amax) amax = fmaxf(amax, amax_rows(p.a_amax, lane, p0, min(p0 + BM, p.P) - 1, p.rps));
+    if constexpr (PRE) {   // the loader SUMS its inputs: |bias| + |interpolated| (+ |dense|)
+      if (p.a_amax) amax += amax_rows(p.a_amax, lane, p0, min(p0 + BM, p.P) - 1, p.rps);
+      if (p.a_amax2) amax += amax_rows(p.a_amax2, lane, p0, min(p0 + BM, p.P) - 1, p.rps);
+    } else if (p.a_amax) {
+      amax = fmaxf(amax, amax_rows(p.a_amax, lane, p0, min(p0 + BM, p.P) - 1, p.rps));
+    }
     uint32_t ex = __float_as_uint(amax) >> 23;
     ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
     ex = __builtin_amdgcn_readfirstlane(ex);
@@ -98,10 +115,13 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
   auto w3 = [&](int g) { return wrs[3] + woff(g * 4 + (wv & 3), 16, 0); };
   auto wl = [&](int g) { return wrs[4] + woff(g, 8, 0); };
   auto wload = [&](const WRef& w, uint32_t byte_off, int pl) { return wref_load(w, wf_lane + pl * 1024, byte_off); };
+  // PRE: the two 256 -> 256 layers in front of the heads (this wave's 32 channels: block wv, 16 steps)
+  const WRef wp0 = PRE ? wref(p.Wp[0], woff(wv, 16, 0)) : wrs[0];
+  const WRef wp1 = PRE ? wref(p.Wp[1], woff(wv, 16, 0)) : wrs[0];
 
   uint4 ring[HD_RING][PL];
   {
-    const WRef w = w0(0, 0);
+    const WRef w = PRE ? wp0 : w0(0, 0);
 #pragma unroll
     for (int d = 0; d < HD_RING; ++d)
 #pragma unroll
@@ -113,11 +133,55 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
   for (int r0 = 0; r0 < BM; r0 += 64) {
     const int row = r0 + (t >> 3), chunk = t & 7;
     const bool ok = p0 + row < p.P;
-    const float* src = p.X + (size_t)(ok ? p0 + row : 0) * p.ldx + chunk * 4;
     float4 ra[8];
+    if constexpr (PRE) {
+      // X0 = relu(sum_k w_k S[idx_k] (+ dense) + bias): the three neighbour rows of the sparse level
+      // (L2-resident: N2 x 256 floats per scene), 4 columns x 8 K-tiles per thread, same arithmetic
+      // order as the chain kernel's loader and interp_add_cl_kernel
+      const int pos = ok ? p0 + row : 0;
+      const int bq = pos / p.N;
+      int i3[3];
+      float w3[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        i3[k] = bq * p.N2 + p.nidx[(size_t)pos * 3 + k];
+        w3[k] = p.nw[(size_t)pos * 3 + k];
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {   // two half panels: 4 K-tiles x 3 (4) loads in flight
+        float4 a[4], b[4], c[4], y[4], bb[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int col = (h * 4 + kk) * 32 + chunk * 4;
+          a[kk] = *reinterpret_cast<const float4*>(p.sparse + (size_t)i3[0] * 256 + col);
+          b[kk] = *reinterpret_cast<const float4*>(p.sparse + (size_t)i3[1] * 256 + col);
+          c[kk] = *reinterpret_cast<const float4*>(p.sparse + (size_t)i3[2] * 256 + col);
+          bb[kk] = *reinterpret_cast<const float4*>(p.lbias + col);
+          y[kk] = p.dense ? *reinterpret_cast<const float4*>(p.dense + (size_t)pos * 256 + col)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const float av[4] = {a[kk].x, a[kk].y, a[kk].z, a[kk].w}, bv[4] = {b[kk].x, b[kk].y, b[kk].z, b[kk].w};
+          const float cv[4] = {c[kk].x, c[kk].y, c[kk].z, c[kk].w}, yv[4] = {y[kk].x, y[kk].y, y[kk].z, y[kk].w};
+          const float bi[4] = {bb[kk].x, bb[kk].y, bb[kk].z, bb[kk].w};
+          float r[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float acc = __fmul_rn(av[e], w3[0]);
+            acc = __fadd_rn(acc, __fmul_rn(bv[e], w3[1]));
+            acc = __fadd_rn(acc, __fmul_rn(cv[e], w3[2]));
+            r[e] = ok ? fmaxf(__fadd_rn(__fadd_rn(yv[e], acc), bi[e]), 0.f) : 0.f;
+          }
+          ra[h * 4 + kk] = make_float4(r[0], r[1], r[2], r[3]);
+        }
+      }
+    } else {
+    const float* src = p.X + (size_t)(ok ? p0 + row : 0) * p.ldx + chunk * 4;
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt)
       ra[kt] = ok ? nt_load4(src + kt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);   // read once: do not displace the W set in L2
+    }
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
       uint16_t* dst = PA + row * astr + kt * 32 + chunk * 4;
@@ -188,15 +252,16 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
 
   // scale | bias of this wave's 32 channels, staged once per phase (read back as float4 per
   // register quad: lane holds channels 8 j + 4 lh + (0..3))
-  auto stage_sb = [&](int L, int gch, float mul) {
-    epi_s[lane] = lane < 32 ? (PL == 2 ? mul * p.wsc[L][gch + lane] : 1.f) : p.bias[L][gch + lane - 32];
+  auto stage_sb2 = [&](const float* wsc, const float* bias, int gch, float mul) {
+    epi_s[lane] = lane < 32 ? (PL == 2 ? mul * wsc[gch + lane] : 1.f) : bias[gch + lane - 32];
   };
+  auto stage_sb = [&](int L, int gch, float mul) { stage_sb2(p.wsc[L], p.bias[L], gch, mul); };
 
   // acc (NRB blocks of 32 positions x this wave's 32 channels) -> relu(acc * scale + bias) ->
   // tile maximum (one barrier: also the point after which nobody reads the old panel B) ->
   // split with the tile's own power-of-two scale -> panel B rows ROWOFF.., columns PCH0..
   float inv_sh = 1.f;
-  auto panel_epilogue = [&](auto nrb_tag, int rowoff, int pch0) {
+  auto panel_epilogue_to = [&](uint16_t* PD, auto nrb_tag, int rowoff, int pch0) {
     constexpr int NRB = decltype(nrb_tag)::value;
     if (S4G_HEADS_ABLATE & 4) {
 #pragma unroll
@@ -243,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int rb = 0; rb < NRB; ++rb) {
-        uint16_t* dst = PB + (rowoff + rb * 32 + li) * astr + pch0 + 8 * j + 4 * lh;
+        uint16_t* dst = PD + (rowoff + rb * 32 + li) * astr + pch0 + 8 * j + 4 * lh;
         if constexpr (PL == 2) {
           const float4 v = make_float4(acc[rb][4 * j], acc[rb][4 * j + 1], acc[rb][4 * j + 2], acc[rb][4 * j + 3]);
           uint2 h, l;
@@ -257,8 +322,20 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
       }
     __syncthreads();
   };
+  auto panel_epilogue = [&](auto nrb_tag, int rowoff, int pch0) { panel_epilogue_to(PB, nrb_tag, rowoff, pch0); };
   using full = std::integral_constant<int, NRBT>;       // all of this workgroup's position blocks
   using half = std::integral_constant<int, NRBT / 2>;
+
+  if constexpr (PRE) {
+    // fp2.1: A -> B, fp2.2: B -> A; X then sits in panel A with the tile's own power-of-two scale
+    stage_sb2(p.wsc_p[0], p.bias_p[0], wv * 32, inv_sa);
+    S4G_HD_STRIP(PA, NRBT, 0, wp0, 16, wp1)
+    panel_epilogue(full{}, 0, wv * 32);
+    stage_sb2(p.wsc_p[1], p.bias_p[1], wv * 32, inv_sh);
+    S4G_HD_STRIP(PB, NRBT, 0, wp1, 16, w0(0, 0))
+    panel_epilogue_to(PA, full{}, 0, wv * 32);
+    inv_sa = inv_sh;
+  }
 
   for (int g = 0; g < 4; ++g) {
     f32x16 acc1[NRBT];   // heads.1 accumulated over the two halves of its 512 inputs, in units of 1 / w_scale
@@ -322,23 +399,33 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
 #undef S4G_HD_TERM
 }
 
-template <int PL, int HD_RING, int NRBT>
-static int launch_heads(const HeadsParams& p, hipStream_t st) {
+template <int PL, int HD_RING, int NRBT, bool PRE>
+static int launch_heads_cfg(const HeadsParams& p, hipStream_t st) {
   constexpr int BM = 32 * NRBT;
   constexpr size_t lds = sizeof(uint16_t) * 2 * PL * BM * (256 + 8) + sizeof(float) * (8 * 64 + 16);
   static_assert(lds <= 160 * 1024, "one workgroup's panels must fit a CU's LDS");
   static LdsAttrCache lds_cache;
-  if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(&mlp_heads_kernel<PL, HD_RING, NRBT>), lds, lds_cache)) return rc;
-  hipLaunchKernelGGL((mlp_heads_kernel<PL, HD_RING, NRBT>), dim3((unsigned)((p.P + BM - 1) / BM)), dim3(512), lds, st, p);
+  if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(&mlp_heads_kernel<PL, HD_RING, NRBT, PRE>), lds, lds_cache)) return rc;
+  hipLaunchKernelGGL((mlp_heads_kernel<PL, HD_RING, NRBT, PRE>), dim3((unsigned)((p.P + BM - 1) / BM)), dim3(512), lds, st, p);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
+}
+template <int PL, int HD_RING, int NRBT>
+static int launch_heads(const HeadsParams& p, hipStream_t st) {
+  return p.Wp[0] ? launch_heads_cfg<PL, HD_RING, NRBT, true>(p, st) : launch_heads_cfg<PL, HD_RING, NRBT, false>(p, st);
 }
 
 }  // namespace s4g
 
 extern "C" int s4g_heads_chain_f32(const s4g_heads_desc_t* d, s4g_stream_t stream) {
   using namespace s4g;
-  if (!d || d->P < 0 || d->N <= 0 || !d->X || (d->ldx & 3) || d->ldx < 256 || ((uintptr_t)d->X & 15))
+  if (!d || d->P < 0 || d->N <= 0) return S4G_EINVAL;
+  const bool pre = d->pre_W_frag[0] != nullptr;
+  if (!pre && (!d->X || (d->ldx & 3) || d->ldx < 256 || ((uintptr_t)d->X & 15))) return S4G_EINVAL;
+  if (pre && (!d->pre_W_frag[1] || !d->pre_bias[0] || !d->pre_bias[1] || !d->pre_nidx || !d->pre_nw ||
+              !d->pre_sparse || !d->pre_lbias || d->pre_N2 < 3 || ((uintptr_t)d->pre_sparse & 15) ||
+              ((uintptr_t)d->pre_dense & 15) || ((uintptr_t)d->pre_lbias & 15) ||
+              (d->precision == S4G_GEMM_F16X2 && (!d->pre_w_inv_scale[0] || !d->pre_w_inv_scale[1]))))
     return S4G_EINVAL;
   if (d->precision != S4G_GEMM_F16X2 && d->precision != S4G_GEMM_BF16) return S4G_EINVAL;
   if (d->C != 256 || d->H0 != 512 || d->H1 != 256 || d->H2 != 256 || d->H3 != 128) return S4G_EUNSUPPORTED;
@@ -362,6 +449,18 @@ extern "C" int s4g_heads_chain_f32(const s4g_heads_desc_t* d, s4g_stream_t strea
   p.a_amax = d->a_amax;
   p.a_floor = d->a_amax_floor;
   p.rps = d->rows_per_scene > 0 ? d->rows_per_scene : 0;
+  for (int l = 0; l < 2; ++l) {
+    p.Wp[l] = pre ? (const uint16_t*)d->pre_W_frag[l] : nullptr;
+    p.bias_p[l] = pre ? d->pre_bias[l] : nullptr;
+    p.wsc_p[l] = pre ? d->pre_w_inv_scale[l] : nullptr;
+  }
+  p.nidx = pre ? d->pre_nidx : nullptr;
+  p.nw = pre ? d->pre_nw : nullptr;
+  p.sparse = pre ? d->pre_sparse : nullptr;
+  p.dense = pre ? d->pre_dense : nullptr;
+  p.lbias = pre ? d->pre_lbias : nullptr;
+  p.a_amax2 = pre ? d->pre_a_amax2 : nullptr;
+  p.N2 = pre ? d->pre_N2 : 0;
   if (d->precision == S4G_GEMM_F16X2 && !d->a_amax && !(d->a_amax_floor > 0.f)) return S4G_EINVAL;
   if (d->P == 0) return S4G_OK;
   hipStream_t st = (hipStream_t)stream;

@@ -156,6 +156,7 @@ class FusedPointNet2:
         self.fp_loader_add = v if v in ("auto", "none") else set(int(t) for t in v.split(",") if t)
         self.geo_streams = max(1, int(os.environ.get("S4G_GEO_STREAMS", "2")))
         self.rel_xyz = os.environ.get("S4G_REL_XYZ", "1") != "0"
+        self.heads_pre = os.environ.get("S4G_HEADS_PRE", "1") != "0"
         p = next(net.parameters())
         if not p.is_cuda:
             raise RuntimeError("FusedPointNet2 needs the model on a HIP device (no CPU fallback)")
@@ -274,6 +275,15 @@ class FusedPointNet2:
             return False
         return bool(_cabi.lib().s4g_gemm_chain_supported(loader, epi, c, l1.kpad16))
 
+    def _heads_take_tail(self, fi, fl, pending):
+        """Last FP level, heads as one launch, the level = (linear-first layer, 256 -> 256, 256 -> 256)
+        with its sum formed in a loader: the two 256-wide layers move into the heads' launch
+        (S4G_HEADS_PRE=0 keeps the separate chain launch)."""
+        return (self.heads_fused is not None and self.heads_pre and fi == len(self.fp) - 1 and len(fl) == 3 and
+                pending["C2"] == 256 and all(l.cin == 256 and l.cout == 256 and l.groups == 1 and
+                                             l.Wfrag is not None for l in fl[1:]) and
+                self.head_layers[0].cin == 256)
+
     # ------------------------------------------------------------------ launches
     def _gemm(self, name, layer, P, loader, epi, relu=True, layer2=None, layer3=None, name3="heads.0",
               rows_per_scene=0, **kw):
@@ -314,15 +324,33 @@ class FusedPointNet2:
             rc = _cabi.lib().s4g_mlp_gemm_f32(ctypes.byref(d), _F._stream())
         _cabi.check(rc, "mlp_gemm " + name)
 
-    def _heads(self, x, x_amax, outs, B, N0):
-        """heads.0 .. heads.3 + logits of all four heads: one launch (s4g_heads_chain_f32)."""
+    def _heads(self, x, x_amax, outs, B, N0, pre=None):
+        """heads.0 .. heads.3 + logits of all four heads: one launch (s4g_heads_chain_f32).
+        pre: the last FP level's tail rides in front (its loader state + its two 256-wide layers):
+        the per-point feature tensor between the FP stack and the heads never exists in HBM."""
         d = HeadsDesc()
         bf16 = self.precision == "bf16"
         d.precision = 2 if bf16 else 3
-        d.P, d.N, d.ldx = B * N0, N0, x.shape[1]
+        d.P, d.N = B * N0, N0
         d.C, d.H0, d.H1, d.H2, d.H3 = 256, 512, 256, 256, 128
-        d.X = x.data_ptr()
         flops = 0.0
+        name = "heads.0-3+logits"
+        if pre is None:
+            d.X, d.ldx = x.data_ptr(), x.shape[1]
+        else:
+            frag = (lambda l: l.Wfrag_bf16) if bf16 else (lambda l: l.Wfrag)
+            for i, layer in enumerate(pre["layers"]):
+                d.pre_W_frag[i] = frag(layer).data_ptr()
+                d.pre_bias[i] = layer.bias.data_ptr()
+                d.pre_w_inv_scale[i] = layer.w_inv_scale.data_ptr()
+                flops += 2.0 * B * N0 * layer.cout * layer.cin
+            d.pre_nidx, d.pre_nw = pre["nidx"].data_ptr(), pre["nw"].data_ptr()
+            d.pre_sparse, d.pre_N2 = pre["sparse"].data_ptr(), pre["N2"]
+            d.pre_dense = None if pre["dense"] is None else pre["dense"].data_ptr()
+            d.pre_lbias = pre["loader_bias"].data_ptr()
+            d.pre_a_amax2 = None if pre["a_amax2"] is None else pre["a_amax2"].data_ptr()
+            x_amax = pre["a_amax"]
+            name = "%s+%s" % (pre["name"], name)
         for l, layer in enumerate(self.heads_fused):
             d.W_frag[l] = (layer.Wfrag_bf16 if bf16 else layer.Wfrag).data_ptr()
             d.bias[l] = layer.bias.data_ptr()
@@ -335,9 +363,9 @@ class FusedPointNet2:
             d.channels[h] = self.head_channels[h]
         d.sigmoid_head = 3
         d.a_amax = None if x_amax is None else x_amax.data_ptr()
-        d.a_amax_floor = 0.0
+        d.a_amax_floor = 0.0 if pre is None else pre["a_amax_floor"]
         d.rows_per_scene = N0
-        with _F._timed("gemm[heads.0-3+logits P=%d K=256 N=4x(512,256,256,128,c)]" % (B * N0), 0, flops):
+        with _F._timed("gemm[%s P=%d K=256 N=4x(512,256,256,128,c)]" % (name, B * N0), 0, flops):
             rc = _cabi.lib().s4g_heads_chain_f32(ctypes.byref(d), _F._stream())
         _cabi.check(rc, "heads_chain")
 
@@ -514,6 +542,7 @@ class FusedPointNet2:
         cur.wait_event(geo["done"])               # the 3-NN searches of the FP path
         (sparse_feat, sparse_amax), n_sparse = level_feat[-1], level_n[-1]
         heads0_fused = False
+        heads_pre = None
         for fi, fp in enumerate(self.fp):
             (dense_feat, dense_amax), n_dense = level_feat[-2 - fi], level_n[-2 - fi]
             nidx, nw = geo["fp"][fi]
@@ -532,6 +561,12 @@ class FusedPointNet2:
             for l, layer in enumerate(fl):
                 if fuse2 and l == len(fl) - 1:
                     continue                      # fused behind the previous layer's launch
+                if pending is not None and self._heads_take_tail(fi, fl, pending):
+                    # the level's last two layers run in front of the heads, inside their launch
+                    heads_pre = dict(pending, layers=[fl[-2], fl[-1]], name="fp%d.1+fp%d.2" % (fi, fi))
+                    pending = None
+                    x = x_amax = None
+                    break
                 l2 = fl[-1] if (fuse2 and l == len(fl) - 2) else None
                 l3 = h0 if (fuse3 and l2 is not None) else None
                 out = torch.empty((P, (l3 or l2 or layer).cout), dtype=torch.float32, device=dev)
@@ -608,9 +643,9 @@ class FusedPointNet2:
         P = B * N0
         x, x_amax = sparse_feat, sparse_amax
         names = ("score", "frame_R", "frame_t", "movable_logits")
-        if self.heads_fused is not None and x.shape[1] == 256:
+        if self.heads_fused is not None and (heads_pre is not None or x.shape[1] == 256):
             outs = [torch.empty((B, c, N0), dtype=torch.float32, device=dev) for c in self.head_channels]
-            self._heads(x, x_amax, outs, B, N0)
+            self._heads(x, x_amax, outs, B, N0, pre=heads_pre)
             return dict(zip(names, outs))
         l0 = self.head_layers[0]
         if not heads0_fused:

@@ -112,3 +112,116 @@ def test_heads_chain_rejects_other_widths_and_bad_arguments(dev):
     assert _cabi.lib().s4g_heads_chain_f32(ctypes.byref(d), st) != 0
     d.H3 = 128
     assert _cabi.lib().s4g_heads_chain_f32(ctypes.byref(d), st) != 0     # no weights / outputs given
+
+
+def _pre_setup(dev, B, N, N2, seed, with_dense):
+    """Inputs of the feature-propagation tail in front of the heads (s4g_heads_desc_t.pre_*):
+    sparse features (B N2, 256), three neighbour indices + weights per point, an optional dense
+    addend, the first layer's bias, and the two 256 -> 256 layers."""
+    from s4g_release_amd.fused import _Layer
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    S = (r(B * N2, 256) * torch.tensor([1.0, 25.0, 0.05])[:B, None].repeat_interleave(N2, dim=0)).to(dev)
+    nidx = torch.randint(0, N2, (B * N, 3), generator=g, dtype=torch.int32).to(dev)
+    w = torch.rand(B * N, 3, generator=g)
+    nw = (w / w.sum(dim=1, keepdim=True)).to(dev)
+    dense = (r(B * N, 256) * 0.5).to(dev) if with_dense else None
+    lbias = r(256).to(dev)
+    pl = [_Layer((r(256, 256) / 16).to(dev), r(256).to(dev), 256) for _ in range(2)]
+    return S, nidx, nw, dense, lbias, pl
+
+
+def _pre_reference(S, nidx, nw, dense, lbias, pl, B, N, N2, rnd=lambda t: t.double()):
+    base = (torch.arange(B, device=S.device).repeat_interleave(N) * N2).view(-1, 1)
+    rows = S.double()[(base + nidx.long())]                       # (P, 3, 256)
+    x = (rows * nw.double().unsqueeze(-1)).sum(dim=1) + lbias.double()
+    if dense is not None:
+        x = x + dense.double()
+    x = x.clamp_min(0)
+    for layer in pl:
+        w = layer.W[0] if layer.W.dim() == 3 else layer.W
+        x = (rnd(x.float()) @ rnd(w).t() + layer.bias.double()).clamp_min(0)
+    return x.float()
+
+
+@pytest.mark.parametrize("precision", [3, 2])
+@pytest.mark.parametrize("B,N,N2,with_dense", [(2, 100, 40, False), (3, 171, 64, True), (1, 64, 3, False)])
+def test_heads_chain_with_fp_tail_in_front(dev, precision, B, N, N2, with_dense):
+    """ABI 6: interpolate + add + ReLU in the loader, two 256 -> 256 layers inside LDS, then the
+    heads -- against fp64 (f16x2: fp32-class) / a reference rounded to bf16 at the layer inputs."""
+    from s4g_release_amd import _cabi
+    Ws, b, layers = _layers(dev, 11 + N)
+    S, nidx, nw, dense, lbias, pl = _pre_setup(dev, B, N, N2, 5 + N, with_dense)
+    d = _cabi.HeadsDesc()
+    d.precision = precision
+    d.P, d.N = B * N, N
+    d.C, d.H0, d.H1, d.H2, d.H3 = 256, 512, 256, 256, 128
+    pick = (lambda l: l.Wfrag_bf16) if precision == 2 else (lambda l: l.Wfrag)
+    for l, layer in enumerate(layers):
+        d.W_frag[l], d.bias[l], d.w_inv_scale[l] = pick(layer).data_ptr(), layer.bias.data_ptr(), layer.w_inv_scale.data_ptr()
+    for l, layer in enumerate(pl):
+        d.pre_W_frag[l], d.pre_bias[l] = pick(layer).data_ptr(), layer.bias.data_ptr()
+        d.pre_w_inv_scale[l] = layer.w_inv_scale.data_ptr()
+    d.pre_nidx, d.pre_nw, d.pre_sparse, d.pre_N2 = nidx.data_ptr(), nw.data_ptr(), S.data_ptr(), N2
+    d.pre_dense = None if dense is None else dense.data_ptr()
+    d.pre_lbias = lbias.data_ptr()
+    amax = torch.zeros((B, 64), device=dev)
+    amax[:, 9] = S.view(B, -1).abs().amax(dim=1)
+    d.a_amax = amax.data_ptr()
+    if dense is not None:
+        amax2 = torch.zeros((B, 64), device=dev)
+        amax2[:, 1] = dense.view(B, -1).abs().amax(dim=1)
+        d.pre_a_amax2 = amax2.data_ptr()
+    d.a_amax_floor = float(lbias.abs().max())
+    d.rows_per_scene = N
+    outs = [torch.full((B, c, N), float("nan"), device=dev) for c in CH]
+    for h, o in enumerate(outs):
+        d.out[h], d.channels[h] = o.data_ptr(), CH[h]
+    d.sigmoid_head = 3
+    _cabi.check(_cabi.lib().s4g_heads_chain_f32(ctypes.byref(d), torch.cuda.current_stream().cuda_stream), "heads")
+    torch.cuda.synchronize()
+    if precision == 3:
+        X = _pre_reference(S, nidx, nw, dense, lbias, pl, B, N, N2)
+        ref = _reference(Ws, b, X, B, N)
+        for h in range(4):
+            assert torch.isfinite(outs[h]).all()
+            err = (outs[h].double() - ref[h]).abs()
+            scale = ref[h].abs().amax(dim=(1, 2), keepdim=True).clamp_min(1.0)
+            assert (err / scale).max().item() < 3e-5, (h, (err / scale).max().item())
+    else:
+        rb = lambda t: t.to(torch.bfloat16).double()
+        X = _pre_reference(S, nidx, nw, dense, lbias, pl, B, N, N2, rnd=rb)
+        ref = _reference(Ws, b, X, B, N, rnd=rb)
+        for h in range(4):
+            scale = max(1.0, ref[h].abs().max().item())
+            assert torch.isfinite(outs[h]).all()
+            assert (outs[h].double() - ref[h]).abs().max().item() < 6e-3 * scale
+            assert (outs[h].double() - ref[h]).abs().mean().item() < 1e-4 * scale
+
+
+def test_fused_model_with_and_without_the_tail_in_the_heads_launch(dev, monkeypatch):
+    """The whole network at a small size: S4G_HEADS_PRE=0 (separate fp2 chain launch) and the default
+    (tail inside the heads launch) agree to fp32 round-off, and the launch list shrinks by one."""
+    from s4g_release_amd import functions as F, synth
+    from s4g_release_amd.fused import FusedPointNet2
+    from s4g_release_amd.model import S4GConfig, build_pointnet2_cls, randomize_bn_
+    torch.manual_seed(3)
+    net = build_pointnet2_cls(S4GConfig())
+    randomize_bn_(net, 4)
+    net = net.to(dev).eval()
+    pts = torch.from_numpy(synth.make_batch([0, 1], 25600)).to(dev)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("S4G_HEADS_PRE", flag)
+        run = FusedPointNet2(net)
+        F.OpTimer.reset(enabled=True)
+        with torch.no_grad():
+            out = run({"scene_points": pts})
+        torch.cuda.synchronize()
+        F.OpTimer.enabled = False
+        res[flag] = ({k: v.clone() for k, v in out.items()}, sorted(F.OpTimer.summary()))
+    a, b = res["0"], res["1"]
+    assert any("fp2.1+fp2.2+heads" in n for n in b[1]) and not any("fp2.1+fp2.2+heads" in n for n in a[1])
+    assert len([n for n in a[1] if n.startswith("gemm[")]) == len([n for n in b[1] if n.startswith("gemm[")]) + 1
+    for k in a[0]:
+        assert (a[0][k] - b[0][k]).abs().max().item() < 2e-5, k

@@ -78,6 +78,25 @@ def test_gemm_desc_matches_the_c_struct_layout():
     assert ctypes.sizeof(d) % 8 == 0
 
 
+def test_heads_desc_matches_the_c_struct_layout(tmp_path):
+    """ctypes mirror of s4g_heads_desc_t against the C compiler's layout of include/s4g_ops.h
+    (sizes and the offsets of the ABI-6 members)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "s4g_ops.h"\n'
+                   'int main(){printf("%zu %zu %zu %zu %zu", sizeof(s4g_heads_desc_t), '
+                   'offsetof(s4g_heads_desc_t, pre_W_frag), offsetof(s4g_heads_desc_t, pre_nidx), '
+                   'offsetof(s4g_heads_desc_t, pre_N2), sizeof(s4g_gemm_desc_t));return 0;}')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    c = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    d = _cabi.HeadsDesc
+    assert c == [ctypes.sizeof(d), d.pre_W_frag.offset, d.pre_nidx.offset, d.pre_N2.offset,
+                 ctypes.sizeof(_cabi.GemmDesc)]
+
+
 def test_randomize_bn_is_deterministic_and_nontrivial():
     cfg = dict(score_classes=3, num_centroids=(8, 4, 2), radius=(0.1, 0.2, 0.4),
                num_neighbours=(16, 16, 16), sa_channels=((8, 8), (8, 8), (8, 8)),
