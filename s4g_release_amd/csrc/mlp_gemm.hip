@@ -1842,7 +1842,8 @@ static int launch_gemm(const GemmParams& p, int groups, hipStream_t st) {
   X(LOAD_PLAIN, EPI_STORE, 1, 2)      /* first layer two panels deep (512 -> 256 -> ...) */      \
   X(LOAD_PLAIN, EPI_STORE, 8, 1)                                                                 \
   X(LOAD_INTERP_ADD, EPI_STORE, 2, 1)                                                            \
-  X(LOAD_INTERP_ADD, EPI_STORE, 1, 1)
+  X(LOAD_INTERP_ADD, EPI_STORE, 1, 1)                                                            \
+  X(LOAD_INTERP_ADD, EPI_STORE, 8, 1) /* FP level 1's last layer + the next level's linear first layer */
 
 #ifdef S4G_CHAIN_STAMPS
 extern "C" int s4g_debug_chain_stamps(unsigned long long* host_out_512x16) {

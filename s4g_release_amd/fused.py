@@ -157,6 +157,7 @@ class FusedPointNet2:
         self.geo_streams = max(1, int(os.environ.get("S4G_GEO_STREAMS", "2")))
         self.rel_xyz = os.environ.get("S4G_REL_XYZ", "1") != "0"
         self.heads_pre = os.environ.get("S4G_HEADS_PRE", "1") != "0"
+        self.fp_chain_next = os.environ.get("S4G_FP_CHAIN_NEXT", "1") != "0"
         p = next(net.parameters())
         if not p.is_cuda:
             raise RuntimeError("FusedPointNet2 needs the model on a HIP device (no CPU fallback)")
@@ -275,6 +276,19 @@ class FusedPointNet2:
             return False
         return bool(_cabi.lib().s4g_gemm_chain_supported(loader, epi, c, l1.kpad16))
 
+    @staticmethod
+    def _fp_split(fp, layer, c2, c1):
+        """First FP layer W = [W_a | W_b] over [interpolated (c2), skip (c1)] columns as two layers
+        without bias (modules.py:124-127 concat order), cached on the level."""
+        sp = fp.get("split")
+        if sp is None or sp[2] != c2:
+            w = layer.W[:, :layer.cin]
+            zero = torch.zeros_like(layer.bias)
+            la = _Layer(_pad_k(w[:, :c2].contiguous()), zero, c2)
+            lb = _Layer(_pad_k(w[:, c2:].contiguous()), zero, c1) if c1 > 0 else None
+            sp = fp["split"] = (la, lb, c2)
+        return sp
+
     def _heads_take_tail(self, fi, fl, pending):
         """Last FP level, heads as one launch, the level = (linear-first layer, 256 -> 256, 256 -> 256)
         with its sum formed in a loader: the two 256-wide layers move into the heads' launch
@@ -286,7 +300,7 @@ class FusedPointNet2:
 
     # ------------------------------------------------------------------ launches
     def _gemm(self, name, layer, P, loader, epi, relu=True, layer2=None, layer3=None, name3="heads.0",
-              rows_per_scene=0, **kw):
+              rows_per_scene=0, relu2=True, name2=None, **kw):
         d = GemmDesc()
         d.loader, d.epilogue, d.groups, d.relu = loader, epi, layer.groups, int(relu)
         d.P, d.Cin, d.Kpad, d.Cout = P, layer.cin, layer.kpad, layer.cout
@@ -310,9 +324,9 @@ class FusedPointNet2:
         if layer2 is not None:   # second layer fused behind this one (intermediate stays in LDS)
             d.W2_f16x2_frag = frag(layer2).data_ptr()
             d.w2_inv_scale, d.bias2 = layer2.w_inv_scale.data_ptr(), layer2.bias.data_ptr()
-            d.Cout2, d.relu2 = layer2.cout, 1
+            d.Cout2, d.relu2 = layer2.cout, int(relu2)
             flops += 2.0 * P * layer2.cout * layer2.cin * layer2.groups
-            name = "%s+%s" % (name, name[:-1] + str(int(name[-1]) + 1))
+            name = "%s+%s" % (name, name2 or name[:-1] + str(int(name[-1]) + 1))
         if layer3 is not None:   # ... and a third one (layer 2's output stays in LDS too)
             d.W3_f16x2_frag = frag(layer3).data_ptr()
             d.w3_inv_scale, d.bias3 = layer3.w_inv_scale.data_ptr(), layer3.bias.data_ptr()
@@ -543,6 +557,8 @@ class FusedPointNet2:
         (sparse_feat, sparse_amax), n_sparse = level_feat[-1], level_n[-1]
         heads0_fused = False
         heads_pre = None
+        carried = None      # (s_out, s_amax) of the NEXT level, produced by this level's last launch
+        sparse_channels = 0
         for fi, fp in enumerate(self.fp):
             (dense_feat, dense_amax), n_dense = level_feat[-2 - fi], level_n[-2 - fi]
             nidx, nw = geo["fp"][fi]
@@ -550,6 +566,18 @@ class FusedPointNet2:
             x = x_amax = None
             fl = fp["layers"]
             pending = None
+            # a two-layer level whose successor starts with a linear layer on ITS output alone (no skip
+            # features there): interpolate + add in the loader, the level's second layer in LDS, the
+            # successor's first layer (no bias, no ReLU) as the chain's final layer -- the level's own
+            # output tensor is never written (S4G_FP_CHAIN_NEXT=0: separate launches)
+            nxt = self.fp[fi + 1] if fi + 1 < len(self.fp) else None
+            chain_next = (self.fp_chain_next and nxt is not None and len(fl) == 2 and self.fp_linear_first and
+                          self.precision in ("f16x2", "bf16") and level_feat[-3 - fi][0] is None and
+                          fl[1].cin == fl[1].cout and fl[1].kpad16 == fl[1].cout and fl[1].Wfrag is not None and
+                          nxt["layers"][0].cin == fl[1].cout and nxt["layers"][0].cout % 64 == 0 and
+                          nxt["layers"][0].cout <= 1024 and len(nxt["layers"]) >= 2 and
+                          bool(_cabi.lib().s4g_gemm_chain_supported(LOAD_INTERP_ADD, EPI_STORE, fl[1].cout,
+                                                                     fl[1].kpad16)))
             fuse2 = len(fl) >= 3 and self._fusable(fl[-2], fl[-1])
             # last FP level: the first head layer (shared input, groups == 1) rides along as a
             # third layer, so the per-point features never go through HBM before the heads
@@ -567,6 +595,20 @@ class FusedPointNet2:
                     pending = None
                     x = x_amax = None
                     break
+                if pending is not None and chain_next and l == 1:
+                    # this level's second layer + the next level's linear first layer: one chain launch
+                    nl = nxt["layers"][0]
+                    nsp = self._fp_split(nxt, nl, layer.cout, 0)
+                    s_next = torch.empty((P, nl.cout), dtype=torch.float32, device=dev)
+                    s_next_amax = next(rows)
+                    self._gemm("fp%d.%d" % (fi, l), layer, P, LOAD_INTERP_ADD, EPI_STORE, out=s_next,
+                               ldc=nl.cout, out_amax=s_next_amax, layer2=nsp[0], relu2=False,
+                               name2="fp%d.0s" % (fi + 1), **pending)
+                    carried = (s_next, s_next_amax)
+                    pending = None
+                    x = x_amax = None             # the level's own output is never materialised
+                    sparse_channels = layer.cout
+                    break
                 l2 = fl[-1] if (fuse2 and l == len(fl) - 2) else None
                 l3 = h0 if (fuse3 and l2 is not None) else None
                 out = torch.empty((P, (l3 or l2 or layer).cout), dtype=torch.float32, device=dev)
@@ -575,31 +617,29 @@ class FusedPointNet2:
                     # the layer is linear: apply it to the sparse features (and to the skip
                     # features) first, interpolate the narrow result afterwards -- the big
                     # tensor's contraction shrinks from K = C2 + C1 to K = C1 (or vanishes)
-                    c2 = sparse_feat.shape[1]
+                    c2 = sparse_channels if sparse_feat is None else sparse_feat.shape[1]
                     c1 = 0 if dense_feat is None else dense_feat.shape[1]
-                    sp = fp.get("split")
-                    if sp is None or sp[2] != c2:
-                        w = layer.W[:, :layer.cin]
-                        zero = torch.zeros_like(layer.bias)
-                        la = _Layer(_pad_k(w[:, :c2].contiguous()), zero, c2)
-                        lb = _Layer(_pad_k(w[:, c2:].contiguous()), zero, c1) if c1 > 0 else None
-                        sp = fp["split"] = (la, lb, c2)
-                    la, lb, _ = sp
-                    s_out = torch.empty((B * n_sparse, layer.cout), dtype=torch.float32, device=dev)
+                    la, lb, _ = self._fp_split(fp, layer, c2, c1)
+                    s_out = None if carried is not None else \
+                        torch.empty((B * n_sparse, layer.cout), dtype=torch.float32, device=dev)
                     # the sum is formed by the NEXT launch's loader where that is faster
                     # (S4G_FP_LOADER_ADD = list of FP levels), else by interp_add_cl_kernel
                     if self.fp_loader_add == "auto":
-                        in_loader = (fuse2 and len(fl) == 3 and
-                                     self._fusable(fl[-2], fl[-1], LOAD_INTERP_ADD, EPI_STORE))
+                        in_loader = chain_next or (fuse2 and len(fl) == 3 and
+                                                   self._fusable(fl[-2], fl[-1], LOAD_INTERP_ADD, EPI_STORE))
                     else:
                         in_loader = self.fp_loader_add != "none" and fi in self.fp_loader_add
                     in_loader = in_loader and self.precision in ("f16x2", "bf16") and len(fl) >= 2
                     if in_loader and fuse2 and not self._fusable(fl[-2], fl[-1], LOAD_INTERP_ADD, EPI_STORE):
                         in_loader = False
                     s_amax = next(rows) if in_loader else None
-                    self._gemm("fp%d.0s" % fi, la, B * n_sparse, LOAD_PLAIN, EPI_STORE, relu=False,
-                               out=s_out, ldc=layer.cout, A=sparse_feat, lda=c2, a_amax=sparse_amax,
-                               out_amax=s_amax)
+                    if carried is not None:      # the previous level's chain already produced it
+                        s_out, s_amax = carried
+                        carried = None
+                    else:
+                        self._gemm("fp%d.0s" % fi, la, B * n_sparse, LOAD_PLAIN, EPI_STORE, relu=False,
+                                   out=s_out, ldc=layer.cout, A=sparse_feat, lda=c2, a_amax=sparse_amax,
+                                   out_amax=s_amax)
                     y = y_amax = None
                     if lb is not None:
                         y = torch.empty((P, layer.cout), dtype=torch.float32, device=dev)

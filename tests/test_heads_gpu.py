@@ -225,3 +225,33 @@ def test_fused_model_with_and_without_the_tail_in_the_heads_launch(dev, monkeypa
     assert len([n for n in a[1] if n.startswith("gemm[")]) == len([n for n in b[1] if n.startswith("gemm[")]) + 1
     for k in a[0]:
         assert (a[0][k] - b[0][k]).abs().max().item() < 2e-5, k
+
+
+def test_fused_model_fp1_chain_into_the_next_levels_first_layer(dev, monkeypatch):
+    """S4G_FP_CHAIN_NEXT: FP level 1's (interpolate + add) -> 512 -> 512 layer and level 2's linear
+    first layer as one chain launch (level 1's own output never written) against the separate
+    launches: same outputs to fp32 round-off, two launches (interp_add + fp2.0s) fewer."""
+    from s4g_release_amd import functions as F, synth
+    from s4g_release_amd.fused import FusedPointNet2
+    from s4g_release_amd.model import S4GConfig, build_pointnet2_cls, randomize_bn_
+    torch.manual_seed(5)
+    net = build_pointnet2_cls(S4GConfig())
+    randomize_bn_(net, 6)
+    net = net.to(dev).eval()
+    pts = torch.from_numpy(synth.make_batch([2, 3], 25600)).to(dev)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("S4G_FP_CHAIN_NEXT", flag)
+        run = FusedPointNet2(net)
+        F.OpTimer.reset(enabled=True)
+        with torch.no_grad():
+            out = run({"scene_points": pts})
+        torch.cuda.synchronize()
+        F.OpTimer.enabled = False
+        res[flag] = ({k: v.clone() for k, v in out.items()}, sorted(F.OpTimer.summary()))
+    a, b = res["0"], res["1"]
+    assert any("fp1.1+fp2.0s" in n for n in b[1]) and not any("fp1.1+fp2.0s" in n for n in a[1])
+    assert any(n.startswith("gemm[fp2.0s") for n in a[1]) and not any(n.startswith("gemm[fp2.0s") for n in b[1])
+    assert len([n for n in a[1] if n.startswith("interp_add")]) == len([n for n in b[1] if n.startswith("interp_add")]) + 1
+    for k in a[0]:
+        assert (a[0][k] - b[0][k]).abs().max().item() < 2e-5, k
