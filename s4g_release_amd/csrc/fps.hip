@@ -49,6 +49,20 @@ struct FpsSlot {
   uint32_t pad[2];
 };
 
+#ifdef S4G_FPS_STAMPS
+// debug build only (make HIPFLAGS_EXTRA=-DS4G_FPS_STAMPS into its own OBJDIR / LIB): per (scene, wave)
+// cycle accumulators of fps_pruned_kernel's phases, read back by tools/fps_stamps.py
+__device__ unsigned long long g_fps_acc[64 * 8 * 8];
+#define S4G_FPS_T() __builtin_amdgcn_s_memtime()
+#define S4G_FPS_ACC(i, v)                                                                   \
+  do {                                                                                      \
+    if (lane == 0 && b < 64) g_fps_acc[(b * 8 + wave) * 8 + (i)] += (unsigned long long)(v); \
+  } while (0)
+#else
+#define S4G_FPS_T() 0ull
+#define S4G_FPS_ACC(i, v)
+#endif
+
 // Block-wide argmax exchange.  Input: this wave's (wmax, wtie) and the
 // coordinates of its candidate (wave-uniform values).  Output: block winner.
 template <int WAVES>
@@ -89,19 +103,30 @@ __device__ __forceinline__ void fps_block_exchange(FpsSlot* slots, int wave,
   cz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.z), wl));
 }
 
-// Two picks per exchange.  Every wave also publishes the distance d2 of its RUNNER-UP (its best
-// point other than its candidate).  Let W be the winning wave and R the best candidate of the
-// other waves.  If d(R) > d2(W) strictly, every point except the winner is <= R in the
-// (distance, tie key) order: the other waves' points are below their own candidates, W's other
-// points are below d2(W).  The winner's update can only lower min-distances, so R is the next
-// pick provided R itself is out of the winner's reach -- dist2(winner, R) is not below R's
-// min-distance, evaluated with the update's own arithmetic.  Returns whether (rcur, rx, ry, rz)
-// is that second pick; everything is wave-uniform and every wave decides alike.
-template <int WAVES, bool FMAD>
-__device__ __forceinline__ bool fps_block_exchange2(FpsSlot* slots, int wave, int lane, uint32_t wmax,
-                                                    uint32_t wtie, uint32_t wd2, float sx, float sy,
-                                                    float sz, int& cur, float& cx, float& cy, float& cz,
-                                                    int& rcur, float& rx, float& ry, float& rz) {
+// Every wave also publishes the distance d2 of its RUNNER-UP (its best point other than its candidate):
+// the bound that lets one exchange settle several picks.
+// Up to MAXP picks per exchange (round 3).  After the barrier every wave knows all WAVES candidates
+// (position, min-distance, tie key) and each wave's runner-up distance d2.  Picks are taken one after
+// the other from the candidates ONLY, and each is the sequential algorithm's next pick as long as it
+// beats everything that is not a candidate:
+//   * a candidate's min-distance after a pick X is known exactly: min(old, dist2(X, candidate)) with
+//     the update's own arithmetic (the positions are here), so the candidates can be re-ranked;
+//   * the other points of a wave are bounded by its candidate's OLD value while that candidate is
+//     untouched (they were below it and only decrease), and by d2 once its candidate has been
+//     picked or lowered ("disturbed").
+// So pick k (k >= 1) = argmax of the re-ranked candidates by (distance, tie key), valid iff it is
+// STRICTLY above the largest d2 of all disturbed waves; ties between candidates resolve by the key
+// as in the reference, and a tie with an untouched wave's other points is impossible to lose (their
+// keys are larger than their candidate's, which lost to the argmax).  The centroids' updates
+// commute, so all picks of an exchange are applied together before the next candidates are taken.
+// Everything is wave-uniform and every wave decides alike.  Returns the number of picks (>= 1).
+template <int WAVES, bool FMAD, int MAXP, typename IdxT>
+__device__ __forceinline__ int fps_block_exchange_multi(FpsSlot* slots, int wave, int lane, uint32_t wmax,
+                                                        uint32_t wtie, uint32_t wd2, float sx, float sy,
+                                                        float sz, int limit, int& cur, float& cx, float& cy,
+                                                        float& cz, uint32_t& picked_waves,
+                                                        IdxT* __restrict__ out_i, float* __restrict__ cout_i,
+                                                        int M, float& fx, float& fy, float& fz) {
   if (lane == 0) {
     FpsSlot s;
     s.d = wmax;
@@ -116,41 +141,66 @@ __device__ __forceinline__ bool fps_block_exchange2(FpsSlot* slots, int wave, in
   __syncthreads();
   const FpsSlot s = slots[lane & (WAVES - 1)];
   const uint64_t first = (1ull << WAVES) - 1ull;
-  const uint32_t bmax = row16_max_u32(s.d);
-  uint64_t win = __ballot(s.d == bmax) & first;
-  uint32_t btie;
-  if (__popcll(win) > 1) {
-    const uint32_t cand = (s.d == bmax) ? s.tie : 0xFFFFFFFFu;
-    btie = __builtin_amdgcn_readlane(row16_min_u32(cand), 0);
-    win = __ballot(s.d == bmax && s.tie == btie) & first;
-  } else {
-    btie = __builtin_amdgcn_readlane(s.tie, __ffsll((unsigned long long)win) - 1);
+  uint32_t v = s.d;          // this entry's current min-distance bits (0: picked / nothing left)
+  uint32_t bnd = 0u;         // largest runner-up distance of the disturbed waves
+  int np = 0;
+  uint32_t pw = 0u;          // picked entries (= wave numbers), 4 bits each: the callers re-read their
+                             // coordinates from this exchange buffer instead of keeping 3 MAXP registers
+  // lane k keeps pick k for ONE store per output array (wave 0 writes)
+  int my_idx = 0;
+  float my_x = 0.f, my_y = 0.f, my_z = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    if (k >= limit) break;
+    const uint32_t bmax = row16_max_u32(v);
+    if (k > 0 && (bmax == 0u || bmax <= bnd)) break;
+    uint64_t win = __ballot(v == bmax) & first;
+    uint32_t btie;
+    if (__popcll(win) > 1) {
+      const uint32_t cand = (v == bmax) ? s.tie : 0xFFFFFFFFu;
+      btie = __builtin_amdgcn_readlane(row16_min_u32(cand), 0);
+      win = __ballot(v == bmax && s.tie == btie) & first;
+    } else {
+      btie = __builtin_amdgcn_readlane(s.tie, __ffsll((unsigned long long)win) - 1);
+    }
+    const int xl = __ffsll((unsigned long long)win) - 1;
+    cx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.x), xl));
+    cy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.y), xl));
+    cz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.z), xl));
+    cur = (int)(btie & FPS_JMASK);
+    pw |= (uint32_t)xl << (4 * k);
+    np = k + 1;
+    if (lane == k) {
+      my_idx = cur;
+      my_x = cx;
+      my_y = cy;
+      my_z = cz;
+    }
+    if (k == 0) {   // (callers that keep the pending centroids in registers: MAXP == 2)
+      fx = cx;
+      fy = cy;
+      fz = cz;
+    }
+    if (k + 1 < MAXP) {
+      // the picked wave is disturbed; the other candidates' values after this pick, exactly
+      const bool me = (lane & (WAVES - 1)) == xl;
+      const uint32_t nd = __float_as_uint(dist2<FMAD>(cx, cy, cz, s.x, s.y, s.z));
+      const bool lowered = !me && v != 0u && nd < v;
+      v = me ? 0u : (lowered ? nd : v);
+      const uint32_t dl = (me || lowered) ? s.d2 : 0u;
+      bnd = max(bnd, (uint32_t)__builtin_amdgcn_readlane(row16_max_u32(dl), 0));
+    }
   }
-  const int wl = __ffsll((unsigned long long)win) - 1;
-  cur = (int)(btie & FPS_JMASK);
-  cx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.x), wl));
-  cy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.y), wl));
-  cz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.z), wl));
-  // the best candidate of the other waves against the winner wave's runner-up
-  const uint32_t so = (lane & (WAVES - 1)) == wl ? 0u : s.d;
-  const uint32_t b2 = __builtin_amdgcn_readlane(row16_max_u32(so), 0);
-  const uint32_t d2w = __builtin_amdgcn_readlane(s.d2, wl);
-  if (b2 == 0u || b2 <= d2w) return false;
-  uint64_t win2 = __ballot(so == b2) & first;
-  uint32_t t2;
-  if (__popcll(win2) > 1) {
-    const uint32_t cand = (so == b2) ? s.tie : 0xFFFFFFFFu;
-    t2 = __builtin_amdgcn_readlane(row16_min_u32(cand), 0);
-    win2 = __ballot(so == b2 && s.tie == t2) & first;
-  } else {
-    t2 = __builtin_amdgcn_readlane(s.tie, __ffsll((unsigned long long)win2) - 1);
+  if (wave == 0 && lane < np) {
+    out_i[lane] = (IdxT)my_idx;
+    if (cout_i) {
+      cout_i[lane] = my_x;
+      cout_i[M + lane] = my_y;
+      cout_i[2 * M + lane] = my_z;
+    }
   }
-  const int rl = __ffsll((unsigned long long)win2) - 1;
-  rcur = (int)(t2 & FPS_JMASK);
-  rx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.x), rl));
-  ry = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.y), rl));
-  rz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.z), rl));
-  return !(dist2<FMAD>(cx, cy, cz, rx, ry, rz) < __uint_as_float(b2));
+  picked_waves = pw;
+  return np;
 }
 
 // Read (x[pw], y[pw], z[pw]) of lane `wl` into wave-uniform values.  `pw` is
@@ -871,7 +921,8 @@ __device__ __forceinline__ void fps_update_slot(const float (&x)[PPT], const flo
   }
 }
 
-template <int THREADS, int PPT, bool FMAD, typename IdxT, bool SPEC>
+// MAXP = picks one exchange may settle (1: the plain exchange; 4 by default, see fps_block_exchange_multi)
+template <int THREADS, int PPT, bool FMAD, typename IdxT, int MAXP>
 __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __restrict__ xyz,
                                                              const int* __restrict__ perm,
                                                              const float* __restrict__ gbox,
@@ -880,6 +931,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
                                                              float* __restrict__ ctr, int lg_bs) {
   constexpr int WAVES = THREADS / 64;
   constexpr int GPL = (PPT + 63) / 64;   // group registers per lane: slot p lives in lane p % 64, reg p / 64
+  constexpr bool SPEC = MAXP > 1;
   __shared__ FpsSlot slots[2][FPS_MAX_WAVES];
   extern __shared__ uint16_t orig[];   // [WAVES * PPT * 64] sorted position -> original index
   const int b = blockIdx.x;
@@ -947,20 +999,39 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
   }
 
   // ---- pruned phase ---------------------------------------------------------
-  // SPEC: an exchange may settle TWO picks (fps_block_exchange2); both centroids are then applied
-  // before the next candidates are taken (the updates commute: each is a running minimum).
-  int npend = 1;                       // centroids whose update is still due: (cx,cy,cz)[, (rx,ry,rz)]
+  // MAXP > 1: an exchange may settle several picks (fps_block_exchange_multi); all their centroids
+  // are then applied before the next candidates are taken (the updates commute: each is a running
+  // minimum).
+  int npend = 1;                       // centroids whose update is still due
   int xpar = 0;                        // LDS exchange buffer of the next exchange
-  int rcur = 0;
-  float rx = 0.f, ry = 0.f, rz = 0.f;
+  uint32_t pwaves = 0u;                // their entries in the previous exchange's buffer, 4 bits each
+  [[maybe_unused]] float f0x, f0y, f0z;  // (first pick of an exchange: unused here)
+  if constexpr (SPEC) {                // the hand-over centroid poses as entry 0 of "the previous exchange"
+    if (t == 0) {
+      FpsSlot s0;
+      s0.d = s0.tie = s0.d2 = s0.pad[0] = s0.pad[1] = 0u;
+      s0.x = cx;
+      s0.y = cy;
+      s0.z = cz;
+      slots[1][0] = s0;
+    }
+    __syncthreads();
+  }
   for (int i = i0; i < M;) {
     uint32_t wmax, wtie, wd2 = 0u;
     float sx = cx, sy = cy, sz = cz;
+    [[maybe_unused]] const unsigned long long st0 = S4G_FPS_T();
     // 1. groups the new centroid(s) can still change
     uint32_t gbits[GPL];
 #pragma unroll 1
     for (int q = 0; q < npend; ++q) {
-    const float ux = q ? rx : cx, uy = q ? ry : cy, uz = q ? rz : cz;
+    float ux = cx, uy = cy, uz = cz;
+    if constexpr (SPEC) {   // pick q of the last exchange: its coordinates are still in that buffer
+      const FpsSlot& e = slots[xpar ^ 1][(pwaves >> (4 * q)) & 15u];
+      ux = e.x;
+      uy = e.y;
+      uz = e.z;
+    }
 #pragma unroll
     for (int r = 0; r < GPL; ++r) {
       const bool live = 64 * r + lane < PPT;
@@ -974,6 +1045,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
         lb = __fadd_rn(__fadd_rn(__fmul_rn(tx, tx), __fmul_rn(ty, ty)), __fmul_rn(tz, tz));
       }
       const uint64_t need = __ballot(live && lb < mg[r]);
+      S4G_FPS_ACC(5, __popcll(need));
       // straight-line dispatch: one (rarely taken) scalar branch per 8 slots, then one per
       // slot; every leaf indexes its registers statically.  The volatile asm pins a leaf's
       // arithmetic behind its branch (the compiler would otherwise evaluate all of them).
@@ -1010,6 +1082,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
       gbits[r] = live ? __float_as_uint(mg[r]) : 0u;
     }
     }
+    [[maybe_unused]] const unsigned long long st1 = S4G_FPS_T();
     // 2. this wave's candidate: the group(s) holding the largest maximum
     uint32_t lmax = gbits[0];
 #pragma unroll
@@ -1051,12 +1124,12 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
             if (__popcll(eq) > 1) {
               nbest = 2;
             } else if (nbest == 1) {
-              const uint32_t in_group = wave_max_u32((s < N && lane != wl) ? __float_as_uint(vm) : 0u);
-              uint32_t others = 0u;
+              // max(this group's other points, the other groups' maxima): one wave reduction for both
+              uint32_t others = (s < N && lane != wl) ? __float_as_uint(vm) : 0u;
 #pragma unroll
               for (int r2 = 0; r2 < GPL; ++r2)
                 others = max(others, (r2 == r && lane == gl) ? 0u : gbits[r2]);
-              wd2 = max(in_group, wave_max_u32(others));
+              wd2 = wave_max_u32(others);
             }
           }
           if (kmin < best_key) {
@@ -1072,33 +1145,25 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
       }
       wtie = best_key;
     }
+    [[maybe_unused]] const unsigned long long st2 = S4G_FPS_T();
+    S4G_FPS_ACC(0, st1 - st0);
+    S4G_FPS_ACC(1, st2 - st1);
     if constexpr (SPEC) {
-      // buffer parity per EXCHANGE, not per step: a double pick advances i by two, and slots[i & 1]
-      // would then be rewritten by a fast wave while a slow one still reads the previous exchange
-      const bool two = fps_block_exchange2<WAVES, FMAD>(slots[xpar], wave, lane, wmax, wtie, wd2, sx, sy, sz,
-                                                        cur, cx, cy, cz, rcur, rx, ry, rz) && i + 1 < M;
+      // buffer parity per EXCHANGE, not per step: a multiple pick advances i by more than one, and
+      // slots[i & 1] could then be rewritten by a fast wave while a slow one still reads the previous
+      // exchange
+      npend = fps_block_exchange_multi<WAVES, FMAD, MAXP, IdxT>(slots[xpar], wave, lane, wmax, wtie, wd2, sx, sy,
+                                                                sz, M - i, cur, cx, cy, cz, pwaves, out + i,
+                                                                cout ? cout + i : nullptr, M, f0x, f0y, f0z);
       xpar ^= 1;
-      if (t == 0) {
-        out[i] = (IdxT)cur;
-        if (two) out[i + 1] = (IdxT)rcur;
-        if (cout) {
-          cout[i] = cx;
-          cout[M + i] = cy;
-          cout[2 * M + i] = cz;
-          if (two) {
-            cout[i + 1] = rx;
-            cout[M + i + 1] = ry;
-            cout[2 * M + i + 1] = rz;
-          }
-        }
-      }
-      npend = two ? 2 : 1;
-      if (two) cur = rcur;
       i += npend;
     } else {
       publish(i, wmax, wtie, sx, sy, sz);
       ++i;
     }
+    S4G_FPS_ACC(2, S4G_FPS_T() - st2);
+    S4G_FPS_ACC(3, 1);
+    S4G_FPS_ACC(4, npend);
   }
 }
 
@@ -1128,7 +1193,7 @@ __global__ __launch_bounds__(256) void fps_sorted_aos_kernel(const float* __rest
   out[(size_t)b * cap + s] = make_float4(p[j], p[(size_t)N + j], p[2 * (size_t)N + j], __int_as_float(j));
 }
 
-template <int THREADS, int PPT, bool FMAD, typename IdxT>
+template <int THREADS, int PPT, bool FMAD, typename IdxT, int MAXP>
 __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __restrict__ xyz,
                                                                 const float4* __restrict__ sorted,
                                                                 const float* __restrict__ gbox, int N, int M,
@@ -1184,17 +1249,21 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
     }
   }
 
+  // (two picks per exchange here: with a touched group costing an L2 round trip the update phase
+  // dominates and more picks per exchange only add imbalance -- 9.7 ms against 9.2 for 32 scenes)
+  static_assert(MAXP == 2, "the pending pair lives in registers");
   int npend = 1;
   int xpar = 0;
-  int rcur = 0;
-  float rx = 0.f, ry = 0.f, rz = 0.f;
+  uint32_t pwaves = 0u;
+  float fx = cx, fy = cy, fz = cz;     // first pick of the last exchange; (cx, cy, cz) = its last one
   for (int i = 1; i < M;) {
     uint32_t wmax, wtie, wd2 = 0u;
     float sx = cx, sy = cy, sz = cz;
     uint32_t gbits[GPL];
 #pragma unroll 1
     for (int q = 0; q < npend; ++q) {
-      const float ux = q ? rx : cx, uy = q ? ry : cy, uz = q ? rz : cz;
+      const bool lastp = q == npend - 1;
+      const float ux = lastp ? cx : fx, uy = lastp ? cy : fy, uz = lastp ? cz : fz;
 #pragma unroll
       for (int r = 0; r < GPL; ++r) {
         const bool live = 64 * r + lane < PPT;
@@ -1283,11 +1352,10 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
           if (__popcll(eq) > 1) {
             nbest = 2;
           } else if (nbest == 1) {
-            const uint32_t in_group = wave_max_u32((s < N && lane != wl) ? __float_as_uint(vm) : 0u);
-            uint32_t others = 0u;
+            uint32_t others = (s < N && lane != wl) ? __float_as_uint(vm) : 0u;
 #pragma unroll
             for (int r2 = 0; r2 < GPL; ++r2) others = max(others, (r2 == r && lane == gl) ? 0u : gbits[r2]);
-            wd2 = max(in_group, wave_max_u32(others));
+            wd2 = wave_max_u32(others);
           }
           if (kmin < best_key) {
             best_key = kmin;
@@ -1300,25 +1368,10 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
       if (nbest > 1) wd2 = wmax;
       wtie = best_key;
     }
-    const bool two = fps_block_exchange2<WAVES, FMAD>(slots[xpar], wave, lane, wmax, wtie, wd2, sx, sy, sz, cur,
-                                                      cx, cy, cz, rcur, rx, ry, rz) && i + 1 < M;
-    xpar ^= 1;   // per exchange (a double pick advances i by two)
-    if (t == 0) {
-      out[i] = (IdxT)cur;
-      if (two) out[i + 1] = (IdxT)rcur;
-      if (cout) {
-        cout[i] = cx;
-        cout[M + i] = cy;
-        cout[2 * M + i] = cz;
-        if (two) {
-          cout[i + 1] = rx;
-          cout[M + i + 1] = ry;
-          cout[2 * M + i + 1] = rz;
-        }
-      }
-    }
-    npend = two ? 2 : 1;
-    if (two) cur = rcur;
+    npend = fps_block_exchange_multi<WAVES, FMAD, MAXP, IdxT>(slots[xpar], wave, lane, wmax, wtie, wd2, sx, sy, sz,
+                                                              M - i, cur, cx, cy, cz, pwaves, out + i,
+                                                              cout ? cout + i : nullptr, M, fx, fy, fz);
+    xpar ^= 1;   // per exchange (a multiple pick advances i by more than one)
     i += npend;
   }
 }
@@ -1472,8 +1525,8 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
   S4G_FPS_CASE(512, 50)
 #undef S4G_FPS_CASE
   if (launched && pruned) {
-  // two picks per exchange where the runner-up is out of the winner's reach (S4G_FPS_SPEC=0: one)
-  static const bool spec = [] { const char* e = getenv("S4G_FPS_SPEC"); return !(e && e[0] == '0'); }();
+  // picks one exchange may settle: S4G_FPS_SPEC=0 (or 1): one, 2: round 2's two, default 4
+  static const int spec = [] { const char* e = getenv("S4G_FPS_SPEC"); const int v = e ? atoi(e) : 4; return v <= 1 ? 1 : (v < 4 ? 2 : 4); }();
 #define S4G_FPS_PRUNED_LAUNCH(T, P, S)                                                             \
   {                                                                                                \
     static LdsAttrCache lds_cache;                                                                 \
@@ -1488,7 +1541,7 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
     hipLaunchKernelGGL(fps_group_box_kernel, dim3((G + 3) / 4, (unsigned)B), dim3(256), 0, stream, \
                        xyz, w.val_out, (int)N, G, w.gbox);                                         \
     S4G_LAUNCH_CHECK();                                                                            \
-    if (spec) S4G_FPS_PRUNED_LAUNCH(T, P, true) else S4G_FPS_PRUNED_LAUNCH(T, P, false)            \
+    if (spec == 4) S4G_FPS_PRUNED_LAUNCH(T, P, 4) else if (spec == 2) S4G_FPS_PRUNED_LAUNCH(T, P, 2) else S4G_FPS_PRUNED_LAUNCH(T, P, 1) \
     S4G_LAUNCH_CHECK();                                                                            \
     return S4G_OK;                                                                                 \
   }
@@ -1521,7 +1574,7 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
       hipLaunchKernelGGL(fps_sorted_aos_kernel, dim3((FPS_L2_CAP + 255) / 256, (unsigned)B), dim3(256), 0,
                          stream, xyz, w2.val_out, (int)N, FPS_L2_CAP, w2.aos);
       S4G_LAUNCH_CHECK();
-      hipLaunchKernelGGL((fps_pruned_l2_kernel<512, 100, FMAD, IdxT>), grid, dim3(512), 0, stream, xyz,
+      hipLaunchKernelGGL((fps_pruned_l2_kernel<512, 100, FMAD, IdxT, 2>), grid, dim3(512), 0, stream, xyz,
                          w2.aos, w2.gbox, (int)N, (int)M, idx, ctr, lg);
       S4G_LAUNCH_CHECK();
       return S4G_OK;
@@ -1565,6 +1618,17 @@ size_t fps_workspace_bytes(int64_t B, int64_t N) {
 }
 
 }  // namespace s4g
+
+#ifdef S4G_FPS_STAMPS
+extern "C" int s4g_debug_fps_stamps(unsigned long long* host_out_64x8x8, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(host_out_64x8x8, HIP_SYMBOL(s4g::g_fps_acc), sizeof(unsigned long long) * 64 * 8 * 8);
+  if (e == hipSuccess && reset) {
+    static unsigned long long zeros[64 * 8 * 8];
+    e = hipMemcpyToSymbol(HIP_SYMBOL(s4g::g_fps_acc), zeros, sizeof(zeros));
+  }
+  return (int)e;
+}
+#endif
 
 extern "C" int s4g_fps_f32(const float* xyz_b3n, int64_t B, int64_t N,
                            int64_t M, int64_t* idx_bm, void* ws,
