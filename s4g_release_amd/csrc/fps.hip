@@ -14,8 +14,8 @@
 //   * fps_pruned_kernel     10 240 < N <= 25 600 (default there): the scene in Morton order, 64-point
 //                           groups with a box and an exact maximum each; a step rescans only the
 //                           groups the new centroid can still change (exact: the bound uses the
-//                           distance contract's own monotone arithmetic); two picks per exchange
-//                           where the runner-up is out of the winner's reach;
+//                           distance contract's own monotone arithmetic); up to four picks per
+//                           exchange (candidates re-ranked exactly, fps_block_exchange_multi);
 //   * fps_pruned_l2_kernel  25 600 < N <= 51 200 (default there): the same, with only the
 //                           min-distances resident and the coordinates of a touched group read
 //                           from the Morton-sorted records in L2 -- one CU per scene;

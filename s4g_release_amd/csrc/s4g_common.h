@@ -59,10 +59,14 @@ __device__ __forceinline__ float dist2(float x1, float y1, float z1, float x2,
 // ---- DPP helpers (gfx9 encodings) ------------------------------------------
 // quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E,
 // row_half_mirror = 0x141, row_mirror = 0x140.
+// (old = 0 with bound_ctrl: every lane of these permutations has a valid source, so the value is
+// the same as with old = v -- but in this form the compiler folds the move into its consumer,
+// `v_max_u32_dpp v, v, v quad_perm:...` = ONE instruction per reduction step instead of
+// mov / nop / mov_dpp / max: half the instructions and half the dependent chain of every
+// row16_* / wave_* reduction below)
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF,
-                                               false);
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
 
 // After these four steps every lane holds the max of its row of 16 lanes.
