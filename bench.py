@@ -52,7 +52,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3      # fp32-in MFMA = fp32 vector peak
 BF16_MFMA_PEAK_TF = 2500.0     # dense bf16 / fp16 MFMA (no sparsity)
 GFLOP_PER_SCENE = 203.48       # SURVEY.md Appendix B (BN folded, 2*MAC), N = 25 600
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
 
 
 def parse(argv=None):
@@ -156,7 +156,7 @@ def source_stamp():
 
 
 def load_traffic(key):
-    """(bytes, source, None) of `key` in profiles/r02_traffic.json when its stamp matches this
+    """(bytes, source, None) of `key` in profiles/r03_traffic.json when its stamp matches this
     tree, else (None, None, reason)."""
     try:
         with open(TRAFFIC_FILE) as f:

@@ -361,6 +361,8 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void bq_grid_query_kernel(
   const float ox = px[0], oy = py[0], oz = pz[0];
   const bool scene_ok = ws.flags[b] == 0;
   const float4* __restrict__ rec = ws.sorted + (size_t)b * GR_RANGES * N;
+  const __amdgpu_buffer_rsrc_t rrec =
+      __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, (int)((size_t)GR_RANGES * N * sizeof(float4)), 0x00020000);
   const int* __restrict__ starts_b = ws.starts + (size_t)b * GR_RANGES * GR_START_STRIDE;
 
   // lane l holds centroid m0 + l
@@ -419,11 +421,17 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void bq_grid_query_kernel(
         const int je = grp < 9 ? __shfl(piece == 0 ? end0 : end1, src) : 0;
         if (grp >= 9) j = 0;
         while (__any(j < je)) {
-          // unconditional loads (record 0 for lanes past their row): a guarded load makes the
-          // compiler wait for each one before issuing the next
+          // ALL BQ_REC record loads go out before any is tested: buffer loads (descriptor + a 32-bit
+          // lane offset: no per-load 64-bit address arithmetic; a lane past its row reads whatever
+          // follows -- or zeros past the end of the array -- and ignores it), pinned by an empty asm:
+          // left to itself the compiler sinks the first load INTO the guarded hit test and splits off
+          // its index word, two dependent round trips per iteration
           float4 p[BQ_REC];
 #pragma unroll
-          for (int u = 0; u < BQ_REC; ++u) p[u] = rec[j + 7 * u < je ? j + 7 * u : 0];
+          for (int u = 0; u < BQ_REC; ++u)
+            p[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrec, (j + 7 * u) * 16, 0, 0));
+#pragma unroll
+          for (int u = 0; u < BQ_REC; ++u) asm volatile("" : "+v"(p[u].x), "+v"(p[u].y), "+v"(p[u].z), "+v"(p[u].w));
 #pragma unroll
           for (int u = 0; u < BQ_REC; ++u)
             if (j + 7 * u < je && dist2<FMAD>(cx, cy, cz, p[u].x, p[u].y, p[u].z) < r2) {

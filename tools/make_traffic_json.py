@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""profiles/r02_traffic.json + profiles/r02_pmc_counters.md from the PMC csv files that
-tools/profile_r2.sh left under gpurun_out/r2prof/ (run in the build container after the gpurun call).
+"""profiles/r0N_traffic.json + profiles/r0N_pmc_counters.md from the PMC csv files that
+tools/profile_r<N>.sh left under gpurun_out/r<N>prof/ (N = S4G_PROFILE_ROUND, default 3) (run in the build container after the gpurun call).
 
 HBM-side bytes per launch = FETCH_SIZE + WRITE_SIZE (KiB counters, separate passes).  gfx950's
 FETCH_SIZE counts 64 B for every 128-B request of a 16-byte-per-lane streaming read
@@ -21,7 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-O = os.path.join(ROOT, "gpurun_out", "r2prof")
+RND = int(os.environ.get("S4G_PROFILE_ROUND", "3"))      # which round's capture (tools/profile_r<N>.sh)
+O = os.path.join(ROOT, "gpurun_out", "r%dprof" % RND)
 CONTRACTION = ("mlp_chain_kernel", "mlp_heads_kernel", "mlp_gemm_")
 
 
@@ -65,7 +66,7 @@ def step_totals(tag, steps):
 def main():
     stamp = bench.source_stamp()
     entries = {}
-    md = ["# Round 2 -- PMC passes (rocprofv3 --pmc, one counter per pass, tools/profile_r2.sh)", "",
+    md = ["# Round %d -- PMC passes (rocprofv3 --pmc, one counter per pass, tools/profile_r%d.sh)" % (RND, RND), "",
           "Source stamp of the measured tree: `%s`.  FETCH_SIZE of the contraction kernels is x2-corrected "
           "(16-byte-per-lane streaming reads, see tools/make_traffic_json.py); WRITE_SIZE as measured." % stamp, ""]
     for tag, key, label in (("default", "contractions[step,B=16,N=25600,precision=f16x2]", "default bench (16 x 25 600, f16x2)"),
@@ -77,7 +78,7 @@ def main():
                         "launches_per_step": n, "source_stamp": stamp,
                         "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 2 "
                                   "--warmup 1 --no-pipeline`, FETCH_SIZE x2-corrected for the 16 B/lane streams, "
-                                  "tools/make_traffic_json.py, profiles/r02_pmc_counters.md"}
+                                  "tools/make_traffic_json.py, profiles/r%02d_pmc_counters.md" % RND}
         md += ["## Contraction launches of one step, %s" % label, "",
                "| kernel | launches (3 steps) | FETCH MB / launch (x2) | WRITE MB / launch |", "|---|---:|---:|---:|"]
         for k, nl, fl, wl in sorted(rows, key=lambda r: -(r[2] + r[3]) * r[1]):
@@ -100,7 +101,7 @@ def main():
             "traffic_bytes": int(pair), "source_stamp": stamp,
             "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/bench_ops.py --ops ball,group; "
                       "grid build + SA1-size query + xyz_to_aos + group_xyz_aos, one launch each; FETCH_SIZE as measured "
-                      "(4-byte plane reads / 16-byte gathers: a lower bound), profiles/r02_pmc_counters.md"}
+                      "(4-byte plane reads / 16-byte gathers: a lower bound), profiles/r%02d_pmc_counters.md" % RND}
         md += ["", "Pair (build + query + AoS copy + group): **%.1f MB** per launch set against 158.3 MB algorithmic." % (pair / 1e6), ""]
     # SQ counters of the dominant kernels
     for tag in ("default", "cfg4"):
@@ -156,9 +157,9 @@ def main():
                 k[:60], d["_n"], d["_us"] / max(d["_n"], 1), mhz,
                 100.0 * d["SQ_VALU_MFMA_BUSY_CYCLES"] / (128.0 * max(d["GRBM_GUI_ACTIVE"], 1.0)), mhz / 2400.0))
         md.append("")
-    with open(os.path.join(ROOT, "profiles", "r02_traffic.json"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "r%02d_traffic.json" % RND), "w") as f:
         json.dump(entries, f, indent=1)
-    with open(os.path.join(ROOT, "profiles", "r02_pmc_counters.md"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "r%02d_pmc_counters.md" % RND), "w") as f:
         f.write("\n".join(md) + "\n")
     print("wrote %d traffic entries, stamp %s" % (len(entries), stamp))
 
