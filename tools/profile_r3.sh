@@ -2,7 +2,7 @@
 # Round-3 profile capture on the GPU box (run through gpurun from the repo root):
 #   kernel-trace + stats of the default bench and of configs[4], then separate PMC passes
 #   (FETCH_SIZE / WRITE_SIZE cannot share a pass) for the contraction launches of one step and
-#   for the ball_query + group_points operator pair.  Outputs land in gpurun_out/r2prof/;
+#   for the ball_query + group_points operator pair.  Outputs land in gpurun_out/r3prof/;
 #   tools/make_traffic_json.py turns the PMC csv files into profiles/r03_traffic.json.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}

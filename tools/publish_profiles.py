@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copy a tools/profile_r2.sh capture (gpurun_out/r2prof) into profiles/: kernel-stats tables with
+"""Copy a tools/profile_r<N>.sh capture (gpurun_out/r<N>prof, N = S4G_PROFILE_ROUND, default 3) into profiles/: kernel-stats tables with
 their command header, the un-profiled bench lines; then tools/make_traffic_json.py for the PMC part."""
 import json
 import os
@@ -7,10 +7,12 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-O = os.path.join(ROOT, "gpurun_out", "r2prof")
+RND = int(os.environ.get("S4G_PROFILE_ROUND", "3"))
+O = os.path.join(ROOT, "gpurun_out", "r%dprof" % RND)
 LEGEND = ("Template arguments: mlp_chain_kernel<loader, epilogue, RW, KC, PL> (loader 0 plain, 3 GATHER_MLP1, 4 GATHER_ADD, "
           "5 INTERP_ADD; epilogue 0 store, 1 max; RW 2 / 1 / 8 = 128- / 256- / 512-wide; PL 2 = f16x2, 1 = bf16), "
-          "mlp_heads_kernel<PL, ring depth, 32-position blocks>, mlp_gemm_f16x2_kernel<loader, epilogue, NCB, PL>.")
+          "mlp_heads_kernel<PL, ring depth, 32-position blocks, FP tail in front>, mlp_gemm_f16x2_kernel<loader, epilogue, NCB, PL>, "
+          "fps_pruned_kernel<threads, points per lane, fmad, index type, picks per exchange>.")
 
 
 def line(path):
@@ -24,16 +26,16 @@ def main():
                               "cfg4 configuration")):
         prof = line(os.path.join(O, "bench_%s_profiled.json" % tag))
         table = open(os.path.join(O, "%s_kernel_stats.md" % tag)).read()
-        head = ["# Round 2 -- rocprofv3 --kernel-trace --stats, %s" % title, "",
-                "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py %s` (tools/profile_r2.sh); bench line of the "
+        head = ["# Round %d -- rocprofv3 --kernel-trace --stats, %s" % (RND, title), "",
+                "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py %s` (tools/profile_r%d.sh); bench line of the "
                 "profiled run: %.1f scenes/s, %.2f ms/step, contractions %.2f ms/step (HIP events); un-profiled run of the "
-                "same build: profiles/r02_bench_%s.json." % (args, prof["value"], prof["ms_per_step"],
-                                                              prof["roofline"]["ms_per_step"], tag),
+                "same build: profiles/r%02d_bench_%s.json." % (args, RND, prof["value"], prof["ms_per_step"],
+                                                               prof["roofline"]["ms_per_step"], RND, tag),
                 LEGEND, ""]
-        with open(os.path.join(ROOT, "profiles", "r02_%s_kernel_stats.md" % tag), "w") as f:
+        with open(os.path.join(ROOT, "profiles", "r%02d_%s_kernel_stats.md" % (RND, tag)), "w") as f:
             f.write("\n".join(head) + "\n" + table)
         raw = [l for l in open(os.path.join(O, "bench_%s.json" % tag)) if l.startswith("{")][0]
-        with open(os.path.join(ROOT, "profiles", "r02_bench_%s.json" % tag), "w") as f:
+        with open(os.path.join(ROOT, "profiles", "r%02d_bench_%s.json" % (RND, tag)), "w") as f:
             f.write(raw)
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_traffic_json.py")])
 
