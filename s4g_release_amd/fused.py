@@ -1,26 +1,37 @@
 """Inference fast path of the S4G network on MI355X.
 
 Same function as `model.PointNet2.forward` in eval mode (reference
-`network_models/models/PointNet2_tcls.py:99-148`), restructured for the
-hardware instead of for torch's operator set:
+`network_models/models/PointNet2_tcls.py:99-148`), restructured for the hardware instead of for
+torch's operator set.  What a forward pass launches (round 3, default f16x2 arithmetic):
 
-  * BatchNorm (eval) is folded into the 1x1-conv weights once:
+  * BatchNorm (eval) is folded into the 1x1-conv weights once (fp64, rounded once):
     W' = W * gamma / sqrt(var + eps),  b' = beta - mean * gamma / sqrt(var + eps)
     (reference nn_utils/conv.py:28-34: conv -> bn -> relu);
-  * every activation is channels-last and every layer is ONE launch of the
-    fp32-MFMA contraction `s4g_mlp_gemm_f32` with a fused loader (grouping +
-    centroid subtraction + concat, or 3-NN interpolation + concat) and a fused
-    epilogue (bias, ReLU, max over the K neighbours, or the channel-first head
-    outputs with the movable-head sigmoid);  the (B,C,M,K) grouped tensors and
-    the (B,C,N) interpolated tensors are never materialised;
-  * the four heads share their input, so their first layers run as one
-    256 -> 4x512 contraction, the middle layers as 4-group launches and the
-    four logit layers as one block-diagonal 512 -> 21 contraction;
-  * FPS also emits the centroid coordinates (no gather launch), ball query and
-    3-NN emit int32 indices, 3-NN emits the interpolation weights directly.
+  * activations are channels-last fp32 in HBM; a contraction splits its operands into two scaled
+    fp16 planes and runs three `v_mfma_f32_32x32x16_f16` products per MAC with fp32 accumulation
+    (fp32-class error); `precision=` selects fp32 MFMA, the exact 3 x bf16 split or plain bf16;
+  * SET ABSTRACTION level l: the first shared-MLP layer is linear, so its feature part is applied
+    once per POINT (`sa{l}.0f`, a plain tiled launch) and the remaining two layers + the max over
+    the K neighbours are ONE chain launch whose loader gathers that row, adds the xyz part + bias
+    and applies the ReLU (`sa{l}.1+sa{l}.2`, intermediate activations stay in LDS); level 0 has no
+    input features: its first layer is evaluated in the loader from pre-gathered (xyz_j - centre)
+    records;
+  * FEATURE PROPAGATION level fi: the first layer is applied to the sparse and to the skip features
+    BEFORE the 3-NN interpolation (`fp{fi}.0s`, `fp{fi}.0d`); level 0 sums through
+    `interp_add_cl_kernel` and runs its 1 024-wide second layer as a tiled launch; level 1's sum
+    is formed in the loader of a chain launch that also applies level 2's linear first layer
+    (`fp1.1+fp2.0s`); level 2's sum and its two 256-wide layers run INSIDE the heads launch;
+  * the four heads (`PointNet2_tcls.py:126-140`) with that tail in front are ONE launch
+    (`s4g_heads_chain_f32`): the 64-position input panel and every hidden activation stay in LDS,
+    the logits leave as channel-first rows;
+  * FPS also emits the centroid coordinates (no gather launch), ball query and 3-NN emit int32
+    indices, 3-NN emits the interpolation weights directly.
+Twelve contraction launches per forward pass.  `submit()` runs the coordinate-only work (FPS
+pyramid, ball queries, 3-NN) on high-priority geometry streams underneath the previous batch's
+contractions.
 
-The geometry (FPS / ball query / 3-NN) uses exactly the kernels behind the
-operator API, so indices are bit-identical to `functions.py`.
+The geometry uses exactly the kernels behind the operator API, so indices are bit-identical to
+`functions.py`; per-scene activation scales make a scene's outputs independent of its batch.
 """
 import ctypes
 import os
