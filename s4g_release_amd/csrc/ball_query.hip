@@ -225,7 +225,10 @@ __global__ __launch_bounds__(GR_BUILD_THREADS) void bq_grid_build_kernel(
     int4* __restrict__ ce = cw.cells + ((size_t)b * GR_RANGES + g) * GR_RANGE_SLOTS;
     const uint32_t pos = wbase2 + (incl2 - nzc);
     if (s) ce[pos] = make_int4((g << 12) | (4 * t), (int)base, (int)s, 0);
-    if (t == GR_BUILD_THREADS - 1) cw.ncell[b * GR_RANGES + g] = (int)(pos + (s ? 1u : 0u));
+    if (t == GR_BUILD_THREADS - 1) {
+      cw.ncell[b * GR_RANGES + g] = (int)(pos + (s ? 1u : 0u));
+      cw.ncell[(gridDim.y + b) * GR_RANGES + g] = (int)(wbase + incl);  // records of this stripe
+    }
   }
   __syncthreads();
 
@@ -793,12 +796,12 @@ int launch_grid_build(const float* xyz, int64_t B, int64_t N, float inv_h, GridW
 
 int launch_grid_build_queries(const float* xyz, const float* ctr, int64_t B, int64_t N,
                               int64_t M, float inv_h, GridWs ws, CellWs cw, hipStream_t st,
-                              bool write_aos) {
+                              bool write_aos, const float* inv_h_dev) {
   const int64_t big = N > M ? N : M;
 #define S4G_GB_LAUNCH(P)                                                                  \
   hipLaunchKernelGGL(bq_grid_build_kernel<P>, dim3(2 * GR_RANGES, (unsigned)B),          \
                      dim3(GR_BUILD_THREADS), 0, st, xyz, (int)N, inv_h, ws, write_aos ? 1 : 0, \
-                     ctr, (int)M, cw, (const float*)nullptr)
+                     ctr, (int)M, cw, inv_h_dev)
   if (big <= 8 * GR_BUILD_THREADS) S4G_GB_LAUNCH(8);
   else if (big <= 25 * GR_BUILD_THREADS) S4G_GB_LAUNCH(25);
   else S4G_GB_LAUNCH(0);

@@ -46,7 +46,7 @@ inline GridWs grid_ws_carve(void* ws, int64_t B, int64_t N) {
 struct CellWs {
   float4* sorted;  // [B][GR_RANGES * M] records (x, y, z, query index bits)
   int4* cells;     // [B][GR_RANGES][GR_RANGE_SLOTS] (first slot, first record, count, 0), compacted
-  int* ncell;      // [B][GR_RANGES] entries used in `cells`
+  int* ncell;      // [B][GR_RANGES] entries used in `cells`, then [B][GR_RANGES] query records per stripe
 };
 
 inline size_t cell_ws_bytes(int64_t B, int64_t M) {
@@ -93,6 +93,6 @@ int launch_grid_build(const float* xyz, int64_t B, int64_t N, float inv_h, GridW
 // into `cw` (cells relative to the same origin as the points').
 int launch_grid_build_queries(const float* xyz, const float* ctr, int64_t B, int64_t N,
                               int64_t M, float inv_h, GridWs ws, CellWs cw, hipStream_t st,
-                              bool write_aos);
+                              bool write_aos, const float* inv_h_dev = nullptr);
 
 }  // namespace s4g

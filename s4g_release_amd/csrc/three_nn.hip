@@ -269,10 +269,16 @@ __global__ __launch_bounds__(1024) void nn_auto_cell_kernel(const float* __restr
   }
 }
 
+// Lane per query, queries taken in CELL order (the build launch bins them into the keys' grid,
+// `cw`): the 64 queries of a wave sit in a few x-adjacent cells, so their 9 key rows are the
+// same lines (coalesced / broadcast loads, equal trip counts) instead of 64 unrelated walks.
+// Per query: the 9 rows' record ranges up front (18 independent loads, the rare x-wrap pieces
+// apart), then the rows in groups of three with four range-checked buffer loads in flight per
+// row; the insertion is branch-free (a (d, index)-ordered triple, as the scan kernels keep it).
 template <bool FMAD, bool WEIGHTS, typename IdxT>
 __global__ __launch_bounds__(NN_THREADS) void three_nn_grid_kernel(
-    const float* __restrict__ q, const float* __restrict__ key, int N1, int N2, float inv_h,
-    float d2_done, GridWs ws, float eps, IdxT* __restrict__ idx, float* __restrict__ out,
+    const float* __restrict__ key, int N1, int N2, float inv_h, float d2_done, GridWs ws,
+    CellWs cw, float eps, IdxT* __restrict__ idx, float* __restrict__ out,
     int* __restrict__ fail_list, int* __restrict__ fail_count,
     const float* __restrict__ cell_dev = nullptr) {
   if (cell_dev) {  // (1 / cell, acceptance bound) chosen by nn_auto_cell_kernel
@@ -280,11 +286,23 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_grid_kernel(
     d2_done = cell_dev[1];
   }
   const int b = blockIdx.y;
-  const int i = blockIdx.x * NN_THREADS + threadIdx.x;
-  if (i >= N1) return;
-  const float* __restrict__ qx = q + (size_t)b * 3 * N1;
+  int r = blockIdx.x * NN_THREADS + threadIdx.x;
+  if (r >= N1) return;
+  // record r of the scene's cell-ordered queries: 8 stripes, each with its own count
+  const int* __restrict__ cnt = cw.ncell + ((size_t)gridDim.y + b) * GR_RANGES;
+  int g = 0;
+#pragma unroll
+  for (int k = 0; k < GR_RANGES - 1; ++k) {
+    const int c = cnt[k];
+    if (g == k && r >= c) {
+      r -= c;
+      g = k + 1;
+    }
+  }
+  const float4 qr = cw.sorted[((size_t)b * GR_RANGES + g) * N1 + r];
+  const int i = __float_as_int(qr.w);
+  const float x1 = qr.x, y1 = qr.y, z1 = qr.z;
   const float* __restrict__ kx = key + (size_t)b * 3 * N2;
-  const float x1 = qx[i], y1 = qx[N1 + i], z1 = qx[2 * N1 + i];
   const float ox = kx[0], oy = kx[N2], oz = kx[2 * N2];
   const bool exact = ws.flags[b] == 0 && grid_coord_ok(x1, ox, inv_h) &&
                      grid_coord_ok(y1, oy, inv_h) && grid_coord_ok(z1, oz, inv_h);
@@ -293,49 +311,83 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_grid_kernel(
   if (exact) {
     const int icx = grid_coord(x1, ox, inv_h), icy = grid_coord(y1, oy, inv_h),
               icz = grid_coord(z1, oz, inv_h);
-    const float4* __restrict__ rec = ws.sorted + (size_t)b * GR_RANGES * N2;
+    const __amdgpu_buffer_rsrc_t rrec = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(ws.sorted + (size_t)b * GR_RANGES * N2), 0, GR_RANGES * N2 * 16, 0x00020000);
     const int* __restrict__ starts_b = ws.starts + (size_t)b * GR_RANGES * GR_START_STRIDE;
     const int x0 = (icx - 1) & 31;
-    for (int r = 0; r < 9; ++r) {
-      const int zz = (icz + r / 3 - 1) & 31, yy = (icy + r % 3 - 1) & 31;
+    const bool wrap = x0 > GR_DIM - 3;
+    const int xe = wrap ? GR_DIM : x0 + 3;
+    int beg[9], n0[9], beg1[9], n1[9];
+#pragma unroll
+    for (int rr = 0; rr < 9; ++rr) {
+      const int zz = (icz + rr / 3 - 1) & 31, yy = (icy + rr % 3 - 1) & 31;
       const int* __restrict__ st = starts_b + grid_range(yy, zz) * GR_START_STRIDE +
                                    grid_local_row(yy, zz);
-      int beg[2], end[2];
-      if (x0 <= GR_DIM - 3) {
-        beg[0] = st[x0];
-        end[0] = st[x0 + 3];
-        beg[1] = end[1] = 0;
-      } else {
-        beg[0] = st[x0];
-        end[0] = st[GR_DIM];
-        beg[1] = st[0];
-        end[1] = st[(x0 + 3) & 31];
+      beg[rr] = st[x0];
+      n0[rr] = st[xe] - beg[rr];
+      beg1[rr] = 0;
+      n1[rr] = 0;
+    }
+    if (__ballot(wrap) != 0ull) {  // the window crosses the torus seam: a second piece
+#pragma unroll
+      for (int rr = 0; rr < 9; ++rr) {
+        const int zz = (icz + rr / 3 - 1) & 31, yy = (icy + rr % 3 - 1) & 31;
+        const int* __restrict__ st = starts_b + grid_range(yy, zz) * GR_START_STRIDE +
+                                     grid_local_row(yy, zz);
+        beg1[rr] = st[0];
+        n1[rr] = wrap ? st[(x0 + 3) & 31] - beg1[rr] : 0;
+      }
+    }
+    auto visit = [&](const float4 p, bool valid) {
+      const int j = valid ? __float_as_int(p.w) : 0x7FFFFFFF;
+      float d = dist2<FMAD>(p.x, p.y, p.z, x1, y1, z1);
+      d = valid ? d : __builtin_inff();
+      const bool c0 = nn_less(d, j, b0, i0), c1 = nn_less(d, j, b1, i1), c2 = nn_less(d, j, b2, i2);
+      const bool c01 = c0 | c1;
+      b2 = c01 ? b1 : (c2 ? d : b2);
+      i2 = c01 ? i1 : (c2 ? j : i2);
+      b1 = c0 ? b0 : (c1 ? d : b1);
+      i1 = c0 ? i0 : (c1 ? j : i1);
+      b0 = c0 ? d : b0;
+      i0 = c0 ? j : i0;
+    };
+    // element t of a row: piece 0 then piece 1; past the end -> an out-of-range offset (reads 0)
+    auto rec_off = [&](int rr, int t) -> int {
+      const int j = t < n0[rr] ? beg[rr] + t : beg1[rr] + (t - n0[rr]);
+      return t < n0[rr] + n1[rr] ? j * 16 : 0x7FFFFFF0;
+    };
+#pragma unroll
+    for (int grp = 0; grp < 3; ++grp) {
+      float4 p[12];
+#pragma unroll
+      for (int u = 0; u < 12; ++u)
+        p[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                              rrec, rec_off(grp * 3 + u / 4, u % 4), 0, 0));
+#pragma unroll
+      for (int u = 0; u < 12; ++u)  // pinned: no sinking of a load into its use
+        asm volatile("" : "+v"(p[u].x), "+v"(p[u].y), "+v"(p[u].z), "+v"(p[u].w));
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        const int rr = grp * 3 + u / 4;
+        visit(p[u], (u % 4) < n0[rr] + n1[rr]);
       }
 #pragma unroll
-      for (int piece = 0; piece < 2; ++piece)
-        for (int j = beg[piece]; j < end[piece]; ++j) {
-          const float4 p = rec[j];
-          const int kj = __float_as_int(p.w);
-          const float d = dist2<FMAD>(p.x, p.y, p.z, x1, y1, z1);
-          if (nn_less(d, kj, b2, i2)) {
-            if (nn_less(d, kj, b1, i1)) {
-              b2 = b1;
-              i2 = i1;
-              if (nn_less(d, kj, b0, i0)) {
-                b1 = b0;
-                i1 = i0;
-                b0 = d;
-                i0 = kj;
-              } else {
-                b1 = d;
-                i1 = kj;
-              }
-            } else {
-              b2 = d;
-              i2 = kj;
-            }
-          }
+      for (int k = 0; k < 3; ++k) {
+        const int rr = grp * 3 + k;
+        const int n = n0[rr] + n1[rr];
+        for (int t = 4; t < n; t += 4) {
+          float4 q4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            q4[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   rrec, rec_off(rr, t + u), 0, 0));
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            asm volatile("" : "+v"(q4[u].x), "+v"(q4[u].y), "+v"(q4[u].z), "+v"(q4[u].w));
+#pragma unroll
+          for (int u = 0; u < 4; ++u) visit(q4[u], t + u < n);
         }
+      }
     }
   }
   const bool done = exact && i2 != 0x7FFFFFFF && b2 < d2_done;
@@ -346,40 +398,34 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_grid_kernel(
   }
 }
 
-// One wave per unanswered query: lanes stride the keys, each keeps its own
-// (d, index)-ordered triple, three wave-argmin rounds merge them.
+// One workgroup per unanswered query (a handful per batch, so the walk over all keys is pure
+// latency: four waves x eight strides of loads in flight per round trip).  Lanes keep their own
+// (d, index)-ordered triple, three wave-argmin rounds merge a wave's, wave 0 merges the four.
 template <bool FMAD, bool WEIGHTS, typename IdxT>
 __global__ __launch_bounds__(NN_THREADS) void three_nn_fallback_kernel(
     const float* __restrict__ q, const float* __restrict__ key, int N1, int N2, float eps,
     IdxT* __restrict__ idx, float* __restrict__ out, const int* __restrict__ fail_list,
     const int* __restrict__ fail_count) {
-  const int lane = threadIdx.x & 63;
-  const int wave0 = blockIdx.x * (NN_THREADS / 64) + (threadIdx.x >> 6);
-  const int nwaves = gridDim.x * (NN_THREADS / 64);
+  constexpr int NW = NN_THREADS / 64;
+  __shared__ float sd[NW * 3];
+  __shared__ int sj[NW * 3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int count = *fail_count;
-  for (int f = wave0; f < count; f += nwaves) {
-    const int qi = fail_list[f];
-    const int b = qi / N1, i = qi - b * N1;
-    const float* __restrict__ qx = q + (size_t)b * 3 * N1;
-    const float* __restrict__ kx = key + (size_t)b * 3 * N2;
-    const float x1 = qx[i], y1 = qx[N1 + i], z1 = qx[2 * N1 + i];
-    float b0 = __builtin_inff(), b1 = __builtin_inff(), b2 = __builtin_inff();
-    int i0 = 0x7FFFFFFF, i1 = 0x7FFFFFFF, i2 = 0x7FFFFFFF;
-    for (int j = lane; j < N2; j += 64) {
-      const float d = dist2<FMAD>(kx[j], kx[N2 + j], kx[2 * N2 + j], x1, y1, z1);
-      if (nn_less(d, j, b2, i2)) {
-        if (nn_less(d, j, b1, i1)) {
-          b2 = b1; i2 = i1;
-          if (nn_less(d, j, b0, i0)) { b1 = b0; i1 = i0; b0 = d; i0 = j; }
-          else { b1 = d; i1 = j; }
-        } else { b2 = d; i2 = j; }
-      }
-    }
-    float rd[3];
-    int rj[3];
+  auto insert = [](float d, int j, float& b0, float& b1, float& b2, int& i0, int& i1, int& i2) {
+    const bool c0 = nn_less(d, j, b0, i0), c1 = nn_less(d, j, b1, i1), c2 = nn_less(d, j, b2, i2);
+    const bool c01 = c0 | c1;
+    b2 = c01 ? b1 : (c2 ? d : b2);
+    i2 = c01 ? i1 : (c2 ? j : i2);
+    b1 = c0 ? b0 : (c1 ? d : b1);
+    i1 = c0 ? i0 : (c1 ? j : i1);
+    b0 = c0 ? d : b0;
+    i0 = c0 ? j : i0;
+  };
+  // pops the wave's three smallest heads by (d, index) into rd / rj (wave-uniform)
+  auto merge3 = [&](float& b0, float& b1, float& b2, int& i0, int& i1, int& i2, float* rd, int* rj) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      // wave-wide minimum of the lanes' heads by (d, index); d >= 0 so its bits order like u32
+      // d >= 0 so its bits order like u32
       const uint32_t dm = wave_min_u32(__float_as_uint(b0));
       const uint32_t jm = wave_min_u32(__float_as_uint(b0) == dm ? (uint32_t)i0 : 0xFFFFFFFFu);
       rd[k] = __uint_as_float(dm);
@@ -388,9 +434,55 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_fallback_kernel(
         b0 = b1; i0 = i1; b1 = b2; i1 = i2; b2 = __builtin_inff(); i2 = 0x7FFFFFFF;
       }
     }
-    if (lane == 0)
-      nn_write<WEIGHTS, IdxT>(idx, out, ((size_t)b * N1 + i) * 3, rj[0], rj[1], rj[2], rd[0], rd[1],
-                              rd[2], eps);
+  };
+  for (int f = blockIdx.x; f < count; f += gridDim.x) {
+    const int qi = fail_list[f];
+    const int b = qi / N1, i = qi - b * N1;
+    const float* __restrict__ qx = q + (size_t)b * 3 * N1;
+    const float* __restrict__ kx = key + (size_t)b * 3 * N2;
+    const float x1 = qx[i], y1 = qx[N1 + i], z1 = qx[2 * N1 + i];
+    float b0 = __builtin_inff(), b1 = __builtin_inff(), b2 = __builtin_inff();
+    int i0 = 0x7FFFFFFF, i1 = 0x7FFFFFFF, i2 = 0x7FFFFFFF;
+    constexpr int FU = 8;
+    for (int j0 = threadIdx.x; j0 < N2; j0 += NN_THREADS * FU) {
+      float px[FU], py[FU], pz[FU];
+#pragma unroll
+      for (int u = 0; u < FU; ++u) {
+        const int j = j0 + NN_THREADS * u < N2 ? j0 + NN_THREADS * u : 0;
+        px[u] = kx[j];
+        py[u] = kx[N2 + j];
+        pz[u] = kx[2 * N2 + j];
+      }
+#pragma unroll
+      for (int u = 0; u < FU; ++u) {
+        const bool valid = j0 + NN_THREADS * u < N2;
+        const float d = dist2<FMAD>(px[u], py[u], pz[u], x1, y1, z1);
+        insert(valid ? d : __builtin_inff(), valid ? j0 + NN_THREADS * u : 0x7FFFFFFF, b0, b1, b2,
+               i0, i1, i2);
+      }
+    }
+    float rd[3];
+    int rj[3];
+    merge3(b0, b1, b2, i0, i1, i2, rd, rj);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        sd[wave * 3 + k] = rd[k];
+        sj[wave * 3 + k] = rj[k];
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      b0 = lane < NW * 3 ? sd[lane] : __builtin_inff();
+      i0 = lane < NW * 3 ? sj[lane] : 0x7FFFFFFF;
+      b1 = b2 = __builtin_inff();
+      i1 = i2 = 0x7FFFFFFF;
+      merge3(b0, b1, b2, i0, i1, i2, rd, rj);
+      if (lane == 0)
+        nn_write<WEIGHTS, IdxT>(idx, out, ((size_t)b * N1 + i) * 3, rj[0], rj[1], rj[2], rd[0],
+                                rd[1], rd[2], eps);
+    }
+    __syncthreads();
   }
 }
 
@@ -448,111 +540,92 @@ extern "C" int s4g_three_nn_weights_i32(const float* q_b3n1, const float* k_b3n2
   return s4g::launch_three_nn_scan<false, true, int32_t>(q_b3n1, k_b3n2, B, N1, N2, eps, idx_bn3, w_bn3, st);
 }
 
+// workspace: [keys' grid][fail header (16 ints) + fail list][queries binned into the keys' grid]
+static size_t nn_fail_bytes(int64_t B, int64_t N1) {
+  return (sizeof(int) * ((size_t)B * N1 + 16) + 63) & ~(size_t)63;
+}
+
 extern "C" size_t s4g_three_nn_grid_workspace_bytes(int64_t B, int64_t N1, int64_t N2) {
-  return s4g::grid_ws_bytes(B, N2) + sizeof(int) * ((size_t)B * N1 + 16);
+  return s4g::grid_ws_bytes(B, N2) + nn_fail_bytes(B, N1) + s4g::cell_ws_bytes(B, N1);
 }
 
-extern "C" int s4g_three_nn_weights_grid_i32(const float* q_b3n1, const float* k_b3n2,
-                                             int64_t B, int64_t N1, int64_t N2, float eps,
-                                             float cell, int32_t* idx_bn3, float* w_bn3,
-                                             void* ws, size_t ws_bytes, int flags,
-                                             s4g_stream_t stream) {
-  using namespace s4g;
+namespace s4g {
+
+// build (keys + queries, one launch) -> cell-ordered lane-per-query search -> scan of the
+// queries it could not prove; cell < 0: the edge is chosen on the device first.
+template <bool WEIGHTS, typename IdxT>
+static int launch_three_nn_grid(const float* q, const float* k, int64_t B, int64_t N1, int64_t N2,
+                                float eps, float cell, IdxT* idx, float* out, void* ws,
+                                size_t ws_bytes, int flags, hipStream_t st) {
+  const bool auto_cell = cell < 0.f;
   if (B < 0 || N1 < 0 || N2 < 3 || B > 65535 || N2 > GR_MAX_POINTS || N1 >= (1ll << 31) ||
-      !(cell > 0.f) || !(cell < 1e18f))
+      B * N1 >= (1ll << 31) || (!auto_cell && (!(cell > 0.f) || !(cell < 1e18f))))
     return S4G_EINVAL;
   if (B == 0 || N1 == 0) return S4G_OK;
-  if (!q_b3n1 || !k_b3n2 || !idx_bn3 || !w_bn3 || !ws) return S4G_EINVAL;
+  if (!q || !k || !idx || !out || !ws) return S4G_EINVAL;
   if (ws_bytes < s4g_three_nn_grid_workspace_bytes(B, N1, N2)) return S4G_EWORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
   const GridWs g = grid_ws_carve(ws, B, N2);
   int* fail_count = reinterpret_cast<int*>((char*)ws + grid_ws_bytes(B, N2));
   int* fail_list = fail_count + 16;
-  hipError_t e = hipMemsetAsync(fail_count, 0, sizeof(int), st);
-  if (e != hipSuccess) return (int)e;
-  const float inv_h = 1.0f / cell;
-  if (int rc = launch_grid_build(k_b3n2, B, N2, inv_h, g, st)) return rc;
-  const float edge = cell * (1.0f - 1e-3f);
-  const float d2_done = edge * edge;
-  const dim3 grid((unsigned)((N1 + NN_THREADS - 1) / NN_THREADS), (unsigned)B);
-  const bool fmad = (flags & S4G_FLAG_FMAD) != 0;
-  if (fmad)
-    hipLaunchKernelGGL((three_nn_grid_kernel<true, true, int32_t>), grid, dim3(NN_THREADS), 0, st,
-                       q_b3n1, k_b3n2, (int)N1, (int)N2, inv_h, d2_done, g, eps, idx_bn3, w_bn3,
-                       fail_list, fail_count);
-  else
-    hipLaunchKernelGGL((three_nn_grid_kernel<false, true, int32_t>), grid, dim3(NN_THREADS), 0, st,
-                       q_b3n1, k_b3n2, (int)N1, (int)N2, inv_h, d2_done, g, eps, idx_bn3, w_bn3,
-                       fail_list, fail_count);
-  S4G_LAUNCH_CHECK();
-  if (fmad)
-    hipLaunchKernelGGL((three_nn_fallback_kernel<true, true, int32_t>), dim3(512), dim3(NN_THREADS),
-                       0, st, q_b3n1, k_b3n2, (int)N1, (int)N2, eps, idx_bn3, w_bn3, fail_list,
-                       fail_count);
-  else
-    hipLaunchKernelGGL((three_nn_fallback_kernel<false, true, int32_t>), dim3(512),
-                       dim3(NN_THREADS), 0, st, q_b3n1, k_b3n2, (int)N1, (int)N2, eps, idx_bn3,
-                       w_bn3, fail_list, fail_count);
-  S4G_LAUNCH_CHECK();
-  return S4G_OK;
-}
-
-// Operator-API form of the grid search: int64 indices + squared distances, i.e. the
-// outputs of s4g_three_nn_f32, for callers that can name a cell edge (the host wrapper
-// derives one from the keys' extent).  Identical results for ANY cell: queries whose
-// third neighbour is not proven inside the 27 cells are answered by the index-order
-// scan kernel.
-extern "C" int s4g_three_nn_grid_f32(const float* q_b3n1, const float* k_b3n2, int64_t B,
-                                     int64_t N1, int64_t N2, float cell, int64_t* idx_bn3,
-                                     float* d2_bn3, void* ws, size_t ws_bytes, int flags,
-                                     s4g_stream_t stream) {
-  using namespace s4g;
-  const bool auto_cell = cell < 0.f;   // pick the cell edge on the device
-  if (B < 0 || N1 < 0 || N2 < 3 || B > 65535 || N2 > GR_MAX_POINTS || N1 >= (1ll << 31) ||
-      (!auto_cell && (!(cell > 0.f) || !(cell < 1e18f))))
-    return S4G_EINVAL;
-  if (B == 0 || N1 == 0) return S4G_OK;
-  if (!q_b3n1 || !k_b3n2 || !idx_bn3 || !d2_bn3 || !ws) return S4G_EINVAL;
-  if (ws_bytes < s4g_three_nn_grid_workspace_bytes(B, N1, N2)) return S4G_EWORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
-  const GridWs g = grid_ws_carve(ws, B, N2);
-  int* fail_count = reinterpret_cast<int*>((char*)ws + grid_ws_bytes(B, N2));
-  int* fail_list = fail_count + 16;
+  const CellWs cw = cell_ws_carve((char*)fail_count + nn_fail_bytes(B, N1), B, N1);
   hipError_t e = hipMemsetAsync(fail_count, 0, sizeof(int), st);
   if (e != hipSuccess) return (int)e;
   float* cell_dev = nullptr;   // header words 4, 5 of the fail list
   if (auto_cell) {
     cell_dev = reinterpret_cast<float*>(fail_count + 4);
     static const float factor = [] { const char* e = getenv("S4G_NN_CELL_FACTOR"); return e ? (float)atof(e) : 1.75f; }();
-    hipLaunchKernelGGL(nn_auto_cell_kernel, dim3(1), dim3(1024), 0, st, k_b3n2, (int)B, (int)N2, cell_dev, factor);
+    hipLaunchKernelGGL(nn_auto_cell_kernel, dim3(1), dim3(1024), 0, st, k, (int)B, (int)N2, cell_dev, factor);
     S4G_LAUNCH_CHECK();
     cell = 1.0f;
   }
   const float inv_h = 1.0f / cell;
-  if (int rc = launch_grid_build(k_b3n2, B, N2, inv_h, g, st, false, cell_dev)) return rc;
+  if (int rc = launch_grid_build_queries(k, q, B, N2, N1, inv_h, g, cw, st, false, cell_dev)) return rc;
   const float edge = cell * (1.0f - 1e-3f);
   const float d2_done = edge * edge;
   const dim3 grid((unsigned)((N1 + NN_THREADS - 1) / NN_THREADS), (unsigned)B);
   const bool fmad = (flags & S4G_FLAG_FMAD) != 0;
   if (fmad)
-    hipLaunchKernelGGL((three_nn_grid_kernel<true, false, int64_t>), grid, dim3(NN_THREADS), 0, st,
-                       q_b3n1, k_b3n2, (int)N1, (int)N2, inv_h, d2_done, g, 0.f, idx_bn3, d2_bn3,
-                       fail_list, fail_count, (const float*)cell_dev);
+    hipLaunchKernelGGL((three_nn_grid_kernel<true, WEIGHTS, IdxT>), grid, dim3(NN_THREADS), 0, st,
+                       k, (int)N1, (int)N2, inv_h, d2_done, g, cw, eps, idx, out, fail_list,
+                       fail_count, (const float*)cell_dev);
   else
-    hipLaunchKernelGGL((three_nn_grid_kernel<false, false, int64_t>), grid, dim3(NN_THREADS), 0, st,
-                       q_b3n1, k_b3n2, (int)N1, (int)N2, inv_h, d2_done, g, 0.f, idx_bn3, d2_bn3,
-                       fail_list, fail_count, (const float*)cell_dev);
+    hipLaunchKernelGGL((three_nn_grid_kernel<false, WEIGHTS, IdxT>), grid, dim3(NN_THREADS), 0, st,
+                       k, (int)N1, (int)N2, inv_h, d2_done, g, cw, eps, idx, out, fail_list,
+                       fail_count, (const float*)cell_dev);
   S4G_LAUNCH_CHECK();
   if (fmad)
-    hipLaunchKernelGGL((three_nn_fallback_kernel<true, false, int64_t>), dim3(512), dim3(NN_THREADS),
-                       0, st, q_b3n1, k_b3n2, (int)N1, (int)N2, 0.f, idx_bn3, d2_bn3, fail_list,
-                       fail_count);
+    hipLaunchKernelGGL((three_nn_fallback_kernel<true, WEIGHTS, IdxT>), dim3(512), dim3(NN_THREADS),
+                       0, st, q, k, (int)N1, (int)N2, eps, idx, out, fail_list, fail_count);
   else
-    hipLaunchKernelGGL((three_nn_fallback_kernel<false, false, int64_t>), dim3(512),
-                       dim3(NN_THREADS), 0, st, q_b3n1, k_b3n2, (int)N1, (int)N2, 0.f, idx_bn3,
-                       d2_bn3, fail_list, fail_count);
+    hipLaunchKernelGGL((three_nn_fallback_kernel<false, WEIGHTS, IdxT>), dim3(512), dim3(NN_THREADS),
+                       0, st, q, k, (int)N1, (int)N2, eps, idx, out, fail_list, fail_count);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
+}
+
+}  // namespace s4g
+
+extern "C" int s4g_three_nn_weights_grid_i32(const float* q_b3n1, const float* k_b3n2,
+                                             int64_t B, int64_t N1, int64_t N2, float eps,
+                                             float cell, int32_t* idx_bn3, float* w_bn3,
+                                             void* ws, size_t ws_bytes, int flags,
+                                             s4g_stream_t stream) {
+  if (!(cell > 0.f)) return S4G_EINVAL;   // no device-chosen edge through this entry
+  return s4g::launch_three_nn_grid<true, int32_t>(q_b3n1, k_b3n2, B, N1, N2, eps, cell, idx_bn3,
+                                                  w_bn3, ws, ws_bytes, flags, (hipStream_t)stream);
+}
+
+// Operator-API form of the grid search: int64 indices + squared distances, i.e. the
+// outputs of s4g_three_nn_f32, for callers that can name a cell edge (cell < 0: chosen on
+// the device from the keys' spacing).  Identical results for ANY cell: queries whose
+// third neighbour is not proven inside the 27 cells are answered by the index-order
+// scan kernel.
+extern "C" int s4g_three_nn_grid_f32(const float* q_b3n1, const float* k_b3n2, int64_t B,
+                                     int64_t N1, int64_t N2, float cell, int64_t* idx_bn3,
+                                     float* d2_bn3, void* ws, size_t ws_bytes, int flags,
+                                     s4g_stream_t stream) {
+  return s4g::launch_three_nn_grid<false, int64_t>(q_b3n1, k_b3n2, B, N1, N2, 0.f, cell, idx_bn3,
+                                                   d2_bn3, ws, ws_bytes, flags, (hipStream_t)stream);
 }
 
 extern "C" int s4g_interp_weights_f32(const float* d2_bn3, int64_t B,

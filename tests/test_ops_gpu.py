@@ -310,6 +310,22 @@ def test_three_nn_grid_out_of_range_scene(F, oracle, dev):
     assert np.array_equal(w.cpu().numpy(), oracle.interp_weights(rd2))
 
 
+@pytest.mark.parametrize("cell", [0.01, 0.03])
+def test_three_nn_grid_cell_order_seam_and_ragged(F, oracle, dev, cell):
+    """The grid search walks the queries in CELL order (they are binned into the keys' grid by the
+    build launch): a ragged query count, a scene wider than the 32-cell torus (windows cross the
+    seam, far cells alias) and queries whose own cell is outside the exactness range (1e4 away)
+    -- every query must be answered exactly once, by the cell walk or by the scan."""
+    pts = synth.make_batch([3, 5, 6], 3001)
+    keys = oracle.gather_points(pts, oracle.fps(pts, 2100))
+    pts[0, :, 17] = (1e4, 0.0, 0.0)
+    pts[2, :, 3000] = (-3e3, 2e3, 1e4)
+    idx, w = F.three_nn_weights_grid(_t(pts, dev), _t(keys, dev), cell)
+    ridx, rd2 = oracle.three_nn(pts, keys)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), ridx)
+    assert np.array_equal(w.cpu().numpy(), oracle.interp_weights(rd2))
+
+
 def test_three_nn_ties_and_errors(F, oracle, dev):
     rng = np.random.default_rng(3)
     q, k = _quantized(rng, 2, 300), _quantized(rng, 2, 40)
