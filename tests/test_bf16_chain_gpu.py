@@ -143,22 +143,43 @@ def _models(dev):
 def test_bf16_forward_51200_points_indices_exact_outputs_bf16_close(dev):
     """configs[4] geometry + arithmetic at B = 2: every index tensor of the bf16 path equals the
     fp32-class path's (the geometry kernels are shared) AND the CPU oracle's at the sizes it
-    finishes in seconds (FPS 51 200 -> 5 120 with all M, ball query, 3-NN), and the four head
-    outputs stay within a bf16 tolerance of the f16x2 (fp32-class) forward:
-    max |diff| <= 0.08 * max |reference|, mean |diff| <= 0.01 * max |reference| per head."""
+    finishes in seconds (FPS 51 200 -> 5 120 with all M, ball query, 3-NN).
+
+    Arithmetic, LAUNCH BY LAUNCH against an fp64 reference that rounds activations and weights to
+    bf16 at the same points (tests/bf16_reference.py), each launch fed with the tensors the HIP path
+    itself left at the previous layer boundary, relative to max |reference| of the tensor:
+    single-layer launches max < 5e-6 (fp32 accumulation only); two-layer chain launches (hidden
+    activation re-rounded in LDS) mean < 2e-6, max < 5e-3 (an fp32-vs-fp64 accumulation difference
+    now and then moves ONE bf16 rounding of a hidden activation); the FP tail + four heads launch
+    (seven layers deep) mean < 5e-5, max < 2e-2.  Measured (tools/bf16_probe.py): 6e-7; 3e-7 / 1e-3;
+    5e-6 / 5e-3.  End to end those flips compound to the bf16 noise level, so the whole forward is
+    only bounded against the fp32-class forward: max <= 0.03, mean <= 0.005 of max |reference|
+    (measured 6e-3 / 1.5e-3)."""
     from oracle import oracle as O
     from s4g_release_amd import synth
     lo, hi = _models(dev)
     assert lo._fusable(lo.sa[0]["layers"][-2], lo.sa[0]["layers"][-1], 3, 1)    # the chains ARE used
     pts = torch.from_numpy(synth.make_batch([0, 1], 51200)).to(dev)
+    from tests.bf16_reference import GemmCapture, bf16_stagewise_errors
     with torch.no_grad():
-        pl, il = lo({"scene_points": pts}, return_intermediates=True)
+        with GemmCapture(lo) as cap:
+            pl, il = lo({"scene_points": pts}, return_intermediates=True)
         pl = {k: v.clone() for k, v in pl.items()}
         il = {k: v.clone() for k, v in il.items()}
         ph, ih = hi({"scene_points": pts}, return_intermediates=True)
     for k in il:
         if k.startswith(("fps", "ball", "cnt", "nn")) and not k.startswith("nnw"):
             assert torch.equal(il[k], ih[k]), k
+    for b in (0, 1):
+        stages = bf16_stagewise_errors(lo, pts, il, cap.out, pl, b)
+        assert len(stages) == 15, [n for n, _, _ in stages]     # 11 launches; the last one has 4 outputs
+        for name, emax, emean in stages:
+            if "heads" in name:
+                assert emax < 2e-2 and emean < 5e-5, (b, name, emax, emean)
+            elif "+" in name:
+                assert emax < 5e-3 and emean < 2e-6, (b, name, emax, emean)
+            else:
+                assert emax < 5e-6, (b, name, emax, emean)
     x = pts.cpu().numpy()
     fps0 = O.fps(x, 5120)
     assert np.array_equal(il["fps0"].cpu().numpy().astype(np.int64), fps0)
@@ -173,8 +194,8 @@ def test_bf16_forward_51200_points_indices_exact_outputs_bf16_close(dev):
         d = (pl[k].double() - ref).abs()
         s = ref.abs().max().item()
         assert torch.isfinite(pl[k]).all()
-        assert d.max().item() <= 0.08 * s, (k, d.max().item(), s)
-        assert d.mean().item() <= 0.01 * s, (k, d.mean().item(), s)
+        assert d.max().item() <= 0.03 * s, (k, d.max().item(), s)
+        assert d.mean().item() <= 0.005 * s, (k, d.mean().item(), s)
 
 
 def test_bf16_forward_b32_full_size_is_batch_invariant_and_finite(dev):
