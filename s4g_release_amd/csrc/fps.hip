@@ -861,6 +861,296 @@ __global__ __launch_bounds__(256) void fps_group_box_kernel(const float* __restr
   }
 }
 
+// The whole pre-pass of the pruned kernels as ONE launch, one workgroup per scene: bounding box,
+// a 15-bit cell key per point, a counting sort by cell in LDS, the permutation, the box of every
+// 64-point group of that order and (N > 25 600) the sorted (x, y, z, index) records.  (Round 2
+// used five kernels around rocprim::radix_sort_pairs: 22 launches per batch on the geometry
+// stream.)
+//
+// The key: the pruned kernels are exact for ANY permutation, the order only decides how tight the
+// groups' boxes are (touched groups per pick, simulated on the bench scenes over all 5 119 picks;
+// round 2's 10-bit-per-axis Morton key on box-normalised coordinates: 8.7 at 25 600 points).
+//  * thin clouds (smallest extent < half the largest: depth-camera scenes are surfaces over a
+//    table): a 2-D Hilbert curve over the two long axes, 64 x 64 square cells, the short axis as 3
+//    minor bits -- 5.3 touched groups per pick.  Hilbert, not Morton: no long jumps inside a group.
+//  * otherwise: 15 Morton bits dealt to the axes by extent -- the next bit always halves the axis
+//    whose cells are currently longest -- so cells come out near-cubic (7.0 on the table-top
+//    scene, where it would deal 6 + 6 + 3; 15.5 against 16.0 on a uniform box).
+// The order INSIDE a cell is whatever order the LDS atomics were served in -- as in the ball
+// query's grid build -- so the permutation is not reproducible run to run; the FPS output is.
+//
+// 2^15 counters as 16-bit halves of 2^14 words (cell c lives in half c >> 14 of word c & 16383;
+// a half never exceeds N <= 65 535): one packed prefix sum over the words yields both halves'
+// starts, the upper halves shifted by the lower halves' total.
+constexpr int FPS_SORT_THREADS = 1024;
+constexpr int FPS_SORT_WORDS = 1 << 14;
+constexpr int FPS_SORT_BITS = 15;
+constexpr int FPS_SORT_AXIS_BITS = 8;   // at most 8 bits per axis (256-entry deposit tables)
+
+__global__ __launch_bounds__(FPS_SORT_THREADS) void fps_cell_sort_kernel(
+    const float* __restrict__ xyz, int N, int G, int* __restrict__ perm, float* __restrict__ gbox,
+    float4* __restrict__ aos, int aos_cap) {
+  extern __shared__ uint32_t sort_lds[];
+  constexpr int NW = FPS_SORT_THREADS / 64;
+  uint32_t* __restrict__ H = sort_lds;                  // [2^14] packed counters
+  uint32_t* __restrict__ dep = H + FPS_SORT_WORDS;      // [3][256] an axis value's bits at their key positions
+  uint16_t* __restrict__ hil = reinterpret_cast<uint16_t*>(dep + 3 * 256);   // [64 * 64] Hilbert index of an (a, b) cell
+  uint32_t* __restrict__ red = dep + 3 * 256 + 64 * 64 / 2;   // [6][NW] + [NW]
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* __restrict__ p = xyz + (size_t)b * 3 * N;
+  int* __restrict__ pm = perm + (size_t)b * N;
+
+  // the three point loops keep U x 3 plane loads in flight (the workgroup is latency-bound)
+  constexpr int U = 6;
+  auto for_points = [&](auto&& body) {
+    for (int j0 = t; j0 < N; j0 += FPS_SORT_THREADS * U) {
+      float c[U][3];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = j0 + u * FPS_SORT_THREADS;
+        const int jj = j < N ? j : 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) c[u][a] = p[(size_t)a * N + jj];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (j0 + u * FPS_SORT_THREADS < N) body(j0 + u * FPS_SORT_THREADS, c[u]);
+    }
+  };
+
+  for (int i = t; i < FPS_SORT_WORDS; i += FPS_SORT_THREADS) H[i] = 0;
+  uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+  for_points([&](int, const float (&c)[3]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const uint32_t v = f32_ordered(c[a]);
+      lo[a] = min(lo[a], v);
+      hi[a] = max(hi[a], v);
+    }
+  });
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const uint32_t l = wave_min_u32(lo[a]), h = wave_max_u32(hi[a]);
+    if (lane == 0) {
+      red[a * NW + wave] = l;
+      red[(3 + a) * NW + wave] = h;
+    }
+  }
+  __syncthreads();
+  float bl[3], ext[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    uint32_t l = red[a * NW], h = red[(3 + a) * NW];
+    for (int w = 1; w < NW; ++w) {
+      l = min(l, red[a * NW + w]);
+      h = max(h, red[(3 + a) * NW + w]);
+    }
+    bl[a] = ordered_f32(l);
+    ext[a] = ordered_f32(h) - bl[a];
+    if (!(ext[a] > 0.f) || !(ext[a] < 3.0e38f)) ext[a] = 0.f;   // degenerate / non-finite axis: never split
+  }
+  // deal the bits (every thread computes the same sequence): seq = 2 bits per level, MSB level first
+  int nb[3] = {0, 0, 0};
+  uint32_t seq = 0;
+  {
+    float edge[3] = {ext[0], ext[1], ext[2]};
+#pragma unroll
+    for (int i = 0; i < FPS_SORT_BITS; ++i) {
+      int a = 0;
+      float best = -1.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float e = nb[k] < FPS_SORT_AXIS_BITS ? edge[k] : -1.f;
+        if (e > best) {
+          best = e;
+          a = k;
+        }
+      }
+      seq |= (uint32_t)a << (2 * i);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (k == a) {
+          ++nb[k];
+          edge[k] *= 0.5f;
+        }
+    }
+  }
+  // axes by extent: ax_a the longest, ax_c the shortest
+  const int ax_a = ext[0] >= ext[1] ? (ext[0] >= ext[2] ? 0 : 2) : (ext[1] >= ext[2] ? 1 : 2);
+  const int ax_c = ext[0] < ext[1] ? (ext[0] < ext[2] ? 0 : 2) : (ext[1] < ext[2] ? 1 : 2);
+  const int ax_b = ax_a == ax_c ? (ax_a + 1) % 3 : 3 - ax_a - ax_c;   // (all extents equal: a == c == 0)
+  const int ax_c2 = ax_a == ax_c ? (ax_a + 2) % 3 : ax_c;
+  auto pick = [](const float (&v)[3], int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); };
+  const bool thin = pick(ext, ax_c2) < 0.5f * pick(ext, ax_a);
+  float inv[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) inv[a] = ext[a] > 0.f ? (float)(1 << nb[a]) / ext[a] : 0.f;   // ordering only: any rounding will do
+  const float inv_ab = pick(ext, ax_a) > 0.f ? 64.0f / pick(ext, ax_a) : 0.f;   // square cells over the two long axes
+  const float inv_c = pick(ext, ax_c2) > 0.f ? 8.0f / pick(ext, ax_c2) : 0.f;
+  if (thin) {   // Hilbert index of every (x, y) cell of the 64 x 64 grid, four cells per thread
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cell = 4 * t + k;
+      int x = cell & 63, y = cell >> 6, d = 0;
+#pragma unroll
+      for (int sz = 32; sz > 0; sz >>= 1) {
+        const int rx = (x & sz) ? 1 : 0, ry = (y & sz) ? 1 : 0;
+        d += sz * sz * ((3 * rx) ^ ry);
+        if (ry == 0) {
+          if (rx == 1) {
+            x = 63 - x;
+            y = 63 - y;
+          }
+          const int tmp = x;
+          x = y;
+          y = tmp;
+        }
+      }
+      hil[cell] = (uint16_t)d;
+    }
+  } else if (t < 3 * 256) {   // deposit table: value v of axis a -> its bits at the levels dealt to a
+    const int a = t >> 8, v = t & 255;
+    const int na = a == 0 ? nb[0] : (a == 1 ? nb[1] : nb[2]);
+    uint32_t key = 0;
+    int used = 0;
+#pragma unroll
+    for (int i = 0; i < FPS_SORT_BITS; ++i)
+      if ((int)((seq >> (2 * i)) & 3u) == a) {
+        ++used;
+        key |= (uint32_t)((v >> (na - used)) & 1) << (FPS_SORT_BITS - 1 - i);
+      }
+    dep[t] = key;
+  }
+  __syncthreads();
+  auto quant = [](float sc, float top) -> uint32_t { return (uint32_t)(sc > 0.f ? (sc < top ? sc : top) : 0.f); };   // NaN -> 0
+  auto cell_of = [&](const float (&c)[3]) -> uint32_t {
+    if (thin) {
+      const uint32_t qa = quant((pick(c, ax_a) - pick(bl, ax_a)) * inv_ab, 63.f);
+      const uint32_t qb = quant((pick(c, ax_b) - pick(bl, ax_b)) * inv_ab, 63.f);
+      const uint32_t qc = quant((pick(c, ax_c2) - pick(bl, ax_c2)) * inv_c, 7.f);
+      return ((uint32_t)hil[qa | (qb << 6)] << 3) | qc;
+    }
+    uint32_t key = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) key |= dep[a * 256 + quant((c[a] - bl[a]) * inv[a], (float)((1 << nb[a]) - 1))];
+    return key;
+  };
+  for_points([&](int, const float (&c)[3]) {
+    const uint32_t cl = cell_of(c);
+    atomicAdd(&H[cl & (FPS_SORT_WORDS - 1)], 1u << (16 * (cl >> 14)));
+  });
+  __syncthreads();
+  {  // exclusive prefix over the packed words, 16 consecutive words per thread
+    static_assert(FPS_SORT_WORDS == 16 * FPS_SORT_THREADS, "scan layout");
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const uint4*>(&H[16 * t + 4 * k]);
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t c;
+      c = v[k].x; v[k].x = run; run += c;
+      c = v[k].y; v[k].y = run; run += c;
+      c = v[k].z; v[k].z = run; run += c;
+      c = v[k].w; v[k].w = run; run += c;
+    }
+    uint32_t incl = run;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) red[6 * NW + wave] = incl;
+    __syncthreads();
+    uint32_t base = incl - run, total = 0;
+    for (int w = 0; w < NW; ++w) {
+      const uint32_t wt = red[6 * NW + w];
+      if (w < wave) base += wt;
+      total += wt;
+    }
+    base += (total & 0xFFFFu) << 16;                     // the upper halves start behind all lower ones
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k].x += base; v[k].y += base; v[k].z += base; v[k].w += base;
+      *reinterpret_cast<uint4*>(&H[16 * t + 4 * k]) = v[k];
+    }
+  }
+  __syncthreads();
+  for_points([&](int j, const float (&c)[3]) {
+    const uint32_t cl = cell_of(c);
+    const uint32_t sh = 16 * (cl >> 14);
+    const uint32_t old = atomicAdd(&H[cl & (FPS_SORT_WORDS - 1)], 1u << sh);
+    pm[(old >> sh) & 0xFFFFu] = j;
+  });
+  __threadfence();                                       // the permutation is read back below
+  __syncthreads();
+
+  // boxes: 16 lanes per 64-point group, four points per lane, two groups per lane in flight
+  const int l16 = t & 15;
+  constexpr int GS = FPS_SORT_THREADS / 16;              // groups per sweep
+  for (int g0 = t >> 4; g0 < G; g0 += 2 * GS) {
+    int j[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int sp = 64 * (g0 + h * GS) + l16 + 16 * k;
+        j[h][k] = sp < N ? __hip_atomic_load(&pm[sp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+      }
+    float c[2][4][3];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) c[h][k][a] = p[(size_t)a * N + (j[h][k] < 0 ? 0 : j[h][k])];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int g = g0 + h * GS;
+      uint32_t bmin[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, bmax[3] = {0u, 0u, 0u};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const uint32_t v = f32_ordered(c[h][k][a]);
+          bmin[a] = min(bmin[a], j[h][k] < 0 ? 0xFFFFFFFFu : v);
+          bmax[a] = max(bmax[a], j[h][k] < 0 ? 0u : v);
+        }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const uint32_t l = row16_min_u32(bmin[a]), hh = row16_max_u32(bmax[a]);
+        if (l16 == 0 && g < G) {
+          float* __restrict__ o = gbox + ((size_t)b * G + g) * 6;
+          o[a] = ordered_f32(l);
+          o[3 + a] = ordered_f32(hh);
+        }
+      }
+    }
+  }
+  if (aos) {   // cell-ordered records of fps_pruned_l2_kernel
+    float4* __restrict__ out = aos + (size_t)b * aos_cap;
+    constexpr int AU = 5;
+    for (int sp0 = t; sp0 < aos_cap; sp0 += FPS_SORT_THREADS * AU) {
+      int j[AU];
+#pragma unroll
+      for (int u = 0; u < AU; ++u) {
+        const int sp = sp0 + u * FPS_SORT_THREADS;
+        j[u] = sp < N ? __hip_atomic_load(&pm[sp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      }
+      float c[AU][3];
+#pragma unroll
+      for (int u = 0; u < AU; ++u)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) c[u][a] = p[(size_t)a * N + j[u]];
+#pragma unroll
+      for (int u = 0; u < AU; ++u) {
+        const int sp = sp0 + u * FPS_SORT_THREADS;
+        if (sp < aos_cap) out[sp] = make_float4(c[u][0], c[u][1], c[u][2], __int_as_float(j[u]));
+      }
+    }
+  }
+}
+
 // md[pw] of every lane for a wave-uniform slot pw (static register index per leaf)
 template <int PPT, int LO, int HI>
 __device__ __forceinline__ float fps_pick_md(const float (&md)[PPT], int pw) {
@@ -1464,6 +1754,17 @@ static bool fps_use_cluster(int64_t B) {
 }
 static size_t fps_cluster_ws_bytes(int64_t B) { return (size_t)B * 4 * sizeof(FpsXch) + 64; }
 
+static int launch_fps_cell_sort(const float* xyz, int64_t B, int64_t N, int G, int* perm, float* gbox,
+                                float4* aos, int aos_cap, hipStream_t stream) {
+  constexpr size_t lds = sizeof(uint32_t) * (FPS_SORT_WORDS + 3 * 256 + 64 * 64 / 2 + 7 * (FPS_SORT_THREADS / 64));
+  static LdsAttrCache lds_cache;
+  if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(&fps_cell_sort_kernel), lds, lds_cache)) return rc;
+  hipLaunchKernelGGL(fps_cell_sort_kernel, dim3((unsigned)B), dim3(FPS_SORT_THREADS), lds, stream, xyz, (int)N, G,
+                     perm, gbox, aos, aos_cap);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
+
 template <bool FMAD, typename IdxT>
 static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
                       IdxT* idx, float* ctr, void* ws, size_t ws_bytes,
@@ -1486,18 +1787,26 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
   int dense_steps = FPS_DENSE_STEPS;
   if (const char* e = getenv("S4G_FPS_DENSE_STEPS")) dense_steps = atoi(e) > 1 ? atoi(e) : 2;
   if (dense_steps >= M) pruned = false;
+  // S4G_FPS_SORT=rocprim: round 2's pre-pass (bbox, 30-bit Morton keys, rocprim::radix_sort_pairs over
+  // the batch, group boxes: 22 launches) instead of the one-launch cell sort
+  static const bool one_launch_sort = [] { const char* e = getenv("S4G_FPS_SORT"); return !(e && e[0] == 'r'); }();
   if (pruned) {
-    hipLaunchKernelGGL(fps_bbox_kernel, dim3((unsigned)B), dim3(1024), 0, stream, xyz, (int)N, w.bbox);
-    S4G_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fps_morton_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256),
-                       0, stream, xyz, (int)N, (int)B, w.bbox, w.key_in, w.val_in);
-    S4G_LAUNCH_CHECK();
-    int bits = 30;
-    while ((1ll << (bits - 30)) < B) ++bits;
-    size_t tb = w.tmp_bytes;
-    const hipError_t e = rocprim::radix_sort_pairs(w.tmp, tb, w.key_in, w.key_out, w.val_in,
-                                                   w.val_out, (size_t)B * (size_t)N, 0, bits, stream);
-    if (e != hipSuccess) return (int)e;
+    if (one_launch_sort) {
+      const int G = 8 * (N <= 512 * 10 ? 10 : N <= 512 * 20 ? 20 : N <= 512 * 32 ? 32 : 50);   // groups of the pruned launch below
+      if (int rc = launch_fps_cell_sort(xyz, B, N, G, w.val_out, w.gbox, nullptr, 0, stream)) return rc;
+    } else {
+      hipLaunchKernelGGL(fps_bbox_kernel, dim3((unsigned)B), dim3(1024), 0, stream, xyz, (int)N, w.bbox);
+      S4G_LAUNCH_CHECK();
+      hipLaunchKernelGGL(fps_morton_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256),
+                         0, stream, xyz, (int)N, (int)B, w.bbox, w.key_in, w.val_in);
+      S4G_LAUNCH_CHECK();
+      int bits = 30;
+      while ((1ll << (bits - 30)) < B) ++bits;
+      size_t tb = w.tmp_bytes;
+      const hipError_t e = rocprim::radix_sort_pairs(w.tmp, tb, w.key_in, w.key_out, w.val_in,
+                                                     w.val_out, (size_t)B * (size_t)N, 0, bits, stream);
+      if (e != hipSuccess) return (int)e;
+    }
     m_run = dense_steps;
     md_out = w.md;
   }
@@ -1538,9 +1847,11 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
   if (N <= (int64_t)T * P) {                                                                       \
     const size_t lds = sizeof(uint16_t) * T * P;                                                   \
     constexpr int G = (T / 64) * P;                                                                \
-    hipLaunchKernelGGL(fps_group_box_kernel, dim3((G + 3) / 4, (unsigned)B), dim3(256), 0, stream, \
-                       xyz, w.val_out, (int)N, G, w.gbox);                                         \
-    S4G_LAUNCH_CHECK();                                                                            \
+    if (!one_launch_sort) {                                                                        \
+      hipLaunchKernelGGL(fps_group_box_kernel, dim3((G + 3) / 4, (unsigned)B), dim3(256), 0, stream, \
+                         xyz, w.val_out, (int)N, G, w.gbox);                                       \
+      S4G_LAUNCH_CHECK();                                                                          \
+    }                                                                                              \
     if (spec == 4) S4G_FPS_PRUNED_LAUNCH(T, P, 4) else if (spec == 2) S4G_FPS_PRUNED_LAUNCH(T, P, 2) else S4G_FPS_PRUNED_LAUNCH(T, P, 1) \
     S4G_LAUNCH_CHECK();                                                                            \
     return S4G_OK;                                                                                 \
@@ -1556,24 +1867,28 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
   if (fps_use_pruned_l2(N, M) && B < (1 << 16)) {
     const FpsSortWs w2 = fps_sort_ws(ws, B, N);
     if (ws && ws_bytes >= w2.total) {
-      hipLaunchKernelGGL(fps_bbox_kernel, dim3((unsigned)B), dim3(1024), 0, stream, xyz, (int)N, w2.bbox);
-      S4G_LAUNCH_CHECK();
-      hipLaunchKernelGGL(fps_morton_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0,
-                         stream, xyz, (int)N, (int)B, w2.bbox, w2.key_in, w2.val_in);
-      S4G_LAUNCH_CHECK();
-      int bits = 30;
-      while ((1ll << (bits - 30)) < B) ++bits;
-      size_t tb = w2.tmp_bytes;
-      const hipError_t e = rocprim::radix_sort_pairs(w2.tmp, tb, w2.key_in, w2.key_out, w2.val_in,
-                                                     w2.val_out, (size_t)B * (size_t)N, 0, bits, stream);
-      if (e != hipSuccess) return (int)e;
       constexpr int G = 8 * 100;
-      hipLaunchKernelGGL(fps_group_box_kernel, dim3((G + 3) / 4, (unsigned)B), dim3(256), 0, stream, xyz,
-                         w2.val_out, (int)N, G, w2.gbox);
-      S4G_LAUNCH_CHECK();
-      hipLaunchKernelGGL(fps_sorted_aos_kernel, dim3((FPS_L2_CAP + 255) / 256, (unsigned)B), dim3(256), 0,
-                         stream, xyz, w2.val_out, (int)N, FPS_L2_CAP, w2.aos);
-      S4G_LAUNCH_CHECK();
+      if (one_launch_sort) {
+        if (int rc = launch_fps_cell_sort(xyz, B, N, G, w2.val_out, w2.gbox, w2.aos, FPS_L2_CAP, stream)) return rc;
+      } else {
+        hipLaunchKernelGGL(fps_bbox_kernel, dim3((unsigned)B), dim3(1024), 0, stream, xyz, (int)N, w2.bbox);
+        S4G_LAUNCH_CHECK();
+        hipLaunchKernelGGL(fps_morton_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0,
+                           stream, xyz, (int)N, (int)B, w2.bbox, w2.key_in, w2.val_in);
+        S4G_LAUNCH_CHECK();
+        int bits = 30;
+        while ((1ll << (bits - 30)) < B) ++bits;
+        size_t tb = w2.tmp_bytes;
+        const hipError_t e = rocprim::radix_sort_pairs(w2.tmp, tb, w2.key_in, w2.key_out, w2.val_in,
+                                                       w2.val_out, (size_t)B * (size_t)N, 0, bits, stream);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(fps_group_box_kernel, dim3((G + 3) / 4, (unsigned)B), dim3(256), 0, stream, xyz,
+                           w2.val_out, (int)N, G, w2.gbox);
+        S4G_LAUNCH_CHECK();
+        hipLaunchKernelGGL(fps_sorted_aos_kernel, dim3((FPS_L2_CAP + 255) / 256, (unsigned)B), dim3(256), 0,
+                           stream, xyz, w2.val_out, (int)N, FPS_L2_CAP, w2.aos);
+        S4G_LAUNCH_CHECK();
+      }
       hipLaunchKernelGGL((fps_pruned_l2_kernel<512, 100, FMAD, IdxT, 2>), grid, dim3(512), 0, stream, xyz,
                          w2.aos, w2.gbox, (int)N, (int)M, idx, ctr, lg);
       S4G_LAUNCH_CHECK();
