@@ -429,6 +429,17 @@ int s4g_fps_gather_i32(const float *xyz_b3n, int64_t B, int64_t N, int64_t M,
                        int32_t *idx_bm, float *ctr_b3m, void *ws, size_t ws_bytes,
                        int flags, s4g_stream_t stream);
 
+/* Diagnostic entry (tests): the pruned FPS kernels' pre-pass on its own -- ONE launch, one
+ * workgroup per scene: bounding box, a 15-bit cell key per point (2-D Hilbert curve over the two
+ * long axes for thin clouds, extent-dealt Morton bits otherwise), LDS counting sort.  Outputs
+ * perm (B,N): a permutation of 0..N-1 per scene (cell order; the order INSIDE a cell is not
+ * reproducible), and gbox (B,G,6): (min x,y,z, max x,y,z) of every run of 64 consecutive perm
+ * entries; G >= ceil(N / 64) groups are written (groups past the end hold NaN).  N <= 65 535.
+ * The FPS result never depends on the permutation (sampling_kernel.cu:49-119 has no such step);
+ * it only decides how many groups a pick has to revisit. */
+int s4g_fps_prepass_f32(const float *xyz_b3n, int64_t B, int64_t N, int64_t G, int32_t *perm_bn,
+                        float *gbox_bg6, s4g_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Next row: pose decode right after the network.
  * s4g_expected_score_f32: softmax over the C score classes of (B,C,N) logits,

@@ -80,6 +80,7 @@ SIGNATURES = {
     "s4g_group_points_ws_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "s4g_three_interpolate_ws_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _int, _vp]),
     "s4g_fps_gather_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _int, _vp]),
+    "s4g_fps_prepass_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "s4g_group_rel_xyz_i32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "s4g_expected_score_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "s4g_decode_poses_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),

@@ -1945,6 +1945,14 @@ extern "C" int s4g_debug_fps_stamps(unsigned long long* host_out_64x8x8, int res
 }
 #endif
 
+extern "C" int s4g_fps_prepass_f32(const float* xyz_b3n, int64_t B, int64_t N, int64_t G,
+                                   int32_t* perm_bn, float* gbox_bg6, s4g_stream_t stream) {
+  if (B < 0 || N <= 0 || N > 65535 || B > 65535 || G < (N + 63) / 64 || G > (1 << 20)) return S4G_EINVAL;
+  if (B == 0) return S4G_OK;
+  if (!xyz_b3n || !perm_bn || !gbox_bg6) return S4G_EINVAL;
+  return s4g::launch_fps_cell_sort(xyz_b3n, B, N, (int)G, perm_bn, gbox_bg6, nullptr, 0, (hipStream_t)stream);
+}
+
 extern "C" int s4g_fps_f32(const float* xyz_b3n, int64_t B, int64_t N,
                            int64_t M, int64_t* idx_bm, void* ws,
                            size_t ws_bytes, int flags, s4g_stream_t stream) {

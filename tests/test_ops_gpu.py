@@ -251,6 +251,72 @@ def test_group_points_backward(F, oracle, dev):
 
 
 # ------------------------------------------------------------------ 3-NN + interpolate
+def _fps_prepass(pts, dev):
+    """s4g_fps_prepass_f32 -> (perm (B,N) int64, boxes (B,G,6) fp32) as numpy."""
+    from s4g_release_amd import _cabi
+    B, _, N = pts.shape
+    G = (N + 63) // 64
+    x = _t(pts, dev)
+    perm = torch.full((B, N), -1, dtype=torch.int32, device=dev)
+    box = torch.zeros((B, G, 6), dtype=torch.float32, device=dev)
+    rc = _cabi.lib().s4g_fps_prepass_f32(x.data_ptr(), B, N, G, perm.data_ptr(), box.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream)
+    _cabi.check(rc, "fps_prepass")
+    torch.cuda.synchronize()
+    return perm.cpu().numpy().astype(np.int64), box.cpu().numpy()
+
+
+def _group_boxes(pts_b, perm_b):
+    N = perm_b.shape[0]
+    G = (N + 63) // 64
+    q = pts_b[:, perm_b]                                   # (3, N) in the pre-pass's order
+    out = np.full((G, 6), np.nan, np.float32)
+    for g in range(G):
+        seg = q[:, 64 * g:64 * g + 64]
+        out[g, :3] = seg.min(axis=1)
+        out[g, 3:] = seg.max(axis=1)
+    return out
+
+
+@pytest.mark.parametrize("variant,N", [("tabletop-v1", 25600), ("tabletop-v1", 12001), ("uniform-box", 25600),
+                                       ("dup-heavy", 20000), ("tabletop-v1", 51200)])
+def test_fps_prepass_is_a_permutation_with_exact_tight_boxes(dev, variant, N):
+    """The one-launch pre-pass of the pruned FPS kernels (bounding box, cell keys, LDS counting
+    sort, group boxes): per scene the output must be a PERMUTATION of 0..N-1 (every later step
+    relies on that and on nothing else), every box the exact fp32 min / max of its 64 points, and
+    the order spatial: the mean box diagonal at most a fifth of index-order groups (two fifths on a volume-filling cloud).."""
+    pts = synth.make_batch([0, 3, 11], N, variant=variant)
+    perm, box = _fps_prepass(pts, dev)
+    for b in range(pts.shape[0]):
+        assert np.array_equal(np.sort(perm[b]), np.arange(N)), b
+        want = _group_boxes(pts[b], perm[b])
+        assert np.array_equal(box[b], want, equal_nan=True), b
+        diag = np.linalg.norm(want[:N // 64, 3:] - want[:N // 64, :3], axis=1).mean()
+        base = _group_boxes(pts[b], np.arange(N))
+        diag0 = np.linalg.norm(base[:N // 64, 3:] - base[:N // 64, :3], axis=1).mean()
+        assert diag < (0.2 if variant != "uniform-box" else 0.4) * diag0, (b, diag, diag0)
+
+
+def test_fps_prepass_degenerate_clouds(dev):
+    """All points equal; a cloud on a line (two zero extents); a plane; non-finite coordinates:
+    still a permutation with exact boxes (the keys only order, they never drop a point)."""
+    rng = np.random.default_rng(5)
+    N = 3000
+    pts = np.zeros((4, 3, N), np.float32)
+    pts[0] = 0.25
+    pts[1, 0] = rng.random(N, dtype=np.float32)
+    pts[2, :2] = rng.random((2, N), dtype=np.float32)
+    pts[3] = rng.random((3, N), dtype=np.float32)
+    pts[3, 1, 7] = np.inf
+    pts[3, 2, 9] = -np.inf
+    perm, box = _fps_prepass(pts, dev)
+    for b in range(4):
+        assert np.array_equal(np.sort(perm[b]), np.arange(N)), b
+        assert np.array_equal(box[b], _group_boxes(pts[b], perm[b]), equal_nan=True), b
+    with pytest.raises(RuntimeError):
+        _fps_prepass(np.zeros((1, 3, 70000), np.float32), dev)     # > 65 535 points
+
+
 @pytest.mark.parametrize("N1,N2", [(1024, 256), (5120, 1024), (25600, 5120), (70, 3)])
 def test_three_nn_matches_oracle(F, oracle, dev, N1, N2):
     pts = synth.make_batch([0, 7], max(N1, 64))[:, :, :N1]
