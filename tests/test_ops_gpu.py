@@ -284,7 +284,8 @@ def test_fps_prepass_is_a_permutation_with_exact_tight_boxes(dev, variant, N):
     """The one-launch pre-pass of the pruned FPS kernels (bounding box, cell keys, LDS counting
     sort, group boxes): per scene the output must be a PERMUTATION of 0..N-1 (every later step
     relies on that and on nothing else), every box the exact fp32 min / max of its 64 points, and
-    the order spatial: the mean box diagonal at most a fifth of index-order groups (two fifths on a volume-filling cloud).."""
+    the order spatial: the mean box diagonal at most a fifth of index-order groups' (two fifths on a
+    volume-filling cloud)."""
     pts = synth.make_batch([0, 3, 11], N, variant=variant)
     perm, box = _fps_prepass(pts, dev)
     for b in range(pts.shape[0]):
