@@ -51,16 +51,24 @@ struct FpsSlot {
 
 #ifdef S4G_FPS_STAMPS
 // debug build only (make HIPFLAGS_EXTRA=-DS4G_FPS_STAMPS into its own OBJDIR / LIB): per (scene, wave)
-// cycle accumulators of fps_pruned_kernel's phases, read back by tools/fps_stamps.py
+// cycle accumulators of fps_pruned_kernel's phases, read back by tools/fps_stamps.py.  The sums are
+// kept in (wave-uniform) registers and written ONCE at the end of the kernel: a read-modify-write
+// of global memory at every phase boundary would stall the wave for a memory round trip each
+// time and end up in the numbers.
 __device__ unsigned long long g_fps_acc[64 * 8 * 8];
 #define S4G_FPS_T() __builtin_amdgcn_s_memtime()
-#define S4G_FPS_ACC(i, v)                                                                   \
-  do {                                                                                      \
-    if (lane == 0 && b < 64) g_fps_acc[(b * 8 + wave) * 8 + (i)] += (unsigned long long)(v); \
+#define S4G_FPS_ACC_DECL() unsigned long long fps_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define S4G_FPS_ACC(i, v) fps_acc_[(i)] += (unsigned long long)(v)
+#define S4G_FPS_ACC_FLUSH()                                                              \
+  do {                                                                                   \
+    if (lane == 0 && b < 64)                                                             \
+      for (int a_ = 0; a_ < 8; ++a_) g_fps_acc[(b * 8 + wave) * 8 + a_] += fps_acc_[a_]; \
   } while (0)
 #else
 #define S4G_FPS_T() 0ull
+#define S4G_FPS_ACC_DECL()
 #define S4G_FPS_ACC(i, v)
+#define S4G_FPS_ACC_FLUSH()
 #endif
 
 // Block-wide argmax exchange.  Input: this wave's (wmax, wtie) and the
@@ -1307,6 +1315,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
     }
     __syncthreads();
   }
+  S4G_FPS_ACC_DECL();
   for (int i = i0; i < M;) {
     uint32_t wmax, wtie, wd2 = 0u;
     float sx = cx, sy = cy, sz = cz;
@@ -1455,6 +1464,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
     S4G_FPS_ACC(3, 1);
     S4G_FPS_ACC(4, npend);
   }
+  S4G_FPS_ACC_FLUSH();
 }
 
 
