@@ -390,9 +390,12 @@ int s4g_three_nn_weights_i32(const float *q_b3n1, const float *k_b3n2, int64_t B
                              s4g_stream_t stream);
 /* Grid-accelerated variant of s4g_three_nn_weights_i32 for the fast path: keys are
  * binned into cells of edge `cell` (use the set-abstraction radius of the level
- * the keys came from), queries search 27 cells, unanswered queries fall back to
- * the index-order scan in the same call -- identical results for every input.
- * Workspace: s4g_three_nn_grid_workspace_bytes(B, N1, N2); N2 <= 65536. */
+ * the keys came from), the queries are binned into the same cells by the same launch
+ * and walked in cell order (a wave's 64 queries share their key rows), each searches
+ * 27 cells, unanswered queries fall back to the index-order scan in the same call --
+ * identical results for every input.
+ * Workspace: s4g_three_nn_grid_workspace_bytes(B, N1, N2) (keys' grid + fail list +
+ * the binned queries: ~128 bytes per query + 0.6 MB per scene); N2 <= 65536. */
 size_t s4g_three_nn_grid_workspace_bytes(int64_t B, int64_t N1, int64_t N2);
 int s4g_three_nn_weights_grid_i32(const float *q_b3n1, const float *k_b3n2, int64_t B,
                                   int64_t N1, int64_t N2, float eps, float cell,
