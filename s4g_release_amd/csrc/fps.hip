@@ -754,8 +754,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_stream_kernel(
 // Pruned variant (N > 5 120): same per-step exchange, but a step only rescans the
 // 64-point groups the new centroid can still change.
 //
-// The scene is put in Morton order first (fps_bbox / fps_morton kernels + one
-// radix sort); group g = sorted positions [64 g, 64 g + 64) is slot g / 8 of wave
+// The scene is put in a spatial order first (fps_cell_sort_kernel: one launch; round 2:
+// bbox / Morton-key kernels + rocPRIM's radix sort); group g = sorted positions [64 g, 64 g + 64) is slot g / 8 of wave
 // g % 8, so a group is a compact patch and neighbouring patches sit in different
 // waves.  Lane l of a wave keeps, for "its" group (slot l), the bounding box and
 // the exact maximum Mg of the group's running min-distances.  A new centroid c
@@ -765,13 +765,15 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_stream_kernel(
 // bound of the ROUNDED distance of every point in the box.  Skipped groups keep
 // their min-distances and Mg bit for bit, so the selected index sequence is the
 // one of the full scan (tests compare against the oracle).  On the bench scenes a
-// centroid touches 9 of 400 groups on average (64 in the first 48 steps); the
-// first FPS_DENSE_STEPS steps are run by the full-scan kernel, which hands its
-// min-distances over through the workspace.  Updates are dispatched by straight-line
+// centroid touches 5.3 of 400 groups on average (8.7 in round 2's Morton order).  The
+// kernel starts by itself from +inf min-distances (md_in == NULL; round 3 -- measured
+// equal alone, and one launch of a whole-CU workgroup fewer inside a pipelined step);
+// S4G_FPS_DENSE_STEPS = n > 1 has the full-scan kernel run the first n steps and hand its
+// min-distances over through the workspace, as rounds 1-2 did.  Updates are dispatched by straight-line
 // guarded blocks (one rarely-taken scalar branch per 8 slots, one per slot) with static
 // register indices; a group's maximum is only re-reduced when a point that held it came
 // closer; the winner's slot is fetched by one walk of a 6-level scalar branch tree.
-// 25 600 -> 5 120: 6.7 ms against 10.9 ms for the full scan (S4G_FPS_MODE=dense).
+// 25 600 -> 5 120: 4.8 ms against 10.9 ms for the full scan (S4G_FPS_MODE=dense).
 // The winner is resolved lazily: wave max over the Mg lanes, then the lane(s) of
 // that group that hold it (static register index through a scalar branch tree),
 // original index and tie key from an LDS table.
@@ -1268,14 +1270,24 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
     z[p] = pz[j];
     // min-distances after the first i0 steps (full-scan kernel); padding lanes sit at 0:
     // never a maximum unless every real point is at 0 too
-    md[p] = ok ? md_in[(size_t)b * N + j] : 0.0f;
+    md[p] = ok ? (md_in ? md_in[(size_t)b * N + j] : __builtin_inff()) : 0.0f;
     orig[s] = (uint16_t)j;
   }
   const uint32_t rkey = (__brev((uint32_t)t & bs_mask) >> (32 - lg_bs)) << 23;   // all-zero case only
   __syncthreads();
 
-  int cur = (int)out[i0 - 1];
+  // md_in == NULL: no full-scan kernel ran before (i0 == 1): point 0 is the first centroid and every
+  // min-distance starts at +inf, so the first update touches every group
+  int cur = md_in ? (int)out[i0 - 1] : 0;
   float cx = px[cur], cy = py[cur], cz = pz[cur];
+  if (!md_in && t == 0) {
+    out[0] = 0;
+    if (cout) {
+      cout[0] = cx;
+      cout[M] = cy;
+      cout[2 * M] = cz;
+    }
+  }
 
   auto publish = [&](int i, uint32_t wmax, uint32_t wtie, float sx, float sy, float sz) {
     fps_block_exchange<WAVES>(slots[i & 1], wave, lane, wmax, wtie, sx, sy, sz, cur, cx, cy, cz);
@@ -1794,8 +1806,10 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
   }
   int m_run = (int)M;
   float* md_out = nullptr;
-  int dense_steps = FPS_DENSE_STEPS;
-  if (const char* e = getenv("S4G_FPS_DENSE_STEPS")) dense_steps = atoi(e) > 1 ? atoi(e) : 2;
+  // steps the full-scan kernel runs in front of the pruned one (S4G_FPS_DENSE_STEPS; 0 = none: the pruned
+  // kernel starts from +inf min-distances by itself)
+  int dense_steps = 0;
+  if (const char* e = getenv("S4G_FPS_DENSE_STEPS")) dense_steps = atoi(e) > 1 ? atoi(e) : 0;
   if (dense_steps >= M) pruned = false;
   // S4G_FPS_SORT=rocprim: round 2's pre-pass (bbox, 30-bit Morton keys, rocprim::radix_sort_pairs over
   // the batch, group boxes: 22 launches) instead of the one-launch cell sort
@@ -1821,7 +1835,7 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
     md_out = w.md;
   }
 
-  bool launched = false;
+  bool launched = pruned && dense_steps == 0;   // (no full-scan launch in front of the pruned kernel)
 #define S4G_FPS_CASE(T, P)                                                   \
   if (!launched && N <= (int64_t)T * P) {                                    \
     hipLaunchKernelGGL((fps_reg_kernel<T, P, FMAD, IdxT>), grid, dim3(T), 0, \
@@ -1851,7 +1865,8 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
     static LdsAttrCache lds_cache;                                                                 \
     if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(&fps_pruned_kernel<T, P, FMAD, IdxT, S>), lds, lds_cache)) return rc;  \
     hipLaunchKernelGGL((fps_pruned_kernel<T, P, FMAD, IdxT, S>), grid, dim3(T), lds, stream, xyz,  \
-                       w.val_out, w.gbox, w.md, dense_steps, (int)N, (int)M, idx, ctr, lg);        \
+                       w.val_out, w.gbox, dense_steps ? w.md : nullptr, dense_steps ? dense_steps : 1, \
+                       (int)N, (int)M, idx, ctr, lg);                                              \
   }
 #define S4G_FPS_PRUNED(T, P)                                                                       \
   if (N <= (int64_t)T * P) {                                                                       \
