@@ -41,8 +41,10 @@ extern "C" {
  * 3: fused layer chains (W2 / W3 fields), GATHER_ADD / INTERP_ADD loaders, s4g_interp_add_cl_f32,
  *    s4g_group_points_ws_f32, device-side cell choice of s4g_three_nn_grid_f32 (cell < 0).
  * 4: per-scene activation maxima (rows_per_scene), bf16 chains, s4g_heads_chain_f32.
- * 5: s4g_group_rel_xyz_i32 and the rel_xyz4 field of s4g_gemm_desc_t. */
-#define S4G_ABI_VERSION 6
+ * 5: s4g_group_rel_xyz_i32 and the rel_xyz4 field of s4g_gemm_desc_t.
+ * 6: pre_* members of s4g_heads_desc_t (the last FP level's tail in front of the heads).
+ * 7: s4g_fps_gather_ex_i32, s4g_fps_prefix_check_f32, s4g_fps_prepass_f32 (no layout change). */
+#define S4G_ABI_VERSION 7
 
 #define S4G_OK 0
 #define S4G_EINVAL (-1)     /* bad size / null pointer */
@@ -431,6 +433,31 @@ int s4g_group_rel_xyz_i32(const float *xyz_b3n, const float *ctr_b3m, const int3
 int s4g_fps_gather_i32(const float *xyz_b3n, int64_t B, int64_t N, int64_t M,
                        int32_t *idx_bm, float *ctr_b3m, void *ws, size_t ws_bytes,
                        int flags, s4g_stream_t stream);
+
+/* FPS of the NEXT set-abstraction level without running it (round 3).
+ *
+ * modules.py:80-83 samples each level from the previous level's centroids, which are the picks of
+ * the previous FPS in pick order.  FPS over such a set, started at its element 0 (sampling_kernel.cu:
+ * 66-68), re-picks the set's own prefix: element k was the farthest point of the WHOLE cloud from
+ * {0..k-1}, the set contains it, so it is also the farthest point of the set -- as long as no other
+ * element ties with it, which is the only case in which the tie rule of sampling_kernel.cu:87-105
+ * matters.  s4g_fps_gather_ex_i32 = s4g_fps_gather_i32 with two optional extras:
+ *   dist_bm (B,M): the min-distance every pick had when it was taken (+inf for pick 0);
+ *                  S4G_EUNSUPPORTED (nothing launched) if this size's kernel cannot report it;
+ *   run_b (B):     run_b[b] == 0 = "scene b's result is the identity prefix": idx = 0..M-1, ctr =
+ *                  the first M input points, nothing sampled (only honoured by the kernels for
+ *                  N <= 10 240; larger inputs are sampled regardless).
+ * s4g_fps_prefix_check_f32 proves or refutes the prefix property per scene: ctr_b3m (B,3,M1) and
+ * dist_bm (B,M1) from the previous level's call; run_b[b] = 0 iff, at every step k < M2, no element
+ * other than k reaches element k's distance (same fp32 arithmetic as the sampler; FMAD flag as
+ * usual).  A scene with run_b[b] = 1 is then sampled for real, so the indices are the reference's
+ * in every case.  One check over M2 steps also covers deeper levels that sample a prefix of this
+ * one (fewer steps over fewer elements).  5 120 -> 1 024: 20 us instead of 0.87 ms. */
+int s4g_fps_gather_ex_i32(const float *xyz_b3n, int64_t B, int64_t N, int64_t M, int32_t *idx_bm,
+                          float *ctr_b3m, float *dist_bm, const int32_t *run_b, void *ws,
+                          size_t ws_bytes, int flags, s4g_stream_t stream);
+int s4g_fps_prefix_check_f32(const float *ctr_b3m, const float *dist_bm, int64_t B, int64_t M1,
+                             int64_t M2, int32_t *run_b, int flags, s4g_stream_t stream);
 
 /* Diagnostic entry (tests): the pruned FPS kernels' pre-pass on its own -- ONE launch, one
  * workgroup per scene: bounding box, a 15-bit cell key per point (2-D Hilbert curve over the two

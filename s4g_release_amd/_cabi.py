@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # declared symbol are checked either way
 LIB_PATH = os.environ.get("S4G_HIP_LIB") or os.path.join(_HERE, "libs4g_hip.so")
 
-S4G_ABI_VERSION = 6
+S4G_ABI_VERSION = 7
+S4G_EUNSUPPORTED = -3
 S4G_FLAG_FMAD = 1
 S4G_OP_FPS, S4G_OP_BALL_QUERY, S4G_OP_THREE_NN = 1, 2, 3
 
@@ -81,6 +82,8 @@ SIGNATURES = {
     "s4g_three_interpolate_ws_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _int, _vp]),
     "s4g_fps_gather_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _int, _vp]),
     "s4g_fps_prepass_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "s4g_fps_gather_ex_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp]),
+    "s4g_fps_prefix_check_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _int, _vp]),
     "s4g_group_rel_xyz_i32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "s4g_expected_score_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "s4g_decode_poses_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),

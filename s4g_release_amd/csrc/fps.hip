@@ -49,6 +49,15 @@ struct FpsSlot {
   uint32_t pad[2];
 };
 
+// Optional per-call extras of the register / pruned kernels: dist (B, M) receives every pick's
+// min-distance at the time it was taken (+inf for pick 0); run (B) = 0 marks scenes whose result is
+// already known to be the identity prefix 0..M-1 (fps_prefix_check_kernel) -- the workgroup writes
+// that and leaves.
+struct FpsExtra {
+  float* dist;
+  const int* run;
+};
+
 #ifdef S4G_FPS_STAMPS
 // debug build only (make HIPFLAGS_EXTRA=-DS4G_FPS_STAMPS into its own OBJDIR / LIB): per (scene, wave)
 // cycle accumulators of fps_pruned_kernel's phases, read back by tools/fps_stamps.py.  The sums are
@@ -79,7 +88,8 @@ __device__ __forceinline__ void fps_block_exchange(FpsSlot* slots, int wave,
                                                    uint32_t wtie, float sx,
                                                    float sy, float sz,
                                                    int& cur, float& cx,
-                                                   float& cy, float& cz) {
+                                                   float& cy, float& cz,
+                                                   uint32_t* dwin = nullptr) {
   if (lane == 0) {
     FpsSlot s;
     s.d = wmax;
@@ -106,6 +116,7 @@ __device__ __forceinline__ void fps_block_exchange(FpsSlot* slots, int wave,
   }
   const int wl = __ffsll((unsigned long long)win) - 1;  // lane < 16, uniform
   cur = (int)(btie & FPS_JMASK);
+  if (dwin) *dwin = __builtin_amdgcn_readfirstlane(bmax);   // the pick's min-distance (bits)
   cx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.x), wl));
   cy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.y), wl));
   cz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.z), wl));
@@ -134,7 +145,8 @@ __device__ __forceinline__ int fps_block_exchange_multi(FpsSlot* slots, int wave
                                                         float sz, int limit, int& cur, float& cx, float& cy,
                                                         float& cz, uint32_t& picked_waves,
                                                         IdxT* __restrict__ out_i, float* __restrict__ cout_i,
-                                                        int M, float& fx, float& fy, float& fz) {
+                                                        int M, float& fx, float& fy, float& fz,
+                                                        float* __restrict__ dout_i = nullptr) {
   if (lane == 0) {
     FpsSlot s;
     s.d = wmax;
@@ -157,6 +169,7 @@ __device__ __forceinline__ int fps_block_exchange_multi(FpsSlot* slots, int wave
   // lane k keeps pick k for ONE store per output array (wave 0 writes)
   int my_idx = 0;
   float my_x = 0.f, my_y = 0.f, my_z = 0.f;
+  uint32_t my_d = 0u;
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) {
     if (k >= limit) break;
@@ -183,6 +196,7 @@ __device__ __forceinline__ int fps_block_exchange_multi(FpsSlot* slots, int wave
       my_x = cx;
       my_y = cy;
       my_z = cz;
+      my_d = bmax;   // the pick's min-distance at the time it is taken (re-ranked exactly for k > 0)
     }
     if (k == 0) {   // (callers that keep the pending centroids in registers: MAXP == 2)
       fx = cx;
@@ -206,6 +220,7 @@ __device__ __forceinline__ int fps_block_exchange_multi(FpsSlot* slots, int wave
       cout_i[M + lane] = my_y;
       cout_i[2 * M + lane] = my_z;
     }
+    if (dout_i) dout_i[lane] = __uint_as_float(my_d);
   }
   picked_waves = pw;
   return np;
@@ -237,7 +252,7 @@ __device__ __forceinline__ void fps_pick(const float (&x)[PPT],
 template <int THREADS, int PPT, bool FMAD, typename IdxT>
 __global__ __launch_bounds__(THREADS) void fps_reg_kernel(
     const float* __restrict__ xyz, int N, int M, IdxT* __restrict__ idx,
-    float* __restrict__ ctr, int lg_bs, int M_run, float* __restrict__ md_out) {
+    float* __restrict__ ctr, int lg_bs, int M_run, float* __restrict__ md_out, FpsExtra ex) {
   // M_run <= M steps are computed (outputs keep stride M); md_out (or NULL) receives the
   // running min-distances afterwards -- the hand-over to fps_pruned_kernel
   constexpr int WAVES = THREADS / 64;
@@ -251,6 +266,19 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(
   const float* __restrict__ pz = py + N;
   IdxT* __restrict__ out = idx + (size_t)b * M;
   float* __restrict__ cout = ctr ? ctr + (size_t)b * 3 * M : nullptr;
+  float* __restrict__ dout = ex.dist ? ex.dist + (size_t)b * M : nullptr;
+  if (ex.run && ex.run[b] == 0) {
+    // proven elsewhere (fps_prefix_check_kernel): this scene's result is the identity prefix
+    for (int i = t; i < M_run; i += THREADS) {
+      out[i] = (IdxT)i;
+      if (cout) {
+        cout[i] = px[i];
+        cout[M + i] = py[i];
+        cout[2 * M + i] = pz[i];
+      }
+    }
+    return;
+  }
 
   float x[PPT], y[PPT], z[PPT], md[PPT];
 #pragma unroll
@@ -276,6 +304,7 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(
       cout[M] = cy;
       cout[2 * M] = cz;
     }
+    if (dout) dout[0] = __builtin_inff();
   }
 
   for (int i = 1; i < M_run; ++i) {
@@ -334,8 +363,9 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(
     // coordinates of this wave's candidate: static register index per case.
     float sx = cx, sy = cy, sz = cz;
     if (pw >= 0) fps_pick<PPT, 0, PPT>(x, y, z, pw, wl, sx, sy, sz);
+    uint32_t dwin;
     fps_block_exchange<WAVES>(slots[i & 1], wave, lane, wmax, wtie, sx, sy, sz, cur,
-                       cx, cy, cz);
+                       cx, cy, cz, &dwin);
     if (t == 0) {
       out[i] = (IdxT)cur;
       if (cout) {  // centroid gather fused in: the winner's xyz is already here
@@ -343,6 +373,7 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(
         cout[M + i] = cy;
         cout[2 * M + i] = cz;
       }
+      if (dout) dout[i] = __uint_as_float(dwin);
     }
   }
   if (md_out) {
@@ -1228,7 +1259,8 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
                                                              const float* __restrict__ gbox,
                                                              const float* __restrict__ md_in, int i0,
                                                              int N, int M, IdxT* __restrict__ idx,
-                                                             float* __restrict__ ctr, int lg_bs) {
+                                                             float* __restrict__ ctr, int lg_bs,
+                                                             float* __restrict__ dist) {
   constexpr int WAVES = THREADS / 64;
   constexpr int GPL = (PPT + 63) / 64;   // group registers per lane: slot p lives in lane p % 64, reg p / 64
   constexpr bool SPEC = MAXP > 1;
@@ -1244,6 +1276,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
   const int* __restrict__ pb = perm + (size_t)b * N;
   IdxT* __restrict__ out = idx + (size_t)b * M;
   float* __restrict__ cout = ctr ? ctr + (size_t)b * 3 * M : nullptr;
+  float* __restrict__ dout = dist ? dist + (size_t)b * M : nullptr;   // every pick's min-distance (optional)
   const uint32_t bs_mask = (1u << lg_bs) - 1u;
   auto tie_key = [&](uint32_t j) { return ((__brev(j & bs_mask) >> (32 - lg_bs)) << 23) | j; };
 
@@ -1287,10 +1320,12 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
       cout[M] = cy;
       cout[2 * M] = cz;
     }
+    if (dout) dout[0] = __builtin_inff();
   }
 
   auto publish = [&](int i, uint32_t wmax, uint32_t wtie, float sx, float sy, float sz) {
-    fps_block_exchange<WAVES>(slots[i & 1], wave, lane, wmax, wtie, sx, sy, sz, cur, cx, cy, cz);
+    uint32_t dwin;
+    fps_block_exchange<WAVES>(slots[i & 1], wave, lane, wmax, wtie, sx, sy, sz, cur, cx, cy, cz, &dwin);
     if (t == 0) {
       out[i] = (IdxT)cur;
       if (cout) {
@@ -1298,6 +1333,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
         cout[M + i] = cy;
         cout[2 * M + i] = cz;
       }
+      if (dout) dout[i] = __uint_as_float(dwin);
     }
   };
 
@@ -1465,7 +1501,8 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
       // exchange
       npend = fps_block_exchange_multi<WAVES, FMAD, MAXP, IdxT>(slots[xpar], wave, lane, wmax, wtie, wd2, sx, sy,
                                                                 sz, M - i, cur, cx, cy, cz, pwaves, out + i,
-                                                                cout ? cout + i : nullptr, M, f0x, f0y, f0z);
+                                                                cout ? cout + i : nullptr, M, f0x, f0y, f0z,
+                                                                dout ? dout + i : nullptr);
       xpar ^= 1;
       i += npend;
     } else {
@@ -1510,7 +1547,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
                                                                 const float4* __restrict__ sorted,
                                                                 const float* __restrict__ gbox, int N, int M,
                                                                 IdxT* __restrict__ idx, float* __restrict__ ctr,
-                                                                int lg_bs) {
+                                                                int lg_bs, float* __restrict__ dist) {
   constexpr int WAVES = THREADS / 64;
   constexpr int GPL = (PPT + 63) / 64;
   constexpr int G = WAVES * PPT;
@@ -1523,6 +1560,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
   const float4* __restrict__ srt = sorted + (size_t)b * THREADS * PPT;
   IdxT* __restrict__ out = idx + (size_t)b * M;
   float* __restrict__ cout = ctr ? ctr + (size_t)b * 3 * M : nullptr;
+  float* __restrict__ dout = dist ? dist + (size_t)b * M : nullptr;
   const uint32_t bs_mask = (1u << lg_bs) - 1u;
   auto tie_key = [&](uint32_t j) { return ((__brev(j & bs_mask) >> (32 - lg_bs)) << 23) | j; };
   // slot p of this lane = sorted position 64 * (WAVES * p + wave) + lane; its record through a
@@ -1559,6 +1597,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
       cout[M] = cy;
       cout[2 * M] = cz;
     }
+    if (dout) dout[0] = __builtin_inff();
   }
 
   // (two picks per exchange here: with a touched group costing an L2 round trip the update phase
@@ -1682,7 +1721,8 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
     }
     npend = fps_block_exchange_multi<WAVES, FMAD, MAXP, IdxT>(slots[xpar], wave, lane, wmax, wtie, wd2, sx, sy, sz,
                                                               M - i, cur, cx, cy, cz, pwaves, out + i,
-                                                              cout ? cout + i : nullptr, M, fx, fy, fz);
+                                                              cout ? cout + i : nullptr, M, fx, fy, fz,
+                                                              dout ? dout + i : nullptr);
     xpar ^= 1;   // per exchange (a multiple pick advances i by more than one)
     i += npend;
   }
@@ -1776,6 +1816,54 @@ static bool fps_use_cluster(int64_t B) {
 }
 static size_t fps_cluster_ws_bytes(int64_t B) { return (size_t)B * 4 * sizeof(FpsXch) + 64; }
 
+// ---------------------------------------------------------------------------
+// FPS of an FPS-ordered set is its own prefix.  Let c_0 .. c_{M1-1} be the picks of one FPS run in
+// pick order, D_k the min-distance pick k had when it was taken.  A second FPS over THAT set (the
+// next set-abstraction level: modules.py:80-83 samples the previous level's centroids) starts at c_0
+// and at step k looks for the point of the set farthest from {c_0 .. c_{k-1}}: c_k was the farthest
+// point of the whole cloud, the set is a subset that contains it, so c_k attains the maximum of the
+// set too -- with the same value D_k, the same fp32 arithmetic.  If it is the ONLY point that attains
+// it, the second run picks position k whatever the tie rule; by induction its output is 0, 1, 2, ...
+// This kernel checks the "only": lane j keeps m = min_{i < k} d(c_i, c_j) (the running min-distance
+// the second run would hold for position j) and the scene fails if some j > k reaches D_k (or D_k
+// is not a positive finite number).  M2 - 1 steps per lane, no communication: 20 us where the
+// sequential run takes 0.87 ms (5 120 -> 1 024).  A scene that fails is sampled by the real kernel
+// (fps_reg_kernel's `run` flag), so the result is the reference's in every case; a check over the
+// first M2 steps also covers every further level that samples a prefix of this one.
+// ---------------------------------------------------------------------------
+template <bool FMAD>
+__global__ __launch_bounds__(256) void fps_prefix_check_kernel(const float* __restrict__ ctr,
+                                                               const float* __restrict__ dist, int M1,
+                                                               int M2, int* __restrict__ run) {
+  __shared__ float4 step[256];   // (c_k, D_{k+1}) of 256 steps at a time
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const float* __restrict__ cx = ctr + (size_t)b * 3 * M1;
+  const float* __restrict__ cy = cx + M1;
+  const float* __restrict__ cz = cy + M1;
+  const float* __restrict__ D = dist + (size_t)b * M1;
+  const int jj = j < M1 ? j : 0;
+  const float sx = cx[jj], sy = cy[jj], sz = cz[jj];
+  float m = __builtin_inff();
+  bool bad = false;
+  for (int k0 = 0; k0 + 1 < M2; k0 += 256) {
+    const int kk = k0 + threadIdx.x;
+    __syncthreads();
+    if (kk + 1 < M2) step[threadIdx.x] = make_float4(cx[kk], cy[kk], cz[kk], D[kk + 1]);
+    __syncthreads();
+    const int n = min(256, M2 - 1 - k0);
+#pragma unroll 4
+    for (int q = 0; q < n; ++q) {
+      const float4 c = step[q];
+      const float d = dist2<FMAD>(c.x, c.y, c.z, sx, sy, sz);   // (centroid, point): the kernels' order
+      m = d < m ? d : m;
+      const int k = k0 + q;
+      bad |= !(c.w > 0.f) || !(c.w < __builtin_inff()) || (j > k + 1 && j < M1 && !(m < c.w));
+    }
+  }
+  if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(&run[b], 1);
+}
+
 static int launch_fps_cell_sort(const float* xyz, int64_t B, int64_t N, int G, int* perm, float* gbox,
                                 float4* aos, int aos_cap, hipStream_t stream) {
   constexpr size_t lds = sizeof(uint32_t) * (FPS_SORT_WORDS + 3 * 256 + 64 * 64 / 2 + 7 * (FPS_SORT_THREADS / 64));
@@ -1790,7 +1878,7 @@ static int launch_fps_cell_sort(const float* xyz, int64_t B, int64_t N, int G, i
 template <bool FMAD, typename IdxT>
 static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
                       IdxT* idx, float* ctr, void* ws, size_t ws_bytes,
-                      hipStream_t stream) {
+                      hipStream_t stream, FpsExtra ex = FpsExtra{nullptr, nullptr}) {
   const int lg = ref_block_lg(N);
   const dim3 grid((unsigned)B);
   int variant = 0;  // S4G_FPS_THREADS=1024 (tuning knob)
@@ -1840,7 +1928,7 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
   if (!launched && N <= (int64_t)T * P) {                                    \
     hipLaunchKernelGGL((fps_reg_kernel<T, P, FMAD, IdxT>), grid, dim3(T), 0, \
                        stream, xyz, (int)N, (int)M, idx, ctr, lg, m_run,     \
-                       md_out);                                              \
+                       md_out, ex);                                          \
     S4G_LAUNCH_CHECK();                                                      \
     launched = true;                                                         \
   }
@@ -1866,7 +1954,7 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
     if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(&fps_pruned_kernel<T, P, FMAD, IdxT, S>), lds, lds_cache)) return rc;  \
     hipLaunchKernelGGL((fps_pruned_kernel<T, P, FMAD, IdxT, S>), grid, dim3(T), lds, stream, xyz,  \
                        w.val_out, w.gbox, dense_steps ? w.md : nullptr, dense_steps ? dense_steps : 1, \
-                       (int)N, (int)M, idx, ctr, lg);                                              \
+                       (int)N, (int)M, idx, ctr, lg, ex.dist);                                     \
   }
 #define S4G_FPS_PRUNED(T, P)                                                                       \
   if (N <= (int64_t)T * P) {                                                                       \
@@ -1915,11 +2003,12 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
         S4G_LAUNCH_CHECK();
       }
       hipLaunchKernelGGL((fps_pruned_l2_kernel<512, 100, FMAD, IdxT, 2>), grid, dim3(512), 0, stream, xyz,
-                         w2.aos, w2.gbox, (int)N, (int)M, idx, ctr, lg);
+                         w2.aos, w2.gbox, (int)N, (int)M, idx, ctr, lg, ex.dist);
       S4G_LAUNCH_CHECK();
       return S4G_OK;
     }
   }
+  if (ex.dist) return S4G_EUNSUPPORTED;   // the remaining kernels do not report pick distances
   // opt-in: two workgroups per scene, all points in registers, winners exchanged through L2 once
   // per step (see fps_use_cluster for the co-residency requirement)
   if (N <= (int64_t)512 * 100 && fps_use_cluster(B) && ws && ws_bytes >= fps_cluster_ws_bytes(B)) {
@@ -1969,6 +2058,40 @@ extern "C" int s4g_debug_fps_stamps(unsigned long long* host_out_64x8x8, int res
   return (int)e;
 }
 #endif
+
+extern "C" int s4g_fps_gather_ex_i32(const float* xyz_b3n, int64_t B, int64_t N, int64_t M,
+                                     int32_t* idx_bm, float* ctr_b3m, float* dist_bm,
+                                     const int32_t* run_b, void* ws, size_t ws_bytes, int flags,
+                                     s4g_stream_t stream) {
+  if (B < 0 || M <= 0 || N < M || N >= (1 << 23)) return S4G_EINVAL;
+  if (B == 0) return S4G_OK;
+  if (!xyz_b3n || !idx_bm || !ctr_b3m) return S4G_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const s4g::FpsExtra ex{dist_bm, run_b};
+  if (flags & S4G_FLAG_FMAD)
+    return s4g::launch_fps<true, int32_t>(xyz_b3n, B, N, M, idx_bm, ctr_b3m, ws, ws_bytes, st, ex);
+  return s4g::launch_fps<false, int32_t>(xyz_b3n, B, N, M, idx_bm, ctr_b3m, ws, ws_bytes, st, ex);
+}
+
+extern "C" int s4g_fps_prefix_check_f32(const float* ctr_b3m, const float* dist_bm, int64_t B,
+                                        int64_t M1, int64_t M2, int32_t* run_b, int flags,
+                                        s4g_stream_t stream) {
+  if (B < 0 || M1 <= 0 || M2 <= 0 || M2 > M1 || M1 >= (1 << 23) || B > 65535) return S4G_EINVAL;
+  if (B == 0) return S4G_OK;
+  if (!ctr_b3m || !dist_bm || !run_b) return S4G_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(run_b, 0, sizeof(int32_t) * (size_t)B, st);
+  if (e != hipSuccess) return (int)e;
+  const dim3 grid((unsigned)((M1 + 255) / 256), (unsigned)B);
+  if (flags & S4G_FLAG_FMAD)
+    hipLaunchKernelGGL(s4g::fps_prefix_check_kernel<true>, grid, dim3(256), 0, st, ctr_b3m, dist_bm, (int)M1,
+                       (int)M2, run_b);
+  else
+    hipLaunchKernelGGL(s4g::fps_prefix_check_kernel<false>, grid, dim3(256), 0, st, ctr_b3m, dist_bm, (int)M1,
+                       (int)M2, run_b);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
 
 extern "C" int s4g_fps_prepass_f32(const float* xyz_b3n, int64_t B, int64_t N, int64_t G,
                                    int32_t* perm_bn, float* gbox_bg6, s4g_stream_t stream) {

@@ -169,6 +169,7 @@ class FusedPointNet2:
         self.rel_xyz = os.environ.get("S4G_REL_XYZ", "1") != "0"
         self.heads_pre = os.environ.get("S4G_HEADS_PRE", "1") != "0"
         self.fp_chain_next = os.environ.get("S4G_FP_CHAIN_NEXT", "1") != "0"
+        self.fps_prefix = os.environ.get("S4G_FPS_PREFIX", "1") != "0"
         p = next(net.parameters())
         if not p.is_cuda:
             raise RuntimeError("FusedPointNet2 needs the model on a HIP device (no CPU fallback)")
@@ -394,17 +395,41 @@ class FusedPointNet2:
             rc = _cabi.lib().s4g_heads_chain_f32(ctypes.byref(d), _F._stream())
         _cabi.check(rc, "heads_chain")
 
-    def _fps_gather(self, xyz, M):
+    def _fps_gather(self, xyz, M, want_dist=False, run=None):
+        """idx (B, M) int32 + centroids (B, 3, M).  want_dist: also the picks' min-distances (B, M), or
+        None where this size's kernel cannot report them; run (B,) int32: scenes with run == 0 are
+        known to sample their own prefix (`_fps_prefix_check`) and are not sampled."""
         B, _, N = xyz.shape
         idx = torch.empty((B, M), dtype=torch.int32, device=xyz.device)
         ctr = torch.empty((B, 3, M), dtype=torch.float32, device=xyz.device)
         ws, nbytes = _F._workspace(_cabi.S4G_OP_FPS, xyz.device, B, N, M, 0)
+        dist = torch.empty((B, M), dtype=torch.float32, device=xyz.device) if want_dist else None
         with _F._timed("fps[N=%d,M=%d]" % (N, M), B * (12 * N + 8 * M)):
-            rc = _cabi.lib().s4g_fps_gather_i32(xyz.data_ptr(), B, N, M, idx.data_ptr(),
-                                                ctr.data_ptr(), _F._ptr(ws), nbytes,
-                                                _F._DIST_FLAGS, _F._stream())
+            if dist is not None or run is not None:
+                rc = _cabi.lib().s4g_fps_gather_ex_i32(xyz.data_ptr(), B, N, M, idx.data_ptr(), ctr.data_ptr(),
+                                                       None if dist is None else dist.data_ptr(),
+                                                       None if run is None else run.data_ptr(),
+                                                       _F._ptr(ws), nbytes, _F._DIST_FLAGS, _F._stream())
+                if rc == _cabi.S4G_EUNSUPPORTED and run is None:
+                    dist, rc = None, 0           # nothing was launched: plain call below
+                    rc = _cabi.lib().s4g_fps_gather_i32(xyz.data_ptr(), B, N, M, idx.data_ptr(), ctr.data_ptr(),
+                                                        _F._ptr(ws), nbytes, _F._DIST_FLAGS, _F._stream())
+            else:
+                rc = _cabi.lib().s4g_fps_gather_i32(xyz.data_ptr(), B, N, M, idx.data_ptr(),
+                                                    ctr.data_ptr(), _F._ptr(ws), nbytes,
+                                                    _F._DIST_FLAGS, _F._stream())
         _cabi.check(rc, "fps_gather")
-        return idx, ctr
+        return (idx, ctr, dist) if want_dist else (idx, ctr)
+
+    def _fps_prefix_check(self, ctr, dist, M2):
+        """(B,) int32, 0 where FPS over these centroids (in pick order) provably re-picks 0..M2-1."""
+        B, _, M1 = ctr.shape
+        run = torch.empty((B,), dtype=torch.int32, device=ctr.device)
+        with _F._timed("fps_prefix_check[M1=%d,M2=%d]" % (M1, M2), B * 16 * M1):
+            rc = _cabi.lib().s4g_fps_prefix_check_f32(ctr.data_ptr(), dist.data_ptr(), B, M1, M2, run.data_ptr(),
+                                                      _F._DIST_FLAGS, _F._stream())
+        _cabi.check(rc, "fps_prefix_check")
+        return run
 
     def _ball_query(self, xyz, ctr, radius, K):
         B, _, N = xyz.shape
@@ -462,11 +487,20 @@ class FusedPointNet2:
         B, _, N0 = xyz.shape
         geo = dict(level_xyz=[xyz], level_n=[N0], sa=[], fp=[], sa_events=[], rel=[])
         n_cur = N0
-        for sa in self.sa:
+        # every level after the first samples the previous level's centroids, which are in pick
+        # order: FPS then re-picks their prefix unless two of them tie (include/s4g_ops.h,
+        # s4g_fps_prefix_check_f32).  One check after level 0 over the next level's M covers all
+        # deeper levels; scenes that fail it are sampled for real.  S4G_FPS_PREFIX=0: always sample.
+        run = None
+        for li, sa in enumerate(self.sa):
             M, K = sa["M"], sa["K"]
             if not n_cur >= M:
                 raise RuntimeError("num_points is not greater than or equal to num_centroids")
-            idx, ctr = self._fps_gather(geo["level_xyz"][-1], M)
+            dist = None
+            if li == 0 and self.fps_prefix and len(self.sa) > 1 and self.sa[1]["M"] <= M:
+                idx, ctr, dist = self._fps_gather(geo["level_xyz"][-1], M, want_dist=True)
+            else:
+                idx, ctr = self._fps_gather(geo["level_xyz"][-1], M, run=run if li > 0 else None)
             gidx, gcnt = self._ball_query(geo["level_xyz"][-1], ctr, sa["radius"], K)
             geo["sa"].append((idx, ctr, gidx, gcnt))
             # the xyz-only first layer runs inside the next layer's loader: hand it its rows
@@ -476,6 +510,9 @@ class FusedPointNet2:
             # the contractions of this SA level only need its own sampling + grouping:
             # they may start while the deeper levels' FPS / 3-NN are still running
             geo["sa_events"].append(torch.cuda.current_stream().record_event())
+            if dist is not None and all(self.sa[l + 1]["M"] <= self.sa[l]["M"] for l in range(1, len(self.sa) - 1)):
+                # (behind the event: the first level's contractions do not wait for the check)
+                run = self._fps_prefix_check(ctr, dist, self.sa[1]["M"])
             geo["level_xyz"].append(ctr)
             geo["level_n"].append(M)
             n_cur = M

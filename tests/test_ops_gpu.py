@@ -251,6 +251,99 @@ def test_group_points_backward(F, oracle, dev):
 
 
 # ------------------------------------------------------------------ 3-NN + interpolate
+def _fps_ex(pts, M, dev, want_dist=True, run=None):
+    """s4g_fps_gather_ex_i32 -> (idx (B,M) int64, ctr (B,3,M), dist (B,M) or None) as numpy."""
+    from s4g_release_amd import _cabi, functions as F
+    B, _, N = pts.shape
+    x = _t(pts, dev)
+    idx = torch.full((B, M), -7, dtype=torch.int32, device=dev)
+    ctr = torch.zeros((B, 3, M), dtype=torch.float32, device=dev)
+    dist = torch.zeros((B, M), dtype=torch.float32, device=dev) if want_dist else None
+    ws, nbytes = F._workspace(_cabi.S4G_OP_FPS, x.device, B, N, M, 0)
+    rc = _cabi.lib().s4g_fps_gather_ex_i32(x.data_ptr(), B, N, M, idx.data_ptr(), ctr.data_ptr(),
+                                           None if dist is None else dist.data_ptr(),
+                                           None if run is None else run.data_ptr(), F._ptr(ws), nbytes,
+                                           F._DIST_FLAGS, torch.cuda.current_stream().cuda_stream)
+    _cabi.check(rc, "fps_gather_ex")
+    torch.cuda.synchronize()
+    return (idx.cpu().numpy().astype(np.int64), ctr.cpu().numpy(),
+            None if dist is None else dist.cpu().numpy())
+
+
+def _prefix_check(ctr, dist, M2, dev):
+    from s4g_release_amd import _cabi, functions as F
+    B, _, M1 = ctr.shape
+    c, d = _t(ctr, dev), _t(dist, dev)
+    run = torch.full((B,), 5, dtype=torch.int32, device=dev)
+    rc = _cabi.lib().s4g_fps_prefix_check_f32(c.data_ptr(), d.data_ptr(), B, M1, M2, run.data_ptr(),
+                                              F._DIST_FLAGS, torch.cuda.current_stream().cuda_stream)
+    _cabi.check(rc, "fps_prefix_check")
+    torch.cuda.synchronize()
+    return run
+
+
+def _pick_distances(pts_b, idx_b):
+    """D_k = min_{i<k} ((dx*dx)+(dy*dy))+(dz*dz) in fp32, every operation rounded (numpy fp32)."""
+    c = pts_b[:, idx_b].astype(np.float32)                       # (3, M)
+    M = c.shape[1]
+    out = np.full(M, np.inf, np.float32)
+    md = np.full(M, np.inf, np.float32)
+    for k in range(1, M):
+        d = c - c[:, k - 1:k]
+        md = np.minimum(md, (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
+        out[k] = md[k]
+    return out
+
+
+@pytest.mark.parametrize("variant,N,M1,M2", [("tabletop-v1", 25600, 5120, 1024), ("dup-heavy", 25600, 5120, 1024),
+                                             ("uniform-box", 12000, 3000, 700), ("tabletop-v1", 5120, 1024, 256),
+                                             ("tabletop-v1", 51200, 5120, 1024)])
+def test_fps_of_an_fps_ordered_set_is_its_prefix(oracle, dev, variant, N, M1, M2):
+    """The next set-abstraction level samples the previous level's centroids (modules.py:80-83), which
+    are in pick order: FPS then re-picks their prefix unless two of them tie.  (1) the pick distances
+    s4g_fps_gather_ex_i32 reports are the fp32 min-distances of the picks; (2) on these clouds
+    s4g_fps_prefix_check_f32 proves the prefix property for every scene; (3) the ORACLE's FPS over the
+    centroids is the identity prefix indeed; (4) the conditional call returns exactly that without
+    sampling."""
+    pts = synth.make_batch([2, 7], N, variant=variant)
+    idx, ctr, dist = _fps_ex(pts, M1, dev)
+    assert np.array_equal(idx, oracle.fps(pts, M1))
+    for b in range(2):
+        assert np.array_equal(dist[b], _pick_distances(pts[b], idx[b])), b
+    run = _prefix_check(ctr, dist, M2, dev)
+    assert run.cpu().tolist() == [0, 0]
+    want = oracle.fps(ctr, M2)
+    assert np.array_equal(want, np.tile(np.arange(M2), (2, 1)))
+    idx2, ctr2, _ = _fps_ex(ctr, M2, dev, want_dist=False, run=run)
+    assert np.array_equal(idx2, want) and np.array_equal(ctr2, ctr[:, :, :M2])
+
+
+def test_fps_prefix_check_refuses_ties_and_the_sampler_runs(oracle, dev):
+    """Lattice clouds: many points share their distance to the picked set, so the tie rule of
+    sampling_kernel.cu:87-105 decides and the next level is NOT the prefix in general.  The check
+    must flag such scenes (never claim a prefix the oracle does not produce), and the conditional
+    call must then equal the oracle's FPS for flagged and unflagged scenes alike."""
+    rng = np.random.default_rng(11)
+    flagged = 0
+    for trial in range(6):
+        pts = _quantized(rng, 3, 4000, levels=12, scale=0.05)
+        if trial % 2:
+            pts[1] = synth.make_batch([trial], 4000)[0]            # a tie-free scene between two lattices
+        M1, M2 = 900, 300
+        idx, ctr, dist = _fps_ex(pts, M1, dev)
+        assert np.array_equal(idx, oracle.fps(pts, M1))
+        run = _prefix_check(ctr, dist, M2, dev)
+        want = oracle.fps(ctr, M2)
+        for b in range(3):
+            if run[b].item() == 0:
+                assert np.array_equal(want[b], np.arange(M2)), (trial, b)
+        flagged += int((run != 0).sum().item())
+        idx2, ctr2, _ = _fps_ex(ctr, M2, dev, want_dist=False, run=run)
+        assert np.array_equal(idx2, want), trial
+        assert np.array_equal(ctr2, oracle.gather_points(ctr, want)), trial
+    assert flagged > 0                                              # the lattice scenes do tie
+
+
 def _fps_prepass(pts, dev):
     """s4g_fps_prepass_f32 -> (perm (B,N) int64, boxes (B,G,6) fp32) as numpy."""
     from s4g_release_amd import _cabi
