@@ -318,6 +318,32 @@ def test_fps_of_an_fps_ordered_set_is_its_prefix(oracle, dev, variant, N, M1, M2
     assert np.array_equal(idx2, want) and np.array_equal(ctr2, ctr[:, :, :M2])
 
 
+def test_fps_prefix_check_fmad_contract_and_unsupported_sizes(F, oracle, dev):
+    """The check uses the sampler's arithmetic, also under the fmad contract (S4G_FLAG_FMAD); sizes whose
+    kernels cannot report pick distances answer S4G_EUNSUPPORTED before launching anything."""
+    from s4g_release_amd import _cabi
+    pts = synth.make_batch([4, 6], 12000)
+    F.set_distance_mode("fmad")
+    try:
+        idx, ctr, dist = _fps_ex(pts, 2400, dev)
+        assert np.array_equal(idx, oracle.fps(pts, 2400, fmad=1))
+        run = _prefix_check(ctr, dist, 600, dev)
+        assert run.cpu().tolist() == [0, 0]
+        assert np.array_equal(oracle.fps(ctr, 600, fmad=1), np.tile(np.arange(600), (2, 1)))
+    finally:
+        F.set_distance_mode("strict")
+    big = _t(synth.make_batch([1], 70000), dev)
+    idx = torch.full((1, 100), -7, dtype=torch.int32, device=dev)
+    ctr = torch.zeros((1, 3, 100), dtype=torch.float32, device=dev)
+    dist = torch.zeros((1, 100), dtype=torch.float32, device=dev)
+    ws, nbytes = F._workspace(_cabi.S4G_OP_FPS, big.device, 1, 70000, 100, 0)
+    rc = _cabi.lib().s4g_fps_gather_ex_i32(big.data_ptr(), 1, 70000, 100, idx.data_ptr(), ctr.data_ptr(),
+                                           dist.data_ptr(), None, F._ptr(ws), nbytes, F._DIST_FLAGS,
+                                           torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rc == _cabi.S4G_EUNSUPPORTED and (idx == -7).all()
+
+
 def test_fps_prefix_check_refuses_ties_and_the_sampler_runs(oracle, dev):
     """Lattice clouds: many points share their distance to the picked set, so the tie rule of
     sampling_kernel.cu:87-105 decides and the next level is NOT the prefix in general.  The check
