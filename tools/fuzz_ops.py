@@ -46,6 +46,8 @@ def main():
             else:
                 os.environ.pop(k, None)
         pts = synth.make_batch([int(rng.integers(1 << 20)) for _ in range(B)], N, variant=variant)
+        if rng.integers(5) == 0:      # a lattice scene: exact distance ties everywhere
+            pts[B - 1] = rng.integers(0, 14, size=(3, N)).astype(np.float32) * np.float32(0.03)
         if rng.integers(3) == 0:      # a few far-away / repeated points
             pts[0, :, int(rng.integers(N))] += np.float32(rng.choice([3.0, 400.0]))
             pts[0, :, int(rng.integers(N))] = pts[0, :, 0]
@@ -65,6 +67,34 @@ def main():
             i2, c2, g2 = F.query_and_group(tp, torch.from_numpy(ctr).to(dev), radius, K)
             assert np.array_equal(i2.cpu().numpy(), ridx), "query_and_group index"
             assert np.array_equal(g2.cpu().numpy(), O.group_points(pts, ridx)), "query_and_group xyz"
+            if N <= 51200 and M >= 2:      # the next level: prefix check + conditional sampler
+                from s4g_release_amd import _cabi
+                lib = _cabi.lib()
+                st = torch.cuda.current_stream().cuda_stream
+                fl = F._DIST_FLAGS
+                i1 = torch.empty((B, M), dtype=torch.int32, device=dev)
+                c1 = torch.empty((B, 3, M), dtype=torch.float32, device=dev)
+                d1 = torch.empty((B, M), dtype=torch.float32, device=dev)
+                ws, nb = F._workspace(_cabi.S4G_OP_FPS, dev, B, N, M, 0)
+                rc = lib.s4g_fps_gather_ex_i32(tp.data_ptr(), B, N, M, i1.data_ptr(), c1.data_ptr(), d1.data_ptr(),
+                                               None, F._ptr(ws), nb, fl, st)
+                # (S4G_EUNSUPPORTED: this size / mode runs a kernel that reports no distances -- nothing launched)
+                assert rc in (0, _cabi.S4G_EUNSUPPORTED), "fps_gather_ex rc"
+            if N <= 51200 and M >= 2 and rc == 0:
+                assert np.array_equal(i1.cpu().numpy().astype(np.int64), rfps), "fps_gather_ex"
+                M2 = int(rng.integers(1, M + 1))
+                run = torch.empty((B,), dtype=torch.int32, device=dev)
+                assert lib.s4g_fps_prefix_check_f32(c1.data_ptr(), d1.data_ptr(), B, M, M2, run.data_ptr(), fl, st) == 0
+                want = O.fps(ctr, M2, fmad=int(fmad))
+                for b in range(B):
+                    if run[b].item() == 0:
+                        assert np.array_equal(want[b], np.arange(M2)), "prefix claimed, oracle disagrees"
+                i2b = torch.empty((B, M2), dtype=torch.int32, device=dev)
+                c2b = torch.empty((B, 3, M2), dtype=torch.float32, device=dev)
+                ws2, nb2 = F._workspace(_cabi.S4G_OP_FPS, dev, B, M, M2, 0)
+                rc = lib.s4g_fps_gather_ex_i32(c1.data_ptr(), B, M, M2, i2b.data_ptr(), c2b.data_ptr(), None,
+                                               run.data_ptr(), F._ptr(ws2), nb2, fl, st)
+                assert rc == 0 and np.array_equal(i2b.cpu().numpy().astype(np.int64), want), "conditional fps"
             if M >= 3:
                 nidx, nd2 = F.search_nn_distance(tp, torch.from_numpy(ctr).to(dev), 3)
                 rn, rd = O.three_nn(pts, ctr, fmad=int(fmad))
