@@ -145,3 +145,43 @@ def test_batch_with_a_rescaled_scene_leaves_the_others_unchanged(dev):
                 assert float((one[k][0] - full[k][s]).abs().max()) <= 1e-6, (s, k)
     for k in HEADS:
         assert torch.isfinite(full[k]).all()
+
+
+def test_proven_and_sampled_scenes_share_a_batch(dev, monkeypatch):
+    """The deeper levels' FPS is proven per scene (FPS of an FPS-ordered set is its own prefix unless
+    two elements tie) and only sampled where the proof fails.  A batch that mixes ordinary scenes
+    with lattice scenes (exact distance ties: the proof must fail there) has to give, scene by scene,
+    exactly what the always-sampling path gives (`S4G_FPS_PREFIX=0`): every index tensor and every
+    output bit for bit -- and the oracle's FPS pyramid for the lattice scene."""
+    from oracle import oracle as O
+    from s4g_release_amd import synth
+    from s4g_release_amd.fused import FusedPointNet2
+    net = GU.build_full_model(20260101).to(dev)
+    rng = np.random.default_rng(23)
+    pts = synth.make_batch([1, 2, 3, 4], 25600)
+    for b in (1, 3):
+        pts[b] = rng.integers(0, 40, size=(3, 25600)).astype(np.float32) * np.float32(0.01)
+    x = torch.from_numpy(pts).to(dev)
+    fast = FusedPointNet2(net)
+    assert fast.fps_prefix
+    monkeypatch.setenv("S4G_FPS_PREFIX", "0")
+    slow = FusedPointNet2(net)
+    assert not slow.fps_prefix
+    with torch.no_grad():
+        pf, inf_ = fast({"scene_points": x}, return_intermediates=True)
+        pf = {k: v.clone() for k, v in pf.items()}
+        inf_ = {k: v.clone() for k, v in inf_.items()}
+        ps, ins = slow({"scene_points": x}, return_intermediates=True)
+    for k in ins:
+        assert torch.equal(inf_[k], ins[k]), k
+    for k in HEADS:
+        assert torch.equal(pf[k], ps[k]), k
+    # the lattice scenes do NOT sample their prefix at level 2 (so the proof had to fail for them) ...
+    f1 = inf_["fps1"].cpu().numpy().astype(np.int64)
+    assert not np.array_equal(f1[1], np.arange(f1.shape[1])) or not np.array_equal(f1[3], np.arange(f1.shape[1]))
+    assert np.array_equal(f1[0], np.arange(f1.shape[1])) and np.array_equal(f1[2], np.arange(f1.shape[1]))
+    # ... and what they sample is the oracle's pyramid
+    i0 = O.fps(pts[1:2], 5120)
+    c0 = O.gather_points(pts[1:2], i0)
+    assert np.array_equal(inf_["fps0"][1:2].cpu().numpy().astype(np.int64), i0)
+    assert np.array_equal(f1[1:2], O.fps(c0, 1024))
