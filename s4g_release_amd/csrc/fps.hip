@@ -29,7 +29,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "s4g_common.h"
 
@@ -819,88 +818,8 @@ __device__ __forceinline__ float ordered_f32(uint32_t u) {
   return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
 }
 
-__global__ __launch_bounds__(1024) void fps_bbox_kernel(const float* __restrict__ xyz, int N,
-                                                         float* __restrict__ bbox) {
-  __shared__ uint32_t red[6][16];
-  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const float* p = xyz + (size_t)b * 3 * N;
-  uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
-  for (int j = t; j < N; j += 1024)
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const uint32_t v = f32_ordered(p[(size_t)a * N + j]);
-      lo[a] = min(lo[a], v);
-      hi[a] = max(hi[a], v);
-    }
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const uint32_t l = wave_min_u32(lo[a]), h = wave_max_u32(hi[a]);
-    if (lane == 0) {
-      red[a][wave] = l;
-      red[3 + a][wave] = h;
-    }
-  }
-  __syncthreads();
-  if (t < 6) {
-    uint32_t v = red[t][0];
-    for (int w = 1; w < 16; ++w) v = t < 3 ? min(v, red[t][w]) : max(v, red[t][w]);
-    bbox[b * 6 + t] = ordered_f32(v);
-  }
-}
 
-__device__ __forceinline__ uint32_t spread10(uint32_t v) {   // 10 bits -> every third bit
-  v &= 0x3FFu;
-  v = (v | (v << 16)) & 0x030000FFu;
-  v = (v | (v << 8)) & 0x0300F00Fu;
-  v = (v | (v << 4)) & 0x030C30C3u;
-  v = (v | (v << 2)) & 0x09249249u;
-  return v;
-}
 
-__global__ void fps_morton_kernel(const float* __restrict__ xyz, int N, int B,
-                                  const float* __restrict__ bbox, uint64_t* __restrict__ key,
-                                  int* __restrict__ val) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int b = blockIdx.y;
-  if (j >= N) return;
-  const float* p = xyz + (size_t)b * 3 * N;
-  const float* bb = bbox + b * 6;
-  uint32_t q[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const float ext = bb[3 + a] - bb[a];
-    const float u = ext > 0.f ? (p[(size_t)a * N + j] - bb[a]) / ext : 0.f;   // ordering only: any rounding will do
-    const float s = u * 1023.0f;
-    q[a] = (uint32_t)(s < 0.f ? 0.f : (s > 1023.f ? 1023.f : s));
-  }
-  const uint32_t m = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
-  key[(size_t)b * N + j] = ((uint64_t)b << 30) | m;
-  val[(size_t)b * N + j] = j;
-}
-
-// Bounding box of every 64-point group of the sorted order: one wave per group.
-__global__ __launch_bounds__(256) void fps_group_box_kernel(const float* __restrict__ xyz,
-                                                            const int* __restrict__ perm, int N,
-                                                            int G, float* __restrict__ gbox) {
-  const int b = blockIdx.y;
-  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (g >= G) return;
-  const float* p = xyz + (size_t)b * 3 * N;
-  const int s = 64 * g + lane;
-  const bool ok = s < N;
-  const int j = ok ? perm[(size_t)b * N + s] : 0;
-  float* o = gbox + ((size_t)b * G + g) * 6;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const uint32_t v = f32_ordered(p[(size_t)a * N + j]);
-    const uint32_t lo = wave_min_u32(ok ? v : 0xFFFFFFFFu), hi = wave_max_u32(ok ? v : 0u);
-    if (lane == 0) {
-      o[a] = ordered_f32(lo);
-      o[3 + a] = ordered_f32(hi);
-    }
-  }
-}
 
 // The whole pre-pass of the pruned kernels as ONE launch, one workgroup per scene: bounding box,
 // a 15-bit cell key per point, a counting sort by cell in LDS, the permutation, the box of every
@@ -1284,7 +1203,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
   float x[PPT], y[PPT], z[PPT], md[PPT];
   float blx[GPL], bly[GPL], blz[GPL], bhx[GPL], bhy[GPL], bhz[GPL];   // boxes of this lane's groups
   float mg[GPL];                                                      // their max min-distances
-  constexpr int G = WAVES * PPT;           // groups of this scene (fps_group_box_kernel's G)
+  constexpr int G = WAVES * PPT;           // groups of this scene (the pre-pass's G)
 #pragma unroll
   for (int r = 0; r < GPL; ++r) {
     const int slot = 64 * r + lane;          // group slot of this lane: group WAVES * slot + wave
@@ -1531,16 +1450,6 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
 // the min-distances start at +inf, so the first steps touch every group (13 blocks of loads per
 // step) and the count decays within a few dozen steps.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fps_sorted_aos_kernel(const float* __restrict__ xyz,
-                                                             const int* __restrict__ perm, int N, int cap,
-                                                             float4* __restrict__ out) {
-  const int b = blockIdx.y;
-  const int s = blockIdx.x * 256 + threadIdx.x;
-  if (s >= cap) return;
-  const float* p = xyz + (size_t)b * 3 * N;
-  const int j = s < N ? perm[(size_t)b * N + s] : 0;
-  out[(size_t)b * cap + s] = make_float4(p[j], p[(size_t)N + j], p[2 * (size_t)N + j], __int_as_float(j));
-}
 
 template <int THREADS, int PPT, bool FMAD, typename IdxT, int MAXP>
 __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __restrict__ xyz,
@@ -1731,23 +1640,16 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
 constexpr int FPS_L2_CAP = 512 * 100;   // points per scene of fps_pruned_l2_kernel<512, 100>
 
 struct FpsSortWs {
-  float* bbox;
-  float* gbox;
-  float* md;
-  uint64_t *key_in, *key_out;
-  int *val_in, *val_out;
-  void* tmp;
-  float4* aos;      // Morton-sorted (x, y, z, index) records: fps_pruned_l2_kernel only (N > 25 600)
-  size_t tmp_bytes, total;
+  float* gbox;      // [B][G][6] boxes of the 64-point groups
+  float* md;        // [B][N] min-distances handed over by the full-scan kernel (S4G_FPS_DENSE_STEPS > 1)
+  int* val_out;     // [B][N] the pre-pass's permutation
+  float4* aos;      // cell-ordered (x, y, z, index) records: fps_pruned_l2_kernel only (N > 25 600)
+  size_t total;
 };
 
 static FpsSortWs fps_sort_ws(void* base, int64_t B, int64_t N) {
   FpsSortWs w;
   const size_t n = (size_t)B * (size_t)N;
-  size_t sort_bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr,
-                                  (int*)nullptr, (int*)nullptr, n);
-  w.tmp_bytes = sort_bytes;
   char* p = (char*)base;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -1755,17 +1657,12 @@ static FpsSortWs fps_sort_ws(void* base, int64_t B, int64_t N) {
     off += (bytes + 255) & ~(size_t)255;
     return r;
   };
-  w.bbox = (float*)take(sizeof(float) * 6 * B);
   // fps_pruned_l2_kernel's box pass always writes 8 * 100 groups per scene (fewer real groups for
   // 25 600 < N < 34 816): size for whichever is larger
   const int64_t gbox_groups = (N + 63) / 64 + 256 > 800 ? (N + 63) / 64 + 256 : 800;
   w.gbox = (float*)take(sizeof(float) * 6 * B * gbox_groups);
   w.md = (float*)take(sizeof(float) * n);
-  w.key_in = (uint64_t*)take(sizeof(uint64_t) * n);
-  w.key_out = (uint64_t*)take(sizeof(uint64_t) * n);
-  w.val_in = (int*)take(sizeof(int) * n);
   w.val_out = (int*)take(sizeof(int) * n);
-  w.tmp = take(w.tmp_bytes);
   w.aos = N > (int64_t)512 * 50 ? (float4*)take(sizeof(float4) * (size_t)B * FPS_L2_CAP) : nullptr;
   w.total = off;
   return w;
@@ -1899,26 +1796,9 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
   int dense_steps = 0;
   if (const char* e = getenv("S4G_FPS_DENSE_STEPS")) dense_steps = atoi(e) > 1 ? atoi(e) : 0;
   if (dense_steps >= M) pruned = false;
-  // S4G_FPS_SORT=rocprim: round 2's pre-pass (bbox, 30-bit Morton keys, rocprim::radix_sort_pairs over
-  // the batch, group boxes: 22 launches) instead of the one-launch cell sort
-  static const bool one_launch_sort = [] { const char* e = getenv("S4G_FPS_SORT"); return !(e && e[0] == 'r'); }();
   if (pruned) {
-    if (one_launch_sort) {
-      const int G = 8 * (N <= 512 * 10 ? 10 : N <= 512 * 20 ? 20 : N <= 512 * 32 ? 32 : 50);   // groups of the pruned launch below
-      if (int rc = launch_fps_cell_sort(xyz, B, N, G, w.val_out, w.gbox, nullptr, 0, stream)) return rc;
-    } else {
-      hipLaunchKernelGGL(fps_bbox_kernel, dim3((unsigned)B), dim3(1024), 0, stream, xyz, (int)N, w.bbox);
-      S4G_LAUNCH_CHECK();
-      hipLaunchKernelGGL(fps_morton_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256),
-                         0, stream, xyz, (int)N, (int)B, w.bbox, w.key_in, w.val_in);
-      S4G_LAUNCH_CHECK();
-      int bits = 30;
-      while ((1ll << (bits - 30)) < B) ++bits;
-      size_t tb = w.tmp_bytes;
-      const hipError_t e = rocprim::radix_sort_pairs(w.tmp, tb, w.key_in, w.key_out, w.val_in,
-                                                     w.val_out, (size_t)B * (size_t)N, 0, bits, stream);
-      if (e != hipSuccess) return (int)e;
-    }
+    const int G = 8 * (N <= 512 * 10 ? 10 : N <= 512 * 20 ? 20 : N <= 512 * 32 ? 32 : 50);   // groups of the pruned launch below
+    if (int rc = launch_fps_cell_sort(xyz, B, N, G, w.val_out, w.gbox, nullptr, 0, stream)) return rc;
     m_run = dense_steps;
     md_out = w.md;
   }
@@ -1959,12 +1839,6 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
 #define S4G_FPS_PRUNED(T, P)                                                                       \
   if (N <= (int64_t)T * P) {                                                                       \
     const size_t lds = sizeof(uint16_t) * T * P;                                                   \
-    constexpr int G = (T / 64) * P;                                                                \
-    if (!one_launch_sort) {                                                                        \
-      hipLaunchKernelGGL(fps_group_box_kernel, dim3((G + 3) / 4, (unsigned)B), dim3(256), 0, stream, \
-                         xyz, w.val_out, (int)N, G, w.gbox);                                       \
-      S4G_LAUNCH_CHECK();                                                                          \
-    }                                                                                              \
     if (spec == 4) S4G_FPS_PRUNED_LAUNCH(T, P, 4) else if (spec == 2) S4G_FPS_PRUNED_LAUNCH(T, P, 2) else S4G_FPS_PRUNED_LAUNCH(T, P, 1) \
     S4G_LAUNCH_CHECK();                                                                            \
     return S4G_OK;                                                                                 \
@@ -1981,27 +1855,7 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
     const FpsSortWs w2 = fps_sort_ws(ws, B, N);
     if (ws && ws_bytes >= w2.total) {
       constexpr int G = 8 * 100;
-      if (one_launch_sort) {
-        if (int rc = launch_fps_cell_sort(xyz, B, N, G, w2.val_out, w2.gbox, w2.aos, FPS_L2_CAP, stream)) return rc;
-      } else {
-        hipLaunchKernelGGL(fps_bbox_kernel, dim3((unsigned)B), dim3(1024), 0, stream, xyz, (int)N, w2.bbox);
-        S4G_LAUNCH_CHECK();
-        hipLaunchKernelGGL(fps_morton_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0,
-                           stream, xyz, (int)N, (int)B, w2.bbox, w2.key_in, w2.val_in);
-        S4G_LAUNCH_CHECK();
-        int bits = 30;
-        while ((1ll << (bits - 30)) < B) ++bits;
-        size_t tb = w2.tmp_bytes;
-        const hipError_t e = rocprim::radix_sort_pairs(w2.tmp, tb, w2.key_in, w2.key_out, w2.val_in,
-                                                       w2.val_out, (size_t)B * (size_t)N, 0, bits, stream);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(fps_group_box_kernel, dim3((G + 3) / 4, (unsigned)B), dim3(256), 0, stream, xyz,
-                           w2.val_out, (int)N, G, w2.gbox);
-        S4G_LAUNCH_CHECK();
-        hipLaunchKernelGGL(fps_sorted_aos_kernel, dim3((FPS_L2_CAP + 255) / 256, (unsigned)B), dim3(256), 0,
-                           stream, xyz, w2.val_out, (int)N, FPS_L2_CAP, w2.aos);
-        S4G_LAUNCH_CHECK();
-      }
+      if (int rc = launch_fps_cell_sort(xyz, B, N, G, w2.val_out, w2.gbox, w2.aos, FPS_L2_CAP, stream)) return rc;
       hipLaunchKernelGGL((fps_pruned_l2_kernel<512, 100, FMAD, IdxT, 2>), grid, dim3(512), 0, stream, xyz,
                          w2.aos, w2.gbox, (int)N, (int)M, idx, ctr, lg, ex.dist);
       S4G_LAUNCH_CHECK();
