@@ -139,7 +139,7 @@ __device__ __forceinline__ void fps_block_exchange(FpsSlot* slots, int wave,
 // commute, so all picks of an exchange are applied together before the next candidates are taken.
 // Everything is wave-uniform and every wave decides alike.  Returns the number of picks (>= 1).
 template <int WAVES, bool FMAD, int MAXP, typename IdxT>
-__device__ __forceinline__ int fps_block_exchange_multi(FpsSlot* slots, int wave, int lane, uint32_t wmax,
+__device__ __forceinline__ int fps_block_exchange_multi_v(FpsSlot* slots, int wave, int lane, uint32_t wmax,
                                                         uint32_t wtie, uint32_t wd2, float sx, float sy,
                                                         float sz, int limit, int& cur, float& cx, float& cy,
                                                         float& cz, uint32_t& picked_waves,
@@ -223,6 +223,114 @@ __device__ __forceinline__ int fps_block_exchange_multi(FpsSlot* slots, int wave
   }
   picked_waves = pw;
   return np;
+}
+
+// The same decisions with a third of the instructions.  A wave issues at most one instruction per
+// four cycles and everything here is one dependent chain, so the exchange costs its instruction
+// COUNT (the form above: ~100 per pick, ~900 cycles; a version on the scalar unit with ~250 cheap
+// instructions per pick measured 8.1 instead of 4.8 ms).  What went: the pick-to-candidate distances
+// of ALL 8 x 8 pairs are one dist2 over 64 lanes before the first round (lane 8 i + j: entry i as the
+// pick, entry j as the candidate) and a round fetches its row with one ds_bpermute; the picks'
+// coordinates and indices are not carried through the rounds at all -- lane k of wave 0 re-reads
+// pick k's entry from the exchange buffer once at the end, the callers' centroid comes from three
+// readlanes after the loop; reductions run over the 8 distinct lanes (three DPP steps).
+template <int WAVES, bool FMAD, int MAXP, typename IdxT>
+__device__ __forceinline__ int fps_block_exchange_multi(FpsSlot* slots, int wave, int lane, uint32_t wmax,
+                                                        uint32_t wtie, uint32_t wd2, float sx, float sy,
+                                                        float sz, int limit, int& cur, float& cx, float& cy,
+                                                        float& cz, uint32_t& picked_waves,
+                                                        IdxT* __restrict__ out_i, float* __restrict__ cout_i,
+                                                        int M, float& fx, float& fy, float& fz,
+                                                        float* __restrict__ dout_i = nullptr) {
+#ifdef S4G_FPS_XCHG_OLD
+  return fps_block_exchange_multi_v<WAVES, FMAD, MAXP, IdxT>(slots, wave, lane, wmax, wtie, wd2, sx, sy, sz, limit,
+                                                             cur, cx, cy, cz, picked_waves, out_i, cout_i, M, fx,
+                                                             fy, fz, dout_i);
+#else
+  static_assert(WAVES == 8, "eight entries: the pick x candidate matrix is the wave's 64 lanes");
+  if (lane == 0) {
+    FpsSlot s;
+    s.d = wmax;
+    s.tie = wtie;
+    s.x = sx;
+    s.y = sy;
+    s.z = sz;
+    s.d2 = wd2;
+    s.pad[0] = s.pad[1] = 0;
+    slots[wave] = s;
+  }
+  __syncthreads();
+  const int ej = lane & 7;
+  const FpsSlot s = slots[ej];                   // candidate j = lane % 8 (every row of 8 lanes holds all eight)
+  const FpsSlot sp = slots[lane >> 3];           // pick i = lane / 8
+  // dist2(pick, candidate): the update's own arithmetic and argument order
+  const uint32_t dm = __float_as_uint(dist2<FMAD>(sp.x, sp.y, sp.z, s.x, s.y, s.z));
+  auto max8 = [](uint32_t x) {                   // max over the 8 lanes of a row half (all of them end up with it)
+    x = max(x, dpp_u32<0xB1>(x));
+    x = max(x, dpp_u32<0x4E>(x));
+    x = max(x, dpp_u32<0x141>(x));
+    return x;
+  };
+  uint32_t v = s.d;          // this entry's current min-distance bits (0: picked / nothing left)
+  uint32_t bnd = 0u;         // largest runner-up distance of the disturbed waves
+  int np = 0, xl = 0, xl0 = 0;
+  uint32_t pw = 0u;          // picked entries (= wave numbers), 4 bits each
+  uint32_t my_d = 0u;
+  const bool upper = (lane & 8) != 0;   // lanes 8..15 of a row reduce the runner-ups while lanes 0..7 reduce v
+  uint32_t bmax = max8(v);
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    if (k >= limit) break;
+    if (k > 0) {
+      const uint32_t bmax_s = __builtin_amdgcn_readfirstlane(bmax);
+      if (bmax_s == 0u || bmax_s <= bnd) break;
+    }
+    uint32_t win = (uint32_t)__ballot(v == bmax) & 0xFFu;
+    if (win & (win - 1u)) {   // equal distances: the smaller key (sampling_kernel.cu's tie rule)
+      uint32_t cand = (v == bmax) ? s.tie : 0xFFFFFFFFu;
+      cand = min(cand, dpp_u32<0xB1>(cand));
+      cand = min(cand, dpp_u32<0x4E>(cand));
+      cand = min(cand, dpp_u32<0x141>(cand));
+      win = (uint32_t)__ballot(v == bmax && s.tie == cand) & 0xFFu;
+    }
+    xl = __ffs(win) - 1;
+    if (k == 0) xl0 = xl;
+    pw |= (uint32_t)xl << (4 * k);
+    np = k + 1;
+    my_d = lane == k ? bmax : my_d;   // the pick's min-distance at the time it is taken
+    if (k + 1 < MAXP) {
+      // the picked wave is disturbed; the other candidates' values after this pick, exactly
+      const uint32_t nd = (uint32_t)__builtin_amdgcn_ds_bpermute((xl * 8 + ej) * 4, (int)dm);
+      const bool me = ej == xl;
+      const bool hit = me || nd < v;             // (v == 0: nothing is below it)
+      v = me ? 0u : min(v, nd);
+      // ONE reduction for both maxima: the next round's bmax in lanes 0..7, the runner-ups in 8..15
+      const uint32_t red = max8(upper ? (hit ? s.d2 : 0u) : v);
+      bnd = max(bnd, (uint32_t)__builtin_amdgcn_readlane(red, 8));
+      bmax = red;   // (valid in lanes 0..7 of every row: the only lanes the ballots and lane k look at)
+    }
+  }
+  // the callers' running centroid = the last pick (and the first one for the MAXP == 2 kernels)
+  cur = (int)((uint32_t)__builtin_amdgcn_readlane(s.tie, xl) & FPS_JMASK);
+  cx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.x), xl));
+  cy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.y), xl));
+  cz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.z), xl));
+  fx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.x), xl0));
+  fy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.y), xl0));
+  fz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.z), xl0));
+  if (wave == 0 && lane < np) {   // lane k stores pick k: ONE store per output array
+    const FpsSlot e = slots[(pw >> (4 * lane)) & 15u];
+    out_i[lane] = (IdxT)(e.tie & FPS_JMASK);
+    if (cout_i) {
+      cout_i[lane] = e.x;
+      cout_i[M + lane] = e.y;
+      cout_i[2 * M + lane] = e.z;
+    }
+    if (dout_i) dout_i[lane] = __uint_as_float(my_d);
+  }
+  picked_waves = pw;
+  return np;
+#endif
 }
 
 // Read (x[pw], y[pw], z[pw]) of lane `wl` into wave-uniform values.  `pw` is
