@@ -1219,6 +1219,13 @@ __global__ __launch_bounds__(FPS_SORT_THREADS) void fps_cell_sort_kernel(
   }
 }
 
+// max(a, b, c) as ONE instruction; NaN operands lose (the boxes of empty groups are NaN)
+__device__ __forceinline__ float fps_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // md[pw] of every lane for a wave-uniform slot pw (static register index per leaf)
 template <int PPT, int LO, int HI>
 __device__ __forceinline__ float fps_pick_md(const float (&md)[PPT], int pw) {
@@ -1409,9 +1416,11 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
 #pragma unroll
     for (int r = 0; r < GPL; ++r) {
       const bool live = 64 * r + lane < PPT;
-      const float tx = ux < blx[r] ? __fsub_rn(blx[r], ux) : (ux > bhx[r] ? __fsub_rn(bhx[r], ux) : 0.f);
-      const float ty = uy < bly[r] ? __fsub_rn(bly[r], uy) : (uy > bhy[r] ? __fsub_rn(bhy[r], uy) : 0.f);
-      const float tz = uz < blz[r] ? __fsub_rn(blz[r], uz) : (uz > bhz[r] ? __fsub_rn(bhz[r], uz) : 0.f);
+      // per axis max(lo - u, u - hi, 0): the distance to the box, one v_max3 instead of two compares + two
+      // selects (u - hi where the select form had hi - u: the square is the same bit for bit)
+      const float tx = fps_max3(__fsub_rn(blx[r], ux), __fsub_rn(ux, bhx[r]), 0.f);
+      const float ty = fps_max3(__fsub_rn(bly[r], uy), __fsub_rn(uy, bhy[r]), 0.f);
+      const float tz = fps_max3(__fsub_rn(blz[r], uz), __fsub_rn(uz, bhz[r]), 0.f);
       float lb;
       if constexpr (FMAD) {
         lb = __fmaf_rn(tz, tz, __fmaf_rn(ty, ty, __fmul_rn(tx, tx)));
@@ -1635,9 +1644,11 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
 #pragma unroll
       for (int r = 0; r < GPL; ++r) {
         const bool live = 64 * r + lane < PPT;
-        const float tx = ux < blx[r] ? __fsub_rn(blx[r], ux) : (ux > bhx[r] ? __fsub_rn(bhx[r], ux) : 0.f);
-        const float ty = uy < bly[r] ? __fsub_rn(bly[r], uy) : (uy > bhy[r] ? __fsub_rn(bhy[r], uy) : 0.f);
-        const float tz = uz < blz[r] ? __fsub_rn(blz[r], uz) : (uz > bhz[r] ? __fsub_rn(bhz[r], uz) : 0.f);
+        // per axis max(lo - u, u - hi, 0): the distance to the box, one v_max3 instead of two compares + two
+        // selects (u - hi where the select form had hi - u: the square is the same bit for bit)
+        const float tx = fps_max3(__fsub_rn(blx[r], ux), __fsub_rn(ux, bhx[r]), 0.f);
+        const float ty = fps_max3(__fsub_rn(bly[r], uy), __fsub_rn(uy, bhy[r]), 0.f);
+        const float tz = fps_max3(__fsub_rn(blz[r], uz), __fsub_rn(uz, bhz[r]), 0.f);
         float lb;
         if constexpr (FMAD) {
           lb = __fmaf_rn(tz, tz, __fmaf_rn(ty, ty, __fmul_rn(tx, tx)));
