@@ -1482,7 +1482,9 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
         if constexpr (SPEC) nbest += __popcll(gmask);
         while (gmask) {                          // one group unless maxima tie across groups
           const int gl = __ffsll((unsigned long long)gmask) - 1;
-          const int pw = 64 * r + gl;
+          // (readfirstlane: the slot number IS wave-uniform, but only a value the compiler knows to be
+          // uniform turns the walk to the slot into scalar compares instead of 64-bit vector compares)
+          const int pw = __builtin_amdgcn_readfirstlane(64 * r + gl);
           gmask &= gmask - 1;
           const int s = 64 * (WAVES * pw + wave) + lane;
           // every lane reads its original index early (the LDS read overlaps the tree walk)
@@ -1710,7 +1712,9 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
         nbest += __popcll(gmask);
         while (gmask) {
           const int gl = __ffsll((unsigned long long)gmask) - 1;
-          const int pw = 64 * r + gl;
+          // (readfirstlane: the slot number IS wave-uniform, but only a value the compiler knows to be
+          // uniform turns the walk to the slot into scalar compares instead of 64-bit vector compares)
+          const int pw = __builtin_amdgcn_readfirstlane(64 * r + gl);
           gmask &= gmask - 1;
           const int s = 64 * (WAVES * pw + wave) + lane;
           const float4 me = record(pw);                         // this lane's point of the group (zeros past the end)
