@@ -31,7 +31,12 @@ Extra objects on the line:
   kernels       every native launch: mean ms, algorithmic bytes / flops, GB/s / TFLOP/s
   configs4      BASELINE.json configs[4] (bf16 path, 32 x 51 200-point clouds): scenes/s, ms/step and
                 its own MFMA roofline object, 5 warm + 10 timed steps after the headline region
+  modules_path  the reference-shaped modules over the HIP operators on the same scenes (what swapping
+                only the extension buys), scenes/s
+  precision_legs  the fast path in true-fp32 MFMA and exact 3 x bf16 arithmetic on the same batch
+  mixed_batch   2 of the 16 scenes tie-heavy: the conditional level-2 / level-3 FPS samplers run timed
   collective    the per-batch all-gather: payload (--gather heads | poses), bytes, the stream it ran on
+  distributed   world, communicator size, every rank's scene range and device (self-verifying)
   cpu_baseline  the CPU oracle forward (oracle/pn2_forward.py) on ONE scene,
                 rank 0 at N == 1 only -- a reported baseline, not the target
 """
@@ -303,6 +308,8 @@ def main():
             decode = lambda pred, xyz: PP.decode_top_poses(pred, xyz, args.num_poses, "detector")
         gather = sdist.OutputGather(args.gather, decode=decode, device=dev)
 
+    solo = [False]    # set once the other ranks have left: nothing after that may enter a collective
+
     def run_steps(n, run=None, data=None, pipe=None, marks=None, gathered=True):
         """n forward passes over the batch.  Pipelined mode keeps up to `--in-flight`
         batches submitted besides the one being collected: batch i+1's FPS chain
@@ -313,6 +320,7 @@ def main():
         run = runner if run is None else run
         data = batch if data is None else data
         pipe = pipelined if pipe is None else pipe
+        assert not (solo[0] and gathered and gather is not None), "all-gather inside a rank-0-only leg"
         fin = (lambda pred: gather(pred, data["scene_points"])) if (gathered and gather is not None) \
             else (lambda pred: pred)
 
@@ -339,17 +347,23 @@ def main():
                 fin(pending.pop(0).result())
                 mark()
 
-    def fence():
+    def _fence(collective=True):
+        """collective=False: the rank-0-only probes after the headline region -- the other ranks have left,
+        a barrier there would wait for peers that never come."""
         torch.cuda.synchronize()
-        if use_dist:
+        if use_dist and collective:
+            assert not solo[0], "collective fence inside a rank-0-only leg"
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed_region(steps, warmup, **kw):
+    def timed_region(steps, warmup, collective=True, timers=True, **kw):
         """`warmup` untimed + EXACTLY `steps` timed passes between fences -> (seconds, step_ms, summary,
-        passes whose launches carried event pairs)."""
+        passes whose launches carried event pairs).  collective=False (rank-0-only legs): the fences only
+        synchronise the device and nothing in the region may enter a collective."""
+        assert collective or kw.get("gathered") is False
+        fence = lambda: _fence(collective)
         run_steps(warmup, **kw)
-        F.OpTimer.reset(enabled=True, every=args.timer_every)
+        F.OpTimer.reset(enabled=timers, every=args.timer_every)
         fence()
         marks = []
         ev0 = torch.cuda.Event(enable_timing=True)
@@ -369,6 +383,10 @@ def main():
         timed_passes = (steps + args.timer_every - 1) // args.timer_every
         return elapsed, step_ms, F.OpTimer.summary(), timed_passes
 
+    # who runs what (one all_gather_object, outside the timed region): world, communicator size as the
+    # collective library reports it, every rank's scene range and device -- checked to tile the global batch
+    shards = sdist.shard_report(scene_ids, world * B, torch.cuda.get_device_name(dev) + " cuda:%d" % local_rank)
+
     elapsed, step_ms, summary, timed_passes = timed_region(args.steps, args.warmup)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -379,6 +397,7 @@ def main():
         if use_dist:
             dist.destroy_process_group()
         return
+    solo[0] = True
 
     scenes = world * B * args.steps
     value = scenes / elapsed
@@ -386,7 +405,7 @@ def main():
     roofline_dense, kernels = dense_roofline(summary, timed_passes, precision)
 
     N, M, K = args.points, cfg.num_centroids[0], cfg.num_neighbours[0]
-    roofline = latency = io = configs4 = None
+    roofline = latency = io = configs4 = modules_path = precision_legs = mixed_batch = None
     if not args.no_extras:
         # ---- one batch alone / one scene: the figures the pipeline hides
         def timed_forward(data, reps):
@@ -476,8 +495,8 @@ def main():
             c4_pts = torch.from_numpy(synth.make_batch(list(range(32)), 51200, variant=args.variant)).to(dev)
             c4_batch = {"scene_points": c4_pts}
             c4_steps, c4_warm = 10, 5
-            c4_el, c4_step, c4_sum, c4_tp = timed_region(c4_steps, c4_warm, run=c4_runner, data=c4_batch,
-                                                         gathered=False)
+            c4_el, c4_step, c4_sum, c4_tp = timed_region(c4_steps, c4_warm, collective=False, run=c4_runner,
+                                                         data=c4_batch, gathered=False)
             c4_roof, _ = dense_roofline(c4_sum, c4_tp, "bf16")
             tb, src, why = load_traffic("contractions[step,B=32,N=51200,precision=bf16]")
             c4_roof["traffic"] = tb
@@ -489,6 +508,54 @@ def main():
                         "ms_per_step": round(1e3 * c4_el / c4_steps, 3), "steps": c4_steps, "warmup": c4_warm,
                         "step_ms_median": c4_step["median"], "roofline": c4_roof}
             del c4_runner, c4_pts, c4_batch
+
+        # ---- what a maintainer who swaps ONLY the extension gets (INTEGRATION.md levels 1-2): the
+        # reference-shaped modules (modules.py / nn_utils.py: torch conv + BN + ReLU over materialised
+        # (B, C, M, K) tensors) on the HIP operators, same 16 scenes, one batch at a time
+        if impl == "fused":
+            m_steps, m_warm = 5, 2
+            m_el, m_step, _, _ = timed_region(m_steps, m_warm, collective=False, timers=False, run=net,
+                                              data=batch, pipe=False, gathered=False)
+            modules_path = {"workload": "reference-shaped modules (QueryGrouper / PointNetSAModule / "
+                                        "PointnetFPModule + torch conv-BN-ReLU) over the HIP operator API, "
+                                        "same %d scenes, fp32 library convolutions, one batch at a time" % B,
+                            "value": round(B * m_steps / m_el, 2), "unit": "scenes/sec",
+                            "ms_per_step": round(1e3 * m_el / m_steps, 3), "steps": m_steps, "warmup": m_warm}
+            # ---- the other arithmetic modes of the fast path on the same batch: true fp32 MFMA
+            # (v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fma chain) and the exact 3 x bf16 split
+            precision_legs = {}
+            for prec in ("fp32", "bf16x3"):
+                if prec == precision:
+                    continue
+                p_runner = fused_cls(net, precision=prec)
+                p_steps, p_warm = 6, 3
+                p_el, p_step, p_sum, p_tp = timed_region(p_steps, p_warm, collective=False, run=p_runner,
+                                                         data=batch, gathered=False)
+                p_roof, _ = dense_roofline(p_sum, p_tp, prec)
+                precision_legs[prec] = {"value": round(B * p_steps / p_el, 2), "unit": "scenes/sec",
+                                        "ms_per_step": round(1e3 * p_el / p_steps, 3), "steps": p_steps,
+                                        "warmup": p_warm, "roofline_frac": p_roof["frac"] if p_roof else None,
+                                        "roofline_peak_TFLOPs": p_roof["peak"] if p_roof else None}
+                del p_runner
+            # ---- a batch that is NOT all "proven": 2 of the 16 scenes are `dup-heavy` clouds (exact
+            # distance ties), so the FPS prefix check refuses them and the level-2 / level-3 samplers
+            # run inside the timed region (the headline's tabletop scenes all pass the check)
+            n_tie = min(2, B)
+            mix = synth.make_batch(scene_ids, args.points, variant=args.variant)
+            mix[:n_tie] = synth.make_batch(scene_ids[:n_tie], args.points, variant="dup-heavy")
+            mix_batch = {"scene_points": torch.from_numpy(mix).to(dev)}
+            x_steps, x_warm = 10, 3
+            x_el, x_step, x_sum, _ = timed_region(x_steps, x_warm, collective=False, run=runner, data=mix_batch,
+                                                  gathered=False)
+            lv = [k for k in x_sum if k.startswith("fps[") and not k.startswith("fps[N=%d," % args.points)]
+            mixed_batch = {"workload": "%d `dup-heavy` + %d `%s` scenes per step: the tie-heavy scenes fail the FPS "
+                                       "prefix proof, their level-2 / level-3 samplers run in the timed region"
+                                       % (n_tie, B - n_tie, args.variant),
+                           "value": round(B * x_steps / x_el, 2), "unit": "scenes/sec",
+                           "ms_per_step": round(1e3 * x_el / x_steps, 3), "step_ms_median": x_step["median"],
+                           "steps": x_steps, "warmup": x_warm,
+                           "deeper_fps_launches_ms": {k: round(x_sum[k][1], 4) for k in sorted(lv)}}
+            del mix_batch
 
     tb, src, why = load_traffic("contractions[step,B=%d,N=%d,precision=%s]" % (B, N, precision))
     if roofline_dense is None:
@@ -557,7 +624,8 @@ def main():
         "value": round(value, 3), "unit": "scenes/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if precision == "bf16" else "f32", "data": "synthetic",
+        "dtype": {"bf16": "bf16", "f16x2": "f32 (f16x2 split)", "bf16x3": "f32 (bf16x3 split)"}.get(precision, "f32"),
+        "data": "synthetic",
         "config": {"workload": "S4G PN2_CLS forward (3 SA + 3 FP + 4 heads), %d scenes/GPU/step, "
                                "%d-pt %s clouds, %s, impl=%s%s" % (B, args.points, args.variant, arith,
                                                                    impl, pipe_label),
@@ -569,7 +637,8 @@ def main():
         # `roofline`: the dominant kernel of the step (the MFMA contraction, >90 % of GPU time);
         # `roofline_ball_query_group_points`: the HBM-bound operator pair the north star names.
         "roofline": roofline_dense, "roofline_ball_query_group_points": roofline,
-        "configs4": configs4, "collective": collective,
+        "configs4": configs4, "modules_path": modules_path, "precision_legs": precision_legs,
+        "mixed_batch": mixed_batch, "collective": collective, "distributed": shards,
         "step_ms": step_ms, "latency": latency, "io": io, "kernels": kernels,
         "cpu_baseline": cpu_baseline,
     }

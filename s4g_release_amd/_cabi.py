@@ -131,6 +131,12 @@ def lib():
     # torch first so the kernels and torch's allocator/streams share ONE runtime
     # (loading ours first gives "no ROCm-capable device" on the first launch).
     import torch  # noqa: F401
+    if os.environ.get("S4G_HIP_LIB"):
+        # a measurement build (possibly with parts compiled out) is about to serve every operator of
+        # this process: say so, loudly -- a leftover variable must never go unnoticed
+        import warnings
+        warnings.warn("S4G_HIP_LIB overrides the shipped library: loading %s" % LIB_PATH, RuntimeWarning,
+                      stacklevel=2)
     L = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:

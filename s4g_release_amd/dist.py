@@ -157,3 +157,35 @@ def scenes_per_rank(global_batch, world):
     if global_batch % world != 0:
         raise ValueError("batch of %d scenes does not divide over %d ranks" % (global_batch, world))
     return global_batch // world
+
+
+def shard_report(scene_ids, global_batch, device_name="", group=None):
+    """What the first real multi-GPU run needs to verify itself (BASELINE.json configs[3]: 128 scenes
+    over 8 ranks): every rank contributes (rank, its scene ids, its device) through ONE
+    `all_gather_object`; every rank gets the world's table back in rank order together with the
+    communicator size the collective library reports, after checking that the ranks' scene ranges
+    tile [0, global_batch) exactly once.  A single process returns its own row without a collective."""
+    mine = {"rank": dist.get_rank(group) if dist.is_initialized() else 0,
+            "scenes": [int(scene_ids[0]), int(scene_ids[-1]) + 1] if len(scene_ids) else [0, 0],
+            "n_scenes": len(scene_ids), "device": device_name}
+    if list(scene_ids) != list(range(mine["scenes"][0], mine["scenes"][1])):
+        raise ValueError("a rank's scenes must be one contiguous block")
+    if dist.is_initialized():
+        comm = dist.get_world_size(group)
+        rows = [None] * comm
+        dist.all_gather_object(rows, mine, group=group)
+        backend = dist.get_backend(group)
+    else:
+        comm, rows, backend = 1, [mine], None
+    rows = sorted(rows, key=lambda r: r["rank"])
+    if [r["rank"] for r in rows] != list(range(comm)):
+        raise RuntimeError("shard_report: ranks %s of a communicator of %d" % ([r["rank"] for r in rows], comm))
+    edge = 0
+    for r in rows:
+        if r["scenes"][0] != edge:
+            raise RuntimeError("shard_report: rank %d starts at scene %d, expected %d" % (r["rank"], r["scenes"][0], edge))
+        edge = r["scenes"][1]
+    if edge != global_batch:
+        raise RuntimeError("shard_report: the ranks cover %d scenes of a global batch of %d" % (edge, global_batch))
+    return {"world": comm, "communicator_size": comm, "backend": backend, "global_batch": int(global_batch),
+            "per_rank": rows}

@@ -22,7 +22,7 @@ def test_bench_prints_one_contract_line():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
     assert d["unit"] == "scenes/sec" and d["higher_is_better"] is True and d["scaling"] == "weak"
-    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32 (f16x2 split)"
     assert "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 16 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
     r = d["roofline"]
@@ -48,6 +48,16 @@ def test_bench_prints_one_contract_line():
     assert "51 200" in c4["workload"] and c4["roofline"]["bound"] == "mfma" and 0 < c4["roofline"]["frac"] < 1
     assert c4["roofline"]["mfma_products_per_mac"] == 1
     assert d["collective"]["op"] is None
+    # what swapping only the extension buys, the other arithmetic modes, a batch with tie-heavy scenes
+    m = d["modules_path"]
+    assert m["unit"] == "scenes/sec" and 0 < m["value"] < d["value"]
+    legs = d["precision_legs"]
+    assert set(legs) == {"fp32", "bf16x3"} and all(0 < v["value"] < d["value"] * 1.05 for v in legs.values())
+    assert legs["fp32"]["roofline_peak_TFLOPs"] == 157.3
+    x = d["mixed_batch"]
+    assert x["value"] > 0 and any(v > 0 for v in x["deeper_fps_launches_ms"].values())
+    sh = d["distributed"]
+    assert sh["world"] == 1 and sh["communicator_size"] == 1 and sh["per_rank"][0]["scenes"] == [0, 16]
 
 
 def test_bench_under_torchrun_takes_the_rccl_path():
@@ -67,6 +77,9 @@ def test_bench_under_torchrun_takes_the_rccl_path():
     c = d["collective"]
     assert c["payload"] == "heads" and c["payload_bytes_per_rank_per_step"] == 16 * 21 * 25600 * 4
     assert c["stream"].startswith("side stream")
+    sh = d["distributed"]     # the self-verifying shard table went through the communicator
+    assert sh["backend"] == "nccl" and sh["communicator_size"] == 1 and sh["per_rank"][0]["scenes"] == [0, 16]
+    assert d["configs4"]["value"] > 0 and d["mixed_batch"]["value"] > 0     # rank-0-only legs: no collective inside
 
 
 def test_bench_gather_poses_over_rccl():

@@ -128,6 +128,43 @@ def test_output_gather_modes_gloo_world2(mode):
         assert where == "caller"
 
 
+def _configs3_worker(rank, world, port, global_batch, q):
+    """BASELINE.json configs[3] in miniature: `--global-batch 128` over 8 ranks, bench.py's own scene
+    assignment (rank g runs scenes [g B, (g + 1) B)), the self-verifying shard table, one all-gather."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sdist.init_from_env(backend="gloo")
+    B = sdist.scenes_per_rank(global_batch, world)
+    scene_ids = [rank * B + i for i in range(B)]          # bench.py: scene_ids
+    rep = sdist.shard_report(scene_ids, global_batch, device_name="cpu:%d" % rank)
+    g = torch.Generator().manual_seed(3)
+    pts = torch.randn(global_batch, 3, 8, generator=g)
+    out = sdist.OutputGather("heads", device=pts.device)(_fake_runner({"scene_points": pts[scene_ids]}), None)
+    ref = _fake_runner({"scene_points": pts})
+    ok = all(torch.equal(out[k], ref[k]) for k in sdist.HEADS)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok, rep))
+
+
+def test_configs3_global_batch_128_over_8_ranks_gloo():
+    for rank, ok, rep in _run_world(_configs3_worker, 8, 128):
+        assert ok, rank
+        assert rep["world"] == 8 and rep["communicator_size"] == 8 and rep["backend"] == "gloo"
+        assert rep["global_batch"] == 128
+        assert [r["scenes"] for r in rep["per_rank"]] == [[16 * g, 16 * g + 16] for g in range(8)]
+        assert [r["device"] for r in rep["per_rank"]] == ["cpu:%d" % g for g in range(8)]
+
+
+def test_shard_report_single_process_and_bad_ranges():
+    rep = sdist.shard_report(list(range(16)), 16, "cuda:0")
+    assert rep["world"] == 1 and rep["per_rank"][0]["scenes"] == [0, 16] and rep["backend"] is None
+    with pytest.raises(RuntimeError):
+        sdist.shard_report(list(range(16)), 32)            # the ranks do not cover the global batch
+    with pytest.raises(ValueError):
+        sdist.shard_report([0, 2, 3], 3)                   # not one contiguous block
+
+
 def test_output_gather_argument_errors():
     with pytest.raises(ValueError):
         sdist.OutputGather("poses")              # no decode function

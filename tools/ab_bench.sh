@@ -4,8 +4,10 @@ alt=$1; shift
 mkdir -p gpurun_out/ab
 for round in 1 2 3; do
   for v in base alt; do
-    if [ $v = alt ]; then export S4G_HIP_LIB=$alt; else unset S4G_HIP_LIB; fi
-    python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras "$@" 2>/dev/null | tail -1 | python -c "
+    # the override is scoped to the one command (never exported: a leftover S4G_HIP_LIB would redirect
+    # every later load of the library in this shell)
+    if [ $v = alt ]; then lib=$alt; else lib=; fi
+    S4G_HIP_LIB=$lib python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras "$@" 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 k=d['kernels']
