@@ -43,8 +43,10 @@ extern "C" {
  * 4: per-scene activation maxima (rows_per_scene), bf16 chains, s4g_heads_chain_f32.
  * 5: s4g_group_rel_xyz_i32 and the rel_xyz4 field of s4g_gemm_desc_t.
  * 6: pre_* members of s4g_heads_desc_t (the last FP level's tail in front of the heads).
- * 7: s4g_fps_gather_ex_i32, s4g_fps_prefix_check_f32, s4g_fps_prepass_f32 (no layout change). */
-#define S4G_ABI_VERSION 7
+ * 7: s4g_fps_gather_ex_i32, s4g_fps_prefix_check_f32, s4g_fps_prepass_f32 (no layout change).
+ * 8: s4g_group_rel_xyz_unique_i32 and the seg4 / seg_rows fields of s4g_gemm_desc_t (the first SA level
+ *    contracts a centroid's distinct rows only). */
+#define S4G_ABI_VERSION 8
 
 #define S4G_OK 0
 #define S4G_EINVAL (-1)     /* bad size / null pointer */
@@ -316,6 +318,17 @@ typedef struct s4g_gemm_desc {
    * row instead of following gidx into the cloud (two dependent round trips at the head of every
    * workgroup); gidx / xyz / ctr are not read.  Same values, same results. */
   const float *rel_xyz4;
+  /* ABI >= 8, optional, both or neither; only S4G_GEMM_LOAD_GATHER_MLP1 + rel_xyz4 + a fused second
+   * layer (W2_f16x2_frag) + S4G_GEMM_EPI_MAX with K == 64 and relu2: the DISTINCT-row form.  rel_xyz4 then
+   * holds what s4g_group_rel_xyz_unique_i32 wrote -- per centroid only the rows ball_query did not pad
+   * (ball_query_kernel.cu:64-67 repeats the first hit; modules.py:243's max over the neighbours cannot
+   * see the copies) -- scene b's rows at b * rows_per_scene .. + seg_rows[b] (a multiple of 128, the
+   * tile height; rows_per_scene % 128 == 0), seg4[row / 4] the OUTPUT row (b M + m) of every group of
+   * four rows, -1 for filler.  `out` must be zero-filled by the caller: a centroid's pieces are merged
+   * with an unsigned atomicMax on the post-ReLU values.  Same maxima as the 64-row form; the hidden
+   * layer's per-tile power-of-two scales see other rows, so outputs agree to fp32 round-off, not bitwise. */
+  const int32_t *seg4;
+  const int32_t *seg_rows;
 } s4g_gemm_desc_t;
 
 int s4g_mlp_gemm_f32(const s4g_gemm_desc_t *desc, s4g_stream_t stream);
@@ -428,6 +441,22 @@ int s4g_query_group_f32(const float *xyz_b3n, const float *ctr_b3m, int64_t B,
 int s4g_group_rel_xyz_i32(const float *xyz_b3n, const float *ctr_b3m, const int32_t *idx_bmk,
                           int64_t B, int64_t N, int64_t M, int64_t K, float *rel_pk4,
                           s4g_stream_t stream);
+
+/* The same records without ball_query's padding copies (ABI >= 8; see s4g_gemm_desc_t.seg4).
+ * cnt_bm = ball_query's count output (int32).  Centroid m of scene b contributes
+ * c4 = round_up(max(cnt, 1), 4) rows (slots cnt .. c4-1 are copies of slot 0, so they are valid
+ * padding; an empty ball keeps its K copies of point 0 as 4 rows), centroids back to back from
+ * row b M K:
+ *   rel_pk4       (B M K, 4) capacity, rows as above; rows between a scene's last centroid and
+ *                 rows_b[b] are zero records
+ *   seg4          (B M K / 4) int32: b M + m per group of 4 rows, -1 for the filler rows
+ *   row_start_bm  (B, M) int32: first row of every centroid relative to its scene's base
+ *   rows_b        (B) int32: rows of scene b, rounded up to 128
+ * K % 4 == 0 and (M K) % 128 == 0, else S4G_EUNSUPPORTED. */
+int s4g_group_rel_xyz_unique_i32(const float *xyz_b3n, const float *ctr_b3m, const int32_t *idx_bmk,
+                                 const int32_t *cnt_bm, int64_t B, int64_t N, int64_t M, int64_t K,
+                                 float *rel_pk4, int32_t *seg4, int32_t *row_start_bm, int32_t *rows_b,
+                                 s4g_stream_t stream);
 
 /* FPS + centroid gather in one call: idx (B,M) int32 and ctr (B,3,M) planar. */
 int s4g_fps_gather_i32(const float *xyz_b3n, int64_t B, int64_t N, int64_t M,

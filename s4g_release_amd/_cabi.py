@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # declared symbol are checked either way
 LIB_PATH = os.environ.get("S4G_HIP_LIB") or os.path.join(_HERE, "libs4g_hip.so")
 
-S4G_ABI_VERSION = 7
+S4G_ABI_VERSION = 8
 S4G_EUNSUPPORTED = -3
 S4G_FLAG_FMAD = 1
 S4G_OP_FPS, S4G_OP_BALL_QUERY, S4G_OP_THREE_NN = 1, 2, 3
@@ -45,7 +45,7 @@ class GemmDesc(ctypes.Structure):
         ("a_amax_floor", _f32), ("out_amax", _vp), ("W_f16x2_frag", _vp),
         ("W2_f16x2_frag", _vp), ("w2_inv_scale", _vp), ("bias2", _vp), ("Cout2", _i32), ("relu2", _i32),
         ("W3_f16x2_frag", _vp), ("w3_inv_scale", _vp), ("bias3", _vp), ("Cout3", _i32), ("relu3", _i32),
-        ("loader_bias", _vp), ("rows_per_scene", _i32), ("rel_xyz4", _vp),
+        ("loader_bias", _vp), ("rows_per_scene", _i32), ("rel_xyz4", _vp), ("seg4", _vp), ("seg_rows", _vp),
     ]
 
 
@@ -85,6 +85,7 @@ SIGNATURES = {
     "s4g_fps_gather_ex_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp]),
     "s4g_fps_prefix_check_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _int, _vp]),
     "s4g_group_rel_xyz_i32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "s4g_group_rel_xyz_unique_i32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "s4g_expected_score_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "s4g_decode_poses_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "s4g_collision_counts_f32": (_int, [_vp, _vp, _i64, _i64, _i64, ctypes.POINTER(ctypes.c_float),

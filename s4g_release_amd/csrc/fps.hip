@@ -1878,7 +1878,10 @@ __global__ __launch_bounds__(256) void fps_prefix_check_kernel(const float* __re
       const float d = dist2<FMAD>(c.x, c.y, c.z, sx, sy, sz);   // (centroid, point): the kernels' order
       m = d < m ? d : m;
       const int k = k0 + q;
-      bad |= !(c.w > 0.f) || !(c.w < __builtin_inff()) || (j > k + 1 && j < M1 && !(m < c.w));
+      // element k + 1's own running min-distance must BE the reported D_{k+1} (bitwise: the sampler that
+      // produced D and this kernel then provably share one arithmetic), every later element stays below it
+      bad |= !(c.w > 0.f) || !(c.w < __builtin_inff()) || (j > k + 1 && j < M1 && !(m < c.w)) ||
+             (j == k + 1 && __float_as_uint(m) != __float_as_uint(c.w));
     }
   }
   if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(&run[b], 1);
@@ -1927,11 +1930,15 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
   }
 
   bool launched = pruned && dense_steps == 0;   // (no full-scan launch in front of the pruned kernel)
+  // the per-scene skip flags are honoured by the full-scan kernel when it IS the sampler (N <= 10 240);
+  // as the dense front of the pruned kernel it must run every scene, or the pruned steps would start
+  // from min-distances nobody wrote
+  const FpsExtra ex_reg = pruned ? FpsExtra{ex.dist, nullptr} : ex;
 #define S4G_FPS_CASE(T, P)                                                   \
   if (!launched && N <= (int64_t)T * P) {                                    \
     hipLaunchKernelGGL((fps_reg_kernel<T, P, FMAD, IdxT>), grid, dim3(T), 0, \
                        stream, xyz, (int)N, (int)M, idx, ctr, lg, m_run,     \
-                       md_out, ex);                                          \
+                       md_out, ex_reg);                                      \
     S4G_LAUNCH_CHECK();                                                      \
     launched = true;                                                         \
   }

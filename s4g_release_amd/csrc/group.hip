@@ -88,6 +88,91 @@ __global__ __launch_bounds__(GP_THREADS) void group_rel_xyz_kernel(const float* 
                                         __fsub_rn(x[2 * (size_t)N + j], c[2 * (size_t)M + m]), 0.f);
 }
 
+// ---- the same records WITHOUT the duplicates (ABI 8).  ball_query pads a ball with fewer than K hits by
+// repeating its first hit (ball_query_kernel.cu:64-67), so slots count .. K-1 of a centroid are copies of
+// slot 0 and the max over the K neighbours (modules.py:243) does not see them: the first SA level only
+// has to push a centroid's DISTINCT rows through its shared MLP.  Scene b's rows start at b M K as before;
+// centroid m contributes c4(m) = its count (at least 1: an empty ball is K copies of point 0) rounded up to
+// a multiple of 4 (slots past the count are copies, so the padding rows are too), centroids back to back.
+//   row_start[b M + m]   first row of centroid m, relative to the scene's base (exclusive scan of c4)
+//   seg4[row / 4]        b M + m for every group of 4 rows; -1 behind the scene's last centroid
+//   rows[b]              the scene's rows rounded up to GU_TILE (the contraction's tile height); the rows
+//                        between the last centroid and that edge are zero records of segment -1
+constexpr int GU_THREADS = 1024, GU_TILE = 128;
+__global__ __launch_bounds__(GU_THREADS) void group_unique_scan_kernel(const int* __restrict__ cnt, int M, int K,
+                                                                       int* __restrict__ row_start,
+                                                                       int* __restrict__ rows,
+                                                                       float4* __restrict__ out,
+                                                                       int* __restrict__ seg4) {
+  __shared__ int wsum[GU_THREADS / 64];
+  __shared__ int total_s;
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int per = (M + GU_THREADS - 1) / GU_THREADS;
+  const int m0 = t * per;
+  int local = 0;
+  for (int i = 0; i < per; ++i) {
+    const int m = m0 + i;
+    if (m < M) local += (max(cnt[(size_t)b * M + m], 1) + 3) & ~3;
+  }
+  int incl = local;   // inclusive scan over the wave, then over the waves
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int w = 0; w < GU_THREADS / 64; ++w) {
+      const int v = wsum[w];
+      wsum[w] = run;
+      run += v;
+    }
+    total_s = run;
+  }
+  __syncthreads();
+  int start = wsum[wave] + incl - local;
+  for (int i = 0; i < per; ++i) {
+    const int m = m0 + i;
+    if (m < M) {
+      row_start[(size_t)b * M + m] = start;
+      start += (max(cnt[(size_t)b * M + m], 1) + 3) & ~3;
+    }
+  }
+  const int total = total_s;                                   // a multiple of 4
+  const int padded = (total + GU_TILE - 1) / GU_TILE * GU_TILE;   // <= M K (a multiple of GU_TILE)
+  if (t == 0) rows[b] = padded;
+  const size_t base = (size_t)b * M * K;
+  for (int r = total + t; r < padded; r += GU_THREADS) {
+    out[base + r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((r & 3) == 0) seg4[(base + r) >> 2] = -1;
+  }
+}
+
+__global__ __launch_bounds__(GP_THREADS) void group_rel_unique_kernel(const float* __restrict__ xyz,
+                                                                      const float* __restrict__ ctr,
+                                                                      const int* __restrict__ idx,
+                                                                      const int* __restrict__ cnt,
+                                                                      const int* __restrict__ row_start, int N,
+                                                                      int M, int K, float4* __restrict__ out,
+                                                                      int* __restrict__ seg4) {
+  const int b = blockIdx.y;
+  const int64_t MK = (int64_t)M * K;
+  const int64_t t = (int64_t)blockIdx.x * GP_THREADS + threadIdx.x;
+  if (t >= MK) return;
+  const int m = (int)(t / K), k = (int)(t - (int64_t)m * K);
+  const int c4 = (max(cnt[(size_t)b * M + m], 1) + 3) & ~3;
+  if (k >= c4) return;
+  const int j = idx[(size_t)b * MK + t];          // slots past the count repeat slot 0 (or hold 0: empty ball)
+  const float* __restrict__ x = xyz + (size_t)b * 3 * N;
+  const float* __restrict__ c = ctr + (size_t)b * 3 * M;
+  const size_t row = (size_t)b * MK + row_start[(size_t)b * M + m] + k;
+  out[row] = make_float4(__fsub_rn(x[j], c[m]), __fsub_rn(x[N + j], c[M + m]),
+                         __fsub_rn(x[2 * (size_t)N + j], c[2 * (size_t)M + m]), 0.f);
+  if ((k & 3) == 0) seg4[row >> 2] = b * M + m;
+}
+
 __global__ __launch_bounds__(GP_THREADS) void group_points_scalar_kernel(
     const float* __restrict__ in, const int64_t* __restrict__ idx, int C, int N,
     int64_t MK, float* __restrict__ out) {
@@ -184,6 +269,30 @@ extern "C" int s4g_group_rel_xyz_i32(const float* xyz_b3n, const float* ctr_b3m,
                      dim3((unsigned)((MK + s4g::GP_THREADS - 1) / s4g::GP_THREADS), (unsigned)B),
                      dim3(s4g::GP_THREADS), 0, st, xyz_b3n, ctr_b3m, idx_bmk, (int)N, (int)M, (int)K,
                      reinterpret_cast<float4*>(rel_pk4));
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
+
+extern "C" int s4g_group_rel_xyz_unique_i32(const float* xyz_b3n, const float* ctr_b3m, const int32_t* idx_bmk,
+                                            const int32_t* cnt_bm, int64_t B, int64_t N, int64_t M, int64_t K,
+                                            float* rel_pk4, int32_t* seg4, int32_t* row_start_bm,
+                                            int32_t* rows_b, s4g_stream_t stream) {
+  if (B < 0 || N <= 0 || M < 0 || K < 0 || B > 65535 || N >= (1ll << 31) || B * M * K >= (1ll << 31))
+    return S4G_EINVAL;
+  const int64_t MK = M * K;
+  if (B == 0 || MK == 0) return S4G_OK;
+  if ((K & 3) || (MK % s4g::GU_TILE) || M > s4g::GU_THREADS * 64) return S4G_EUNSUPPORTED;
+  if (!xyz_b3n || !ctr_b3m || !idx_bmk || !cnt_bm || !rel_pk4 || !seg4 || !row_start_bm || !rows_b ||
+      ((uintptr_t)rel_pk4 & 15))
+    return S4G_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(s4g::group_unique_scan_kernel, dim3((unsigned)B), dim3(s4g::GU_THREADS), 0, st, cnt_bm, (int)M,
+                     (int)K, row_start_bm, rows_b, reinterpret_cast<float4*>(rel_pk4), seg4);
+  S4G_LAUNCH_CHECK();
+  hipLaunchKernelGGL(s4g::group_rel_unique_kernel,
+                     dim3((unsigned)((MK + s4g::GP_THREADS - 1) / s4g::GP_THREADS), (unsigned)B),
+                     dim3(s4g::GP_THREADS), 0, st, xyz_b3n, ctr_b3m, idx_bmk, cnt_bm, row_start_bm, (int)N, (int)M,
+                     (int)K, reinterpret_cast<float4*>(rel_pk4), seg4);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }

@@ -85,6 +85,11 @@ struct GemmParams {
   // A[p][k] = relu(w1[k].x*rx + w1[k].y*ry + w1[k].z*rz + w1[k].w), k < Cin
   const float4* mlp1;
   const float4* rel4;   // optional: the rows' (xyz_j - ctr_m, 0) records, read instead of following gidx
+  // optional (mlp_chain_kernel, GATHER_MLP1 + rel4 + MAX): rel4 holds every centroid's DISTINCT rows only
+  // (s4g_group_rel_xyz_unique_i32): seg4[row / 4] = output row of each group of 4 rows (-1: none),
+  // seg_rows[scene] = rows the scene occupies behind its base scene * rps
+  const int* seg4;
+  const int* seg_rows;
   // INTERP: sparse (B*N2, C2), dense (B*N1, C1), nidx/nw (B*N1, 3)
   const int* nidx;
   const float* nw;
@@ -1329,6 +1334,14 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
   const int p0 = blockIdx.x * BM;
 
   constexpr bool ADD_BOUNDS = LOADER == LOAD_GATHER_ADD || LOADER == LOAD_INTERP_ADD;   // the loader SUMS its inputs
+  constexpr bool SEGMAX = LOADER == LOAD_GATHER_MLP1 && EPI2 == EPI_MAX;   // may run on distinct rows only (seg4)
+  if constexpr (SEGMAX) {
+    // distinct-row form: a scene's rows end before its base + rps; the tiles behind them have nothing to do
+    if (p.seg_rows) {
+      const int sc = p0 / p.rps;
+      if (p0 - sc * p.rps >= p.seg_rows[sc]) return;
+    }
+  }
   const int p_hi = min(p0 + BM, p.P) - 1;   // rows of this tile: [p0, p_hi]
   // The input maxima of this tile's scene are REQUESTED here and reduced after the W prefetch and
   // the loader's own loads have been issued (vector loads return in order: asked for first, they
@@ -1623,6 +1636,16 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
   prime_a();
   WRef wstrip = w2;
   const float* __restrict__ bg2 = bgF;
+  // distinct-row form: the output rows of this half-wave's eight 4-row groups (rows 64 wr + 32 lh + 4 i ..)
+  int sidv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (SEGMAX) {
+    if (p.seg4) {
+      const int4* sp = reinterpret_cast<const int4*>(p.seg4 + ((p0 + wr * 64 + lh * 32) >> 2));
+      const int4 s0 = sp[0], s1 = sp[1];
+      sidv[0] = s0.x; sidv[1] = s0.y; sidv[2] = s0.z; sidv[3] = s0.w;
+      sidv[4] = s1.x; sidv[5] = s1.y; sidv[6] = s1.z; sidv[7] = s1.w;
+    }
+  }
   for (int strip = 0; strip < nstrip2; ++strip, wstrip = wstrip + strip_stride) {
     if ((strip * CW + wc_u) * 64 >= CoutF) break;
     const int n = (strip * CW + wc) * 64 + lane;
@@ -1668,6 +1691,54 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
           }
         }
       if (p.out_amax) {
+        const uint32_t wm = wave_max_u32(__float_as_uint(omax));
+        if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave + strip, p0, p_hi, p.rps);
+      }
+    } else if (SEGMAX && p.seg4) {
+      // distinct-row form: the wave's 64 rows are pieces of several centroids, each a run of 4-row groups
+      // with one output row (seg4).  Per channel block: the group maxima (4 -> 1 in registers), one
+      // half-exchange per pair (v_permlane32_swap: afterwards the lower half-wave holds the 8 groups of
+      // row block 0 for its channel, the upper half those of block 1), then every half walks ITS eight
+      // groups; where the output row changes the run's maximum is scaled, biased, clamped (post-ReLU
+      // values are >= 0: their bit patterns order like unsigned integers) and merged into the
+      // zero-initialised output with atomicMax -- a centroid's rows may continue in the other half, the
+      // next wave's rows or the next tile.  max is exact and order-free: same values as the 64-row form.
+      uint32_t* __restrict__ outu = reinterpret_cast<uint32_t*>(p.out);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const float sc = __shfl(e_sc, cb * 32 + li);
+        const float bias = __shfl(e_bias, cb * 32 + li);
+        const int nn = n0 + cb * 32 + li;
+        float v[8];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          // rows 32 rb + 8 qd + 4 lh + (0..3) = group 8 rb + 2 qd + lh of the wave's 16
+          const float o0 = fmaxf(fmaxf(acc[0][cb][4 * qd], acc[0][cb][4 * qd + 1]),
+                                 fmaxf(acc[0][cb][4 * qd + 2], acc[0][cb][4 * qd + 3]));
+          const float o1 = fmaxf(fmaxf(acc[1][cb][4 * qd], acc[1][cb][4 * qd + 1]),
+                                 fmaxf(acc[1][cb][4 * qd + 2], acc[1][cb][4 * qd + 3]));
+          const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(o0), __float_as_uint(o1), false, false);
+          v[2 * qd] = __uint_as_float(r[0]);       // lower half: block 0's group 2 qd;     upper: block 1's
+          v[2 * qd + 1] = __uint_as_float(r[1]);   // lower half: block 0's group 2 qd + 1; upper: block 1's
+        }
+        auto emit = [&](int seg, float m) {
+          if (seg < 0) return;
+          const float x = fmaxf(m * sc + bias, 0.f);
+          omax = fmaxf(omax, x);
+          if (nn < CoutF) atomicMax(outu + (size_t)seg * p.ldc + p.c_coff + nn, __float_as_uint(x));
+        };
+        int cur = sidv[0];
+        float m = v[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) {
+          const bool chg = sidv[i] != cur;
+          if (chg) emit(cur, m);
+          m = chg ? v[i] : fmaxf(m, v[i]);
+          cur = sidv[i];
+        }
+        emit(cur, m);
+      }
+      if (PL == 2 && p.out_amax) {
         const uint32_t wm = wave_max_u32(__float_as_uint(omax));
         if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave + strip, p0, p_hi, p.rps);
       }
@@ -1888,6 +1959,8 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   p.Cf = d->Cf; p.N = d->N; p.M = d->M; p.K = d->K;
   p.mlp1 = (const float4*)d->mlp1_w;
   p.rel4 = (const float4*)d->rel_xyz4;
+  p.seg4 = d->seg4;
+  p.seg_rows = d->seg_rows;
   p.nidx = d->nidx; p.nw = d->nw; p.sparse = d->sparse; p.dense = d->dense;
   p.C2 = d->C2; p.C1 = d->C1; p.N2 = d->N2; p.N1 = d->N1;
   p.out = d->out; p.ldc = d->ldc; p.c_coff = d->c_coff; p.c_gcol = d->c_gcol;
@@ -1933,6 +2006,11 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
         !d->mlp1_w || (d->Cin & 3) || d->K <= 0 || d->M <= 0 || d->N <= 0 || d->groups != 1 ||
         ((uintptr_t)d->mlp1_w & 15))
       return S4G_EINVAL;
+    // distinct-row form: only the fused chain with the max epilogue knows how to merge a centroid's pieces
+    if ((d->seg4 != nullptr) != (d->seg_rows != nullptr)) return S4G_EINVAL;
+    if (d->seg4 && (!d->rel_xyz4 || !d->W2_f16x2_frag || d->epilogue != S4G_GEMM_EPI_MAX || d->K != 64 ||
+                    d->rows_per_scene <= 0 || (d->rows_per_scene & 127) || !d->relu2 || d->W3_f16x2_frag))
+      return S4G_EINVAL;
   } else if (d->loader == S4G_GEMM_LOAD_GATHER_ADD) {
     if (!d->gidx || !d->xyz || !d->ctr || !d->mlp1_w || !d->feat || (d->Cin & 3) || d->Cf != d->Cin ||
         d->K <= 0 || d->M <= 0 || d->N <= 0 || d->groups != 1 || ((uintptr_t)d->mlp1_w & 15) ||
@@ -1950,6 +2028,7 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   } else {
     return S4G_EINVAL;
   }
+  if (d->loader != S4G_GEMM_LOAD_GATHER_MLP1 && (d->seg4 || d->seg_rows)) return S4G_EINVAL;
   if (d->epilogue == S4G_GEMM_EPI_MAX) {
     if (!(d->K == 16 || d->K == 32 || d->K == 64) || d->groups != 1 || !d->out) return S4G_EINVAL;
   } else if (d->epilogue == S4G_GEMM_EPI_STORE) {

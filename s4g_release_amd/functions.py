@@ -93,6 +93,8 @@ class OpTimer:
         acc = {}
         for name, e0, e1, nbytes, flops in cls.records:
             n, t, b, f = acc.get(name, (0, 0.0, 0, 0.0))
+            if callable(flops):        # data-dependent work: evaluated now, after the region's fence
+                flops = flops()
             acc[name] = (n + 1, t + e0.elapsed_time(e1), b + nbytes, f + flops)
         return {k: (n, t / n, b / n, f / n) for k, (n, t, b, f) in acc.items()}
 

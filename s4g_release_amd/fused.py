@@ -167,6 +167,9 @@ class FusedPointNet2:
         self.fp_loader_add = v if v in ("auto", "none") else set(int(t) for t in v.split(",") if t)
         self.geo_streams = max(1, int(os.environ.get("S4G_GEO_STREAMS", "2")))
         self.rel_xyz = os.environ.get("S4G_REL_XYZ", "1") != "0"
+        # first SA level on a centroid's DISTINCT rows only (ball_query pads short balls with copies of the
+        # first hit, the max over the neighbours cannot see them): S4G_SA_UNIQUE=0 contracts all K rows
+        self.sa_unique = os.environ.get("S4G_SA_UNIQUE", "1") != "0"
         self.heads_pre = os.environ.get("S4G_HEADS_PRE", "1") != "0"
         self.fp_chain_next = os.environ.get("S4G_FP_CHAIN_NEXT", "1") != "0"
         self.fps_prefix = os.environ.get("S4G_FPS_PREFIX", "1") != "0"
@@ -293,12 +296,12 @@ class FusedPointNet2:
         """First FP layer W = [W_a | W_b] over [interpolated (c2), skip (c1)] columns as two layers
         without bias (modules.py:124-127 concat order), cached on the level."""
         sp = fp.get("split")
-        if sp is None or sp[2] != c2:
+        if sp is None or sp[2] != (c2, c1):
             w = layer.W[:, :layer.cin]
             zero = torch.zeros_like(layer.bias)
             la = _Layer(_pad_k(w[:, :c2].contiguous()), zero, c2)
             lb = _Layer(_pad_k(w[:, c2:].contiguous()), zero, c1) if c1 > 0 else None
-            sp = fp["split"] = (la, lb, c2)
+            sp = fp["split"] = (la, lb, (c2, c1))
         return sp
 
     def _heads_take_tail(self, fi, fl, pending):
@@ -312,7 +315,7 @@ class FusedPointNet2:
 
     # ------------------------------------------------------------------ launches
     def _gemm(self, name, layer, P, loader, epi, relu=True, layer2=None, layer3=None, name3="heads.0",
-              rows_per_scene=0, relu2=True, name2=None, **kw):
+              rows_per_scene=0, relu2=True, name2=None, rows_used=None, **kw):
         d = GemmDesc()
         d.loader, d.epilogue, d.groups, d.relu = loader, epi, layer.groups, int(relu)
         d.P, d.Cin, d.Kpad, d.Cout = P, layer.cin, layer.kpad, layer.cout
@@ -345,6 +348,11 @@ class FusedPointNet2:
             d.Cout3, d.relu3 = layer3.cout, 1
             flops += 2.0 * P * layer3.cout * layer3.cin * layer3.groups
             name += "+" + name3
+        if rows_used is not None:
+            # a data-dependent row count (the distinct-row SA level): the flops of the rows that exist,
+            # read back when the timers are summarised (after the timed region's fence)
+            per_row = flops / P
+            flops = lambda: per_row * float(rows_used.sum().item())
         with _F._timed("gemm[%s P=%d K=%d N=%dx%d]" % (name, P, layer.cin, layer.groups, layer.cout),
                        0, flops):
             rc = _cabi.lib().s4g_mlp_gemm_f32(ctypes.byref(d), _F._stream())
@@ -457,6 +465,29 @@ class FusedPointNet2:
         _cabi.check(rc, "group_rel_xyz_i32")
         return rel
 
+    def _group_rel_xyz_unique(self, xyz, ctr, gidx, gcnt):
+        """The same records without ball_query's padding copies (s4g_group_rel_xyz_unique_i32): rows
+        (B*M*K capacity, 4), seg4 (B*M*K/4) output row per group of 4 rows, rows per scene (B), or None
+        where the shape is not supported."""
+        B, _, N = xyz.shape
+        _, M, K = gidx.shape
+        if K % 4 or (M * K) % 128:
+            return None
+        dev = xyz.device
+        rel = torch.empty((B * M * K, 4), dtype=torch.float32, device=dev)
+        seg4 = torch.empty((B * M * K // 4,), dtype=torch.int32, device=dev)
+        row_start = torch.empty((B, M), dtype=torch.int32, device=dev)
+        rows = torch.empty((B,), dtype=torch.int32, device=dev)
+        with _F._timed("group_rel_xyz_unique[N=%d,M=%d,K=%d]" % (N, M, K), B * M * K * (4 + 12 + 16)):
+            rc = _cabi.lib().s4g_group_rel_xyz_unique_i32(xyz.data_ptr(), ctr.data_ptr(), gidx.data_ptr(),
+                                                          gcnt.data_ptr(), B, N, M, K, rel.data_ptr(),
+                                                          seg4.data_ptr(), row_start.data_ptr(), rows.data_ptr(),
+                                                          _F._stream())
+        if rc == _cabi.S4G_EUNSUPPORTED:
+            return None
+        _cabi.check(rc, "group_rel_xyz_unique_i32")
+        return rel, seg4, rows
+
     def _three_nn(self, q, k, eps, cell=0.0):
         B, _, N1 = q.shape
         N2 = k.shape[2]
@@ -479,6 +510,12 @@ class FusedPointNet2:
                                                       _F._DIST_FLAGS, _F._stream())
         _cabi.check(rc, "three_nn_weights_i32")
         return idx, w
+
+    def _sa_unique_ok(self, sa):
+        """The distinct-row form needs the fused two-layer chain behind the xyz-only first layer."""
+        layers = sa["layers"]
+        return (self.precision in ("f16x2", "bf16") and len(layers) == 3 and layers[-1].groups == 1 and
+                self._fusable(layers[-2], layers[-1], LOAD_GATHER_MLP1, EPI_MAX))
 
     # ------------------------------------------------------------------ forward
     def _geometry(self, xyz):
@@ -505,8 +542,18 @@ class FusedPointNet2:
             geo["sa"].append((idx, ctr, gidx, gcnt))
             # the xyz-only first layer runs inside the next layer's loader: hand it its rows
             # pre-gathered (S4G_REL_XYZ=0: the loader follows gidx itself)
-            geo["rel"].append(self._group_rel_xyz(geo["level_xyz"][-1], ctr, gidx)
-                              if sa["mlp1"] is not None and self.rel_xyz else None)
+            rel = None
+            if sa["mlp1"] is not None and self.rel_xyz:
+                if self.sa_unique and K == 64 and self._sa_unique_ok(sa):
+                    # (rows, seg4, rows per scene) + the level's zero-filled output, which the chain's
+                    # atomicMax epilogue merges into (zeroed here, off the contraction stream)
+                    rel = self._group_rel_xyz_unique(geo["level_xyz"][-1], ctr, gidx, gcnt)
+                    if rel is not None:
+                        rel = rel + (torch.zeros((B * M, sa["layers"][-1].cout), dtype=torch.float32,
+                                                 device=xyz.device),)
+                if rel is None:
+                    rel = self._group_rel_xyz(geo["level_xyz"][-1], ctr, gidx)
+            geo["rel"].append(rel)
             # the contractions of this SA level only need its own sampling + grouping:
             # they may start while the deeper levels' FPS / 3-NN are still running
             geo["sa_events"].append(torch.cuda.current_stream().record_event())
@@ -574,14 +621,20 @@ class FusedPointNet2:
                 nrow = B * M if last else P
                 l2 = layers[-1] if (fuse2 and l == len(layers) - 2) else None
                 cout = l2.cout if l2 is not None else layer.cout
-                out = torch.empty((nrow, cout), dtype=torch.float32, device=dev)
+                rel = geo["rel"][li] if (l == 1 and sa["mlp1"] is not None) else None
+                uniq = isinstance(rel, tuple) and l2 is not None
+                out = rel[3] if uniq else torch.empty((nrow, cout), dtype=torch.float32, device=dev)
                 out_amax = next(rows)
                 kw = dict(out=out, ldc=cout, K=K, out_amax=out_amax, layer2=l2)
                 if l == 1 and sa["mlp1"] is not None:
                     kw.update(gidx=gidx, xyz=level_xyz[li], ctr=ctr, N=level_n[li], M=M,
                               mlp1_w=sa["mlp1"], a_amax_floor=sa["mlp1_bound"])
-                    if geo["rel"][li] is not None:
-                        kw.update(rel_xyz4=geo["rel"][li])
+                    if uniq:      # distinct rows only; flops are counted over the rows that exist
+                        kw.update(rel_xyz4=rel[0], seg4=rel[1], seg_rows=rel[2], rows_used=rel[2])
+                    elif isinstance(rel, tuple):
+                        raise RuntimeError("distinct-row records without the fused chain that consumes them")
+                    elif rel is not None:
+                        kw.update(rel_xyz4=rel)
                     loader = LOAD_GATHER_MLP1
                 elif l == 1 and pre is not None:
                     kw.update(gidx=gidx, feat=fpre, Cf=layers[0].cout, xyz=level_xyz[li], ctr=ctr,
@@ -680,11 +733,11 @@ class FusedPointNet2:
                     in_loader = in_loader and self.precision in ("f16x2", "bf16") and len(fl) >= 2
                     if in_loader and fuse2 and not self._fusable(fl[-2], fl[-1], LOAD_INTERP_ADD, EPI_STORE):
                         in_loader = False
-                    s_amax = next(rows) if in_loader else None
                     if carried is not None:      # the previous level's chain already produced it
                         s_out, s_amax = carried
                         carried = None
                     else:
+                        s_amax = next(rows) if in_loader else None
                         self._gemm("fp%d.0s" % fi, la, B * n_sparse, LOAD_PLAIN, EPI_STORE, relu=False,
                                    out=s_out, ldc=layer.cout, A=sparse_feat, lda=c2, a_amax=sparse_amax,
                                    out_amax=s_amax)
@@ -822,8 +875,9 @@ class FusedPointNet2:
                 for t in (idx, ctr, gidx, gcnt):
                     t.record_stream(ds)
             for t in geo["rel"]:
-                if t is not None:
-                    t.record_stream(ds)
+                for u in (t if isinstance(t, tuple) else (t,)):
+                    if u is not None:
+                        u.record_stream(ds)
             for nidx, nw in geo["fp"]:
                 nidx.record_stream(ds)
                 nw.record_stream(ds)

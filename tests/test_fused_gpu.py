@@ -274,6 +274,7 @@ def test_model_with_and_without_pregathered_rows(dev, monkeypatch):
     randomize_bn_(net, 4)
     net = net.to(dev).eval()
     pts = torch.from_numpy(synth.make_batch([5, 6], 25600)).to(dev)
+    monkeypatch.setenv("S4G_SA_UNIQUE", "0")     # (the distinct-row form has its own tests: test_sa_unique_gpu.py)
     a = FusedPointNet2(net)({"scene_points": pts})
     monkeypatch.setenv("S4G_REL_XYZ", "0")
     b = FusedPointNet2(net)({"scene_points": pts})

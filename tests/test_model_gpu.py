@@ -15,7 +15,7 @@ TOL = 1e-4
 def _capture_indices(F):
     """Wrap the raw entry points to record the index tensors a forward produces."""
     rec = {"fps": [], "ball": [], "nn": []}
-    orig = (F._farthest_point_sample, F._ball_query, F._point_search)
+    orig = (F._farthest_point_sample, F._ball_query, F._point_search, F.query_and_group)
 
     def fps(*a):
         r = orig[0](*a); rec["fps"].append(r); return r
@@ -25,12 +25,14 @@ def _capture_indices(F):
 
     def nn(*a):
         r = orig[2](*a); rec["nn"].append(r); return r
-    F._farthest_point_sample, F._ball_query, F._point_search = fps, ball, nn
+    def qgroup(*a):      # QueryGrouper's one-pass form: (index, count, grouped xyz)
+        r = orig[3](*a); rec["ball"].append((r[0], r[1])); return r
+    F._farthest_point_sample, F._ball_query, F._point_search, F.query_and_group = fps, ball, nn, qgroup
     return rec, orig
 
 
 def _restore(F, orig):
-    F._farthest_point_sample, F._ball_query, F._point_search = orig
+    F._farthest_point_sample, F._ball_query, F._point_search, F.query_and_group = orig
 
 
 def test_reference_shaped_model_small_golden(dev):
