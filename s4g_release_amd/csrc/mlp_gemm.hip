@@ -1557,6 +1557,46 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
     S4G_F2_STRIP(true, true, wcur, cb_stride, wnxt, cb_stride)
   }
   S4G_STAMP(4 + 4 * ph);
+  if constexpr (LOADER == LOAD_PLAIN && EPI2 == EPI_STORE) {
+    if (!p.Wfrag2) {
+      // ONE layer (the plain single-layer launches of a step run here instead of on the tiled kernel: the
+      // A panel is staged K columns at a time, W streams through the register ring, two barriers per
+      // K-wide chunk instead of two per 32 columns): out = act(scale * acc + bias), this workgroup's
+      // 64 positions x this group's K channels (the caller maps 256-channel strips of a wider layer to
+      // groups that share A).  Operands are swapped: a lane holds 4 consecutive channels of a position.
+      float omax1 = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int nn = wc * 64 + nb * 32 + 8 * j + 4 * lh;
+          const float4 sc4 = *reinterpret_cast<const float4*>(epi_s + nb * 32 + 8 * j + 4 * lh);
+          const float4 b4 = *reinterpret_cast<const float4*>(epi_s + 64 + nb * 32 + 8 * j + 4 * lh);
+          const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+          const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x = __fmaf_rn(acc[nb][pb][4 * j + e], scv[e], bv[e]);
+              if (p.relu) x = fmaxf(x, 0.f);
+              v[e] = x;
+              omax1 = fmaxf(omax1, fabsf(x));
+            }
+            const int row = p0 + wr * 64 + pb * 32 + li;
+            if (row < p.P)
+              *reinterpret_cast<float4*>(p.out + (size_t)row * p.ldc + p.c_coff + g * p.c_gcol + nn) =
+                  make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      if (PL == 2 && p.out_amax) {
+        const uint32_t wm = wave_max_u32(__float_as_uint(omax1));
+        if (lane == 0) amax_publish(p.out_amax, wm, (blockIdx.x * 4 + wave) * 5 + g, p0, p_hi, p.rps);
+      }
+      return;
+    }
+  }
   if (S4G_CHAIN_ABLATE & 4) {
     chain_keep_alive(acc[0][0]); chain_keep_alive(acc[0][1]); chain_keep_alive(acc[1][0]); chain_keep_alive(acc[1][1]);
     __syncthreads();
@@ -1911,6 +1951,7 @@ static int launch_gemm(const GemmParams& p, int groups, hipStream_t st) {
   X(LOAD_PLAIN, EPI_STORE, 2, 1)                                                                 \
   X(LOAD_PLAIN, EPI_STORE, 1, 1)                                                                 \
   X(LOAD_PLAIN, EPI_STORE, 1, 2)      /* first layer two panels deep (512 -> 256 -> ...) */      \
+  X(LOAD_PLAIN, EPI_STORE, 1, 4)      /* ... or four (the 1 024-deep single-layer launches) */   \
   X(LOAD_PLAIN, EPI_STORE, 8, 1)                                                                 \
   X(LOAD_INTERP_ADD, EPI_STORE, 2, 1)                                                            \
   X(LOAD_INTERP_ADD, EPI_STORE, 1, 1)                                                            \
@@ -2063,6 +2104,32 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
     S4G_FUSED2_LIST(S4G_FUSED2_CASE)
 #undef S4G_FUSED2_CASE
     return S4G_EUNSUPPORTED;
+  }
+  // plain single layers whose widths allow it run on the chain kernel's first-layer machinery (round 4):
+  // 64 positions x 256 channels per workgroup, the 256-channel strips of a wider layer as groups that
+  // share A (S4G_GEMM_SINGLE_CHAIN=0: the tiled kernel)
+  {
+    static const bool single_chain = [] { const char* e = getenv("S4G_GEMM_SINGLE_CHAIN"); return !(e && e[0] == '0'); }();
+    const bool bf1 = d->precision == S4G_GEMM_BF16;
+    const int kc = d->Kpad16 / 256;
+    if (single_chain && (h2 || bf1) && d->loader == S4G_GEMM_LOAD_PLAIN && d->epilogue == S4G_GEMM_EPI_STORE &&
+        d->W_f16x2_frag && d->groups == 1 && d->Cout % 256 == 0 && d->Kpad16 % 256 == 0 &&
+        (kc == 1 || kc == 2 || kc == 4) && ((d->ldc | d->c_coff) & 3) == 0 && ((uintptr_t)d->out & 15) == 0) {
+      GemmParams q = p;
+      q.Cout = 256;
+      q.a_gcol = 0;
+      q.c_gcol = 256;
+      q.b_gstride = 256;
+      const int strips = d->Cout / 256;
+#define S4G_SINGLE_CASE(KCH)                                                                     \
+  if (kc == KCH)                                                                                 \
+    return bf1 ? launch_mlp_chain<LOAD_PLAIN, EPI_STORE, 1, KCH, 1>(q, strips, st)               \
+               : launch_mlp_chain<LOAD_PLAIN, EPI_STORE, 1, KCH, 2>(q, strips, st);
+      S4G_SINGLE_CASE(1)
+      S4G_SINGLE_CASE(2)
+      S4G_SINGLE_CASE(4)
+#undef S4G_SINGLE_CASE
+    }
   }
   // single-product bf16: the swizzled-LDS tile kernel with one plane (S4G_BF16_TILED=0: the bf16x3
   // kernel's hi-plane-only mode it replaced)

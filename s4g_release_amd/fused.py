@@ -328,7 +328,7 @@ class FusedPointNet2:
         d.W_f16x2, d.w_inv_scale = layer.Wh2.data_ptr(), layer.w_inv_scale.data_ptr()
         bf16 = self.precision == "bf16"      # chains take ONE bf16 plane in fragment order
         frag = (lambda l: l.Wfrag_bf16) if bf16 else (lambda l: l.Wfrag)
-        if layer.Wfrag is not None and (not bf16 or layer2 is not None):
+        if layer.Wfrag is not None:     # (bf16: the one-plane fragments; single layers take them too)
             d.W_f16x2_frag = frag(layer).data_ptr()
         for k, v in kw.items():
             if isinstance(v, torch.Tensor):
