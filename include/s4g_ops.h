@@ -48,6 +48,41 @@ extern "C" {
  *    contracts a centroid's distinct rows only). */
 #define S4G_ABI_VERSION 8
 
+/* ---------------------------------------------------------------------------
+ * Environment knobs (round 4: the complete list; everything else that used to be read from the
+ * environment is gone).  None is needed in production -- the defaults are the measured-fastest exact
+ * paths; every alternative below is exact too and exists for tests and A/B measurements.
+ *
+ *  read inside libs4g_hip.so (per call unless noted):
+ *   S4G_FPS_MODE=dense|pruned      FPS kernel for N <= 25 600: full scan | group-pruned (default: pruned
+ *                                  above 10 240 points).  =dense also turns the L2-resident pruned kernel
+ *                                  off for 25 600 < N <= 51 200 (the streaming kernel runs instead)
+ *   S4G_FPS_DENSE_STEPS=k          first k picks by the full-scan kernel in front of the pruned one (0)
+ *   S4G_BQ_MODE=scan|grid          ball query path (default: grid from 8 192 points)
+ *   S4G_GRID_BUILD=loop            streaming grid build for every size (read once)
+ *   S4G_NN_SPLIT=0                 3-NN: never the split scan for 24 <= N2 <= 2 048
+ *   S4G_NN_CELL_FACTOR=f           3-NN operator API: cell edge = f x measured 3rd-neighbour spacing (1.75; once)
+ *   S4G_INTERP_MODE=lane           three_interpolate: lane-per-point kernel instead of the LDS tile
+ *   S4G_GEMM_SINGLE_CHAIN=0|1      plain single layers never / wherever supported on mlp_chain_kernel's first-layer
+ *                                  form (default: where it measured faster: Cout >= 1024 or K >= 1024)
+ *  measurement builds only (make HIPFLAGS_EXTRA=-DS4G_VARIANTS, s4g_build_variants() == 1):
+ *   S4G_FPS_MODE=cluster|hybrid, S4G_BQ_MODE=cell (+ S4G_BQ_CELL_WGS), S4G_GEMM_RESIDENT=0|1
+ *  read by the Python host side (s4g_release_amd/):
+ *   S4G_HIP_LIB=path               load another build of this library (warns; tools/ab_libs.sh)
+ *   S4G_DIST_MODE=fmad             distance arithmetic contract (S4G_FLAG_FMAD) instead of strict
+ *   S4G_GEMM_MODE=f16x2|bf16x3|fp32|bf16   default contraction arithmetic of FusedPointNet2
+ *   S4G_SA_UNIQUE=0                first SA level contracts all K rows, padding copies included
+ *   S4G_REL_XYZ=0                  first SA level's loader follows the indices itself
+ *   S4G_SA_LINEAR_FIRST=0, S4G_FP_LINEAR_FIRST=0   no linear-layer-before-grouping / -interpolation
+ *   S4G_FP_LOADER_ADD=auto|none|levels, S4G_FP_CHAIN_NEXT=0   where the FP sums are formed
+ *   S4G_GEMM_FUSE2=0, S4G_GEMM_FUSE3=0, S4G_GEMM_FUSE512=0    layer chains as separate launches
+ *   S4G_HEADS_FUSED=0, S4G_HEADS_PRE=0   heads layer by layer / FP tail outside the heads launch
+ *   S4G_FPS_PREFIX=0               always sample SA levels 2 and 3 (no prefix proof)
+ *   S4G_NN_MODE=scan               3-NN: never the cell-grid search
+ *   S4G_GEO_STREAMS=n, S4G_DENSE_STREAMS=n   geometry / contraction streams of the pipeline (2 / 1)
+ *  bench.py: S4G_BENCH_FORCE_DIST=1 (RCCL path with one rank), S4G_BENCH_TIMER_EVERY=k
+ * ------------------------------------------------------------------------- */
+
 #define S4G_OK 0
 #define S4G_EINVAL (-1)     /* bad size / null pointer */
 #define S4G_EWORKSPACE (-2) /* workspace too small */
@@ -63,6 +98,11 @@ typedef void *s4g_stream_t; /* hipStream_t */
 #define S4G_OP_THREE_NN 3
 
 int s4g_abi_version(void);
+/* ABI >= 8.  1 if the library is a measurement build (make HIPFLAGS_EXTRA=-DS4G_VARIANTS) that also
+ * carries the measured-slower kernel variants of csrc/variants/ (two-CU / hybrid FPS for 51 200 points,
+ * the cell-centric ball query, the resident-A single-layer contraction); 0 for the shipped library,
+ * where S4G_FPS_MODE=cluster|hybrid, S4G_BQ_MODE=cell and S4G_GEMM_RESIDENT select nothing. */
+int s4g_build_variants(void);
 const char *s4g_error_string(int code);
 
 /* Bytes of device scratch an operator needs for the given problem

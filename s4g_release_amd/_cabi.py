@@ -84,6 +84,7 @@ SIGNATURES = {
     "s4g_fps_prepass_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "s4g_fps_gather_ex_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp]),
     "s4g_fps_prefix_check_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _int, _vp]),
+    "s4g_build_variants": (_int, []),
     "s4g_group_rel_xyz_i32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "s4g_group_rel_xyz_unique_i32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "s4g_expected_score_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),

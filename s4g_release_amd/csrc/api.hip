@@ -8,6 +8,15 @@ size_t ball_query_workspace_bytes(int64_t B, int64_t N, int64_t M, int64_t K);
 
 extern "C" int s4g_abi_version(void) { return S4G_ABI_VERSION; }
 
+// 1: a measurement build (-DS4G_VARIANTS) that also carries the measured-slower kernel variants
+extern "C" int s4g_build_variants(void) {
+#ifdef S4G_VARIANTS
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 extern "C" const char* s4g_error_string(int code) {
   if (code == S4G_OK) return "ok";
   if (code == S4G_EINVAL) return "invalid argument (size, null pointer or range)";

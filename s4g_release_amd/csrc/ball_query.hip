@@ -470,309 +470,9 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void bq_grid_query_kernel(
   }
 }
 
-// ---------------------------------------------------------------- CELL path
-// Cell-centric query: the centres are binned into the same grid (build workgroups
-// 8..15) and ONE WORKGROUP TAKES ONE NON-EMPTY X-QUAD OF CENTRE CELLS (4 x-adjacent
-// cells) AT A TIME.  All its centres share the 6 x 3 x 3 cell candidate set, so the
-// workgroup
-//   1. loads the candidate records once, marks their point indices in ONE LDS
-//      bitmap and turns the bitmap into ranks (prefix popcounts): a counting sort
-//      BY POINT INDEX that costs one bitmap sweep per quad instead of one per centre;
-//   2. scatters the records into LDS in rank order (windows of 1024 ranks);
-//   3. hands the centres to its waves round-robin; a wave answers a centre with the
-//      index-order scan of the SCAN path (ballot + mbcnt rank, early exit at K) over
-//      the staged records -- hits leave for global memory already in the
-//      reference's order, and the grouped coordinates come out of the same records
-//      (no gather).  Per-centre state (count, first hit) lives in lane j of the
-//      owning wave between windows.
-// Centres outside the exactness range take the index-order scan over the cloud.
-__device__ __forceinline__ float bq_readlane_f(float v, int l) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
-
-constexpr int BQC_THREADS = 256;
-constexpr int BQC_WAVES = BQC_THREADS / 64;
-constexpr int BQC_WIN = 1024;                   // ranks per window = records staged in LDS
-constexpr int BQC_RPT = BQC_WIN / BQC_THREADS;  // records per thread per window
-
-template <bool FMAD, typename IdxT, bool GROUP>
-__global__ __launch_bounds__(BQC_THREADS) void bq_cell_query_kernel(
-    const float* __restrict__ xyz, int N, int M, float r2, float inv_h, int K, GridWs ws,
-    CellWs cw, IdxT* __restrict__ idx, IdxT* __restrict__ cnt_out,
-    float* __restrict__ grouped, int bm_words, int wgs_per_scene) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  const int b = blockIdx.y;
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = t >> 6;
-  // bm_words: multiple of 4 * BQC_THREADS (thread t owns words [t*wpt, (t+1)*wpt))
-  const int wpt = bm_words / BQC_THREADS;
-  uint32_t* __restrict__ bm = lds;
-  uint16_t* __restrict__ pre = (uint16_t*)(bm + bm_words);          // prefix per bitmap word
-  float4* __restrict__ stage = (float4*)(bm + bm_words + bm_words / 2);  // records in rank order
-  uint32_t* __restrict__ wsum = bm + bm_words + bm_words / 2 + 4 * BQC_WIN;
-  // per-wave output row (index + grouped x, y, z), written out coalesced
-  const int Kp = (K + 3) & ~3;
-  int* __restrict__ orow = (int*)(wsum + 8) + wave * (GROUP ? 4 : 1) * Kp;
-  float* __restrict__ ogx = (float*)(orow + Kp);
-  for (int w = 4 * t; w < bm_words; w += 4 * BQC_THREADS)
-    *reinterpret_cast<uint4*>(bm + w) = make_uint4(0u, 0u, 0u, 0u);
-
-  const float* __restrict__ px = xyz + (size_t)b * 3 * N;
-  const float* __restrict__ py = px + N;
-  const float* __restrict__ pz = py + N;
-  const float ox = px[0], oy = py[0], oz = pz[0];
-  const bool scene_ok = ws.flags[b] == 0;
-  const float4* __restrict__ rec = ws.sorted + (size_t)b * GR_RANGES * N;
-  const int* __restrict__ starts_b = ws.starts + (size_t)b * GR_RANGES * GR_START_STRIDE;
-  const float4* __restrict__ crec = cw.sorted + (size_t)b * GR_RANGES * M;
-  const int4* __restrict__ cells_b = cw.cells + (size_t)b * GR_RANGES * GR_RANGE_SLOTS;
-  const size_t MK = (size_t)M * K;
-
-  // non-empty centre quads of this scene: 8 stripe lists, addressed as one range
-  const int ncl = lane < GR_RANGES ? cw.ncell[b * GR_RANGES + lane] : 0;
-  const int ninc = (int)wave_inclusive_scan_u32((uint32_t)ncl);
-  const int nitems = __builtin_amdgcn_readlane(ninc, 63);
-  __syncthreads();
-
-  for (int item = blockIdx.x; item < nitems; item += wgs_per_scene) {
-    const int g = __popcll(__ballot(lane < GR_RANGES && ninc <= item));
-    const int e = item - (__shfl(ninc, g) - __shfl(ncl, g));
-    const int4 ce = cells_b[(size_t)g * GR_RANGE_SLOTS + e];
-    const int slot = __builtin_amdgcn_readfirstlane(ce.x);
-    const int cstart = __builtin_amdgcn_readfirstlane(ce.y);
-    const int ccount = __builtin_amdgcn_readfirstlane(ce.z);
-    // record ranges of the 9 (dy, dz) rows, 6 cells [x - 1, x + 4] each: lanes 0..8 first
-    // piece, 9..17 the part that wrapped around x (first / last quad of a row only)
-    int pbeg = 0, plen = 0;
-    {
-      const int local = slot & (GR_RANGE_SLOTS - 1);
-      const int icx = local & 31, icy = (((local >> 5) & 3) << 3) | (slot >> 12), icz = local >> 7;
-      if (lane < 18) {
-        const int r = lane < 9 ? lane : lane - 9;
-        const int dz = r / 3 - 1, dy = r % 3 - 1;
-        const int zz = (icz + dz) & 31, yy = (icy + dy) & 31;
-        const int* __restrict__ st = starts_b + grid_range(yy, zz) * GR_START_STRIDE +
-                                     grid_local_row(yy, zz);
-        if (icx == 0) {           // cells 31 | 0..4
-          pbeg = lane < 9 ? st[31] : st[0];
-          plen = (lane < 9 ? st[32] : st[5]) - pbeg;
-        } else if (icx == 28) {   // cells 27..31 | 0
-          pbeg = lane < 9 ? st[27] : st[0];
-          plen = (lane < 9 ? st[32] : st[1]) - pbeg;
-        } else if (lane < 9) {
-          pbeg = st[icx - 1];
-          plen = st[icx + 5] - pbeg;
-        }
-      }
-    }
-    const int pinc = (int)wave_inclusive_scan_u32((uint32_t)plen);
-    const int poff = pbeg - (pinc - plen);
-    const int tot = __builtin_amdgcn_readlane(pinc, 17);
-    const bool wrapped = tot != __builtin_amdgcn_readlane(pinc, 8);
-    // flat candidate number q -> record index: q + off_i for the piece i that holds q
-    auto record_of = [&](int q) {
-      int off = __builtin_amdgcn_readlane(poff, 0);
-#pragma unroll
-      for (int i = 1; i < 9; ++i)
-        off = q >= __builtin_amdgcn_readlane(pinc, i - 1) ? __builtin_amdgcn_readlane(poff, i) : off;
-      if (wrapped) {
-#pragma unroll
-        for (int i = 9; i < 18; ++i)
-          off = q >= __builtin_amdgcn_readlane(pinc, i - 1) ? __builtin_amdgcn_readlane(poff, i) : off;
-      }
-      return q + off;
-    };
-    auto load_records = [&](float4 (&r)[BQC_RPT], int q0) {
-#pragma unroll
-      for (int u = 0; u < BQC_RPT; ++u) {
-        const int q = q0 + BQC_THREADS * u + t;
-        r[u] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-        if (q0 + BQC_THREADS * u < tot && q < tot) r[u] = rec[record_of(q)];
-      }
-    };
-
-    // ---- 1. candidates -> bitmap over the point index -> prefix popcounts
-    float4 p[BQC_RPT];  // window 0's records stay in registers
-    load_records(p, 0);
-#pragma unroll
-    for (int u = 0; u < BQC_RPT; ++u) {
-      const int pi = __float_as_int(p[u].w);
-      if (pi >= 0) atomicOr(&bm[pi >> 5], 1u << (pi & 31));
-    }
-    for (int q0 = BQC_WIN; q0 < tot; q0 += BQC_WIN) {
-      float4 r[BQC_RPT];
-      load_records(r, q0);
-#pragma unroll
-      for (int u = 0; u < BQC_RPT; ++u) {
-        const int pi = __float_as_int(r[u].w);
-        if (pi >= 0) atomicOr(&bm[pi >> 5], 1u << (pi & 31));
-      }
-    }
-    __syncthreads();
-    {
-      int local_cnt = 0;
-      for (int w = 0; w < wpt; w += 4) {
-        const uint4 v = *reinterpret_cast<const uint4*>(bm + t * wpt + w);
-        local_cnt += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
-      }
-      const int incl = (int)wave_inclusive_scan_u32((uint32_t)local_cnt);
-      if (lane == 63) wsum[wave] = (uint32_t)incl;
-      __syncthreads();
-      int run = incl - local_cnt;
-      for (int w = 0; w < wave; ++w) run += (int)wsum[w];
-      for (int w = 0; w < wpt; w += 4) {
-        const uint4 v = *reinterpret_cast<const uint4*>(bm + t * wpt + w);
-        const int r0 = run, r1 = r0 + __popc(v.x), r2_ = r1 + __popc(v.y), r3 = r2_ + __popc(v.z);
-        run = r3 + __popc(v.w);
-        *reinterpret_cast<uint2*>(pre + t * wpt + w) =
-            make_uint2((uint32_t)r0 | ((uint32_t)r1 << 16), (uint32_t)r2_ | ((uint32_t)r3 << 16));
-      }
-    }
-    __syncthreads();
-    // records whose rank falls into [win0, win0 + WIN) -> stage[rank - win0]
-    auto stage_records = [&](const float4 (&r)[BQC_RPT], int win0) {
-#pragma unroll
-      for (int u = 0; u < BQC_RPT; ++u) {
-        const int pi = __float_as_int(r[u].w);
-        if (pi >= 0) {
-          const int w = pi >> 5;
-          const int rank = pre[w] + __popc(bm[w] & ((1u << (pi & 31)) - 1u)) - win0;
-          if ((unsigned)rank < (unsigned)BQC_WIN) stage[rank] = r[u];
-        }
-      }
-    };
-    if (tot <= BQC_WIN) stage_records(p, 0);  // stays staged for every centre group
-
-    // ---- the quad's centres: wave w owns centres w, w + 4, ...; lane j holds centre
-    // c0 + w + 4 j and its running state
-    for (int c0 = 0; c0 < ccount; c0 += 64 * BQC_WAVES) {
-      const int ngrp = min(64 * BQC_WAVES, ccount - c0);
-      const int nmine = (ngrp - wave + BQC_WAVES - 1) / BQC_WAVES;  // centres of this wave
-      const float4 lc = crec[cstart + c0 + wave + BQC_WAVES * (lane < nmine ? lane : 0)];
-      const bool lexact = scene_ok && grid_coord_ok(lc.x, ox, inv_h) &&
-                          grid_coord_ok(lc.y, oy, inv_h) && grid_coord_ok(lc.z, oz, inv_h);
-      int st_cnt = 0, st_first = 0;
-      float st_fx = ox, st_fy = oy, st_fz = oz;  // rows without a hit are zeros = point 0
-      for (int win0 = 0; win0 < tot || win0 == 0; win0 += BQC_WIN) {
-        const bool last_win = win0 + BQC_WIN >= tot;
-        // ---- 2. ranks [win0, win0 + WIN) -> LDS
-        if (tot > BQC_WIN) {
-          __syncthreads();  // the previous window's readers are done
-          for (int q0 = 0; q0 < tot; q0 += BQC_WIN) {
-            float4 r[BQC_RPT];
-            load_records(r, q0);
-            stage_records(r, win0);
-          }
-        }
-        __syncthreads();
-        const int nwin = min(BQC_WIN, tot - win0);
-        // ---- 3. this wave's centres: index-order scan over the staged records
-        for (int j = 0; j < nmine; ++j) {
-          const float cx = bq_readlane_f(lc.x, j), cy = bq_readlane_f(lc.y, j),
-                      cz = bq_readlane_f(lc.z, j);
-          const int m = __builtin_amdgcn_readlane(__float_as_int(lc.w), j);
-          const bool exact = __builtin_amdgcn_readlane((int)lexact, j) != 0;
-          IdxT* __restrict__ out_row = idx + ((size_t)b * M + m) * K;
-          IdxT* __restrict__ out_cnt = cnt_out + (size_t)b * M + m;
-          float* __restrict__ gx = GROUP ? grouped + (size_t)b * 3 * MK + (size_t)m * K : nullptr;
-          if (!exact) {
-            if (win0 == 0) {
-              bq_scan_centroid<FMAD, IdxT>(px, py, pz, N, cx, cy, cz, r2, K, lane, out_row,
-                                           out_cnt);
-              if constexpr (GROUP) {
-                __threadfence_block();
-                for (int k = lane; k < K; k += 64) {
-                  const int v = (int)out_row[k];
-                  gx[k] = px[v];
-                  gx[MK + k] = py[v];
-                  gx[2 * MK + k] = pz[v];
-                }
-              }
-            }
-            continue;
-          }
-          int cnt = __builtin_amdgcn_readlane(st_cnt, j);
-          if (cnt >= K) continue;  // finished in an earlier window
-          const int cnt0 = cnt;    // out_row[0 .. cnt0) left with the earlier windows
-          int first = __builtin_amdgcn_readlane(st_first, j);
-          float fx = bq_readlane_f(st_fx, j), fy = bq_readlane_f(st_fy, j),
-                fz = bq_readlane_f(st_fz, j);
-          for (int u0 = 0; u0 < nwin && cnt < K; u0 += 64 * BQ_UNROLL) {
-            float4 s[BQ_UNROLL];
-#pragma unroll
-            for (int u = 0; u < BQ_UNROLL; ++u)
-              if (u0 + 64 * u < nwin) s[u] = stage[min(u0 + 64 * u + lane, BQC_WIN - 1)];
-#pragma unroll
-            for (int u = 0; u < BQ_UNROLL; ++u) {
-              if (u0 + 64 * u < nwin && cnt < K) {
-                const bool hit = (u0 + 64 * u + lane < nwin) &&
-                                 dist2<FMAD>(cx, cy, cz, s[u].x, s[u].y, s[u].z) < r2;
-                const uint64_t mask = __ballot(hit);
-                if (mask != 0) {
-                  const int pos = cnt + mask_rank(mask);
-                  if (hit && pos < K) {
-                    orow[pos] = __float_as_int(s[u].w);
-                    if constexpr (GROUP) {
-                      ogx[pos] = s[u].x;
-                      ogx[Kp + pos] = s[u].y;
-                      ogx[2 * Kp + pos] = s[u].z;
-                    }
-                  }
-                  if (cnt == 0) {
-                    const int fl = __ffsll((unsigned long long)mask) - 1;
-                    first = __builtin_amdgcn_readlane(__float_as_int(s[u].w), fl);
-                    if constexpr (GROUP) {
-                      fx = bq_readlane_f(s[u].x, fl);
-                      fy = bq_readlane_f(s[u].y, fl);
-                      fz = bq_readlane_f(s[u].z, fl);
-                    }
-                  }
-                  cnt += __popcll(mask);
-                }
-              }
-            }
-          }
-          if (last_win || cnt >= K) {
-            if (cnt > K) cnt = K;
-            if (lane == j) st_cnt = K;
-            for (int k = cnt0 + lane; k < K; k += 64) {
-              out_row[k] = (IdxT)(k < cnt ? orow[k] : first);
-              if constexpr (GROUP) {
-                gx[k] = k < cnt ? ogx[k] : fx;
-                gx[MK + k] = k < cnt ? ogx[Kp + k] : fy;
-                gx[2 * MK + k] = k < cnt ? ogx[2 * Kp + k] : fz;
-              }
-            }
-            if (lane == 0) *out_cnt = (IdxT)cnt;
-          } else {
-            for (int k = cnt0 + lane; k < cnt; k += 64) {  // this window's hits
-              out_row[k] = (IdxT)orow[k];
-              if constexpr (GROUP) {
-                gx[k] = ogx[k];
-                gx[MK + k] = ogx[Kp + k];
-                gx[2 * MK + k] = ogx[2 * Kp + k];
-              }
-            }
-            if (lane == j) {
-              st_cnt = cnt;
-              st_first = first;
-              st_fx = fx;
-              st_fy = fy;
-              st_fz = fz;
-            }
-          }
-        }
-        if (!last_win &&
-            __syncthreads_and((int)__all(lane >= nmine || !lexact || st_cnt >= K)))
-          break;
-      }
-    }
-    __syncthreads();  // every rank lookup and staged read of this quad is done
-    for (int w = 0; w < wpt; w += 4)  // clean bitmap for the next quad
-      *reinterpret_cast<uint4*>(bm + t * wpt + w) = make_uint4(0u, 0u, 0u, 0u);
-  }
-}
+#ifdef S4G_VARIANTS
+#include "variants/bq_cell.inc"
+#endif
 
 int launch_grid_build(const float* xyz, int64_t B, int64_t N, float inv_h, GridWs ws,
                       hipStream_t st, bool write_aos, const float* inv_h_dev) {
@@ -832,7 +532,12 @@ static bool bq_use_grid(int64_t N, int64_t K) {
 // OPT-IN (S4G_BQ_MODE=cell): exact, but as built it is slower than the per-centre
 // kernel (SA1, 16 scenes: 0.142 ms against 0.116 ms) -- see the CELL path's header.
 static bool bq_use_cell(int64_t M) {
+#ifdef S4G_VARIANTS
   return bq_mode() == BQ_CELL && M >= 1 && M < (1 << 24);
+#else
+  (void)M;
+  return false;   // the cell-centric kernel is in measurement builds only: S4G_BQ_MODE=cell then means grid
+#endif
 }
 
 size_t ball_query_workspace_bytes(int64_t B, int64_t N, int64_t M, int64_t K) {
@@ -878,6 +583,7 @@ static int ball_query_dispatch(const float* xyz, const float* ctr, int64_t B,
   const int words = (int)((N + 31) / 32);
   int wpl = (words + 63) / 64;
   if ((wpl & 1) == 0) ++wpl;  // odd stride: conflict-free per-lane word runs
+#ifdef S4G_VARIANTS
   if (bq_use_cell(M) && ws_bytes >= grid_ws_bytes(B, N) + cell_ws_bytes(B, M)) {
     const CellWs cw = cell_ws_carve((char*)ws + grid_ws_bytes(B, N), B, M);
     if (int rc = launch_grid_build_queries(xyz, ctr, B, N, M, inv_h, g, cw, st, false)) return rc;
@@ -905,6 +611,7 @@ static int ball_query_dispatch(const float* xyz, const float* ctr, int64_t B,
     S4G_LAUNCH_CHECK();
     return S4G_OK;
   }
+#endif
   if (int rc = launch_grid_build(xyz, B, N, inv_h, g, st, grouped != nullptr)) return rc;
   const size_t lds = sizeof(uint32_t) * BQ_WAVES_PER_BLOCK * (size_t)(64 * wpl + ((K + 3) & ~3));
 #define S4G_BQ_LAUNCH4(F, G, W, C)                                                        \

@@ -19,8 +19,9 @@
 //   * fps_pruned_l2_kernel  25 600 < N <= 51 200 (default there): the same, with only the
 //                           min-distances resident and the coordinates of a touched group read
 //                           from the Morton-sorted records in L2 -- one CU per scene;
-//   * fps_cluster_kernel / fps_hybrid_kernel: full scans for that size on two CUs / one CU
-//                           (S4G_FPS_MODE=cluster|hybrid), fps_stream_kernel beyond 51 200.
+//   * fps_stream_kernel     any other size (and 25 600 < N <= 51 200 without a workspace); the two full-scan
+//                           kernels for that range (variants/fps_fullscan_51k.inc: S4G_FPS_MODE=cluster|hybrid)
+//                           are compiled into measurement builds only (-DS4G_VARIANTS).
 // The reference's tie rule is reproduced exactly through a composite key: maximise d, then
 // minimise (bitrev_{log2 bs}(j mod bs) << 23 | j), where bs = clamp(pow2ceil(N),16,512) is the
 // REFERENCE's block size (sampling_kernel.cu:34-42,148-167) -- see SURVEY.md Appendix A.1.  In
@@ -139,102 +140,6 @@ __device__ __forceinline__ void fps_block_exchange(FpsSlot* slots, int wave,
 // commute, so all picks of an exchange are applied together before the next candidates are taken.
 // Everything is wave-uniform and every wave decides alike.  Returns the number of picks (>= 1).
 template <int WAVES, bool FMAD, int MAXP, typename IdxT>
-__device__ __forceinline__ int fps_block_exchange_multi_v(FpsSlot* slots, int wave, int lane, uint32_t wmax,
-                                                        uint32_t wtie, uint32_t wd2, float sx, float sy,
-                                                        float sz, int limit, int& cur, float& cx, float& cy,
-                                                        float& cz, uint32_t& picked_waves,
-                                                        IdxT* __restrict__ out_i, float* __restrict__ cout_i,
-                                                        int M, float& fx, float& fy, float& fz,
-                                                        float* __restrict__ dout_i = nullptr) {
-  if (lane == 0) {
-    FpsSlot s;
-    s.d = wmax;
-    s.tie = wtie;
-    s.x = sx;
-    s.y = sy;
-    s.z = sz;
-    s.d2 = wd2;
-    s.pad[0] = s.pad[1] = 0;
-    slots[wave] = s;
-  }
-  __syncthreads();
-  const FpsSlot s = slots[lane & (WAVES - 1)];
-  const uint64_t first = (1ull << WAVES) - 1ull;
-  uint32_t v = s.d;          // this entry's current min-distance bits (0: picked / nothing left)
-  uint32_t bnd = 0u;         // largest runner-up distance of the disturbed waves
-  int np = 0;
-  uint32_t pw = 0u;          // picked entries (= wave numbers), 4 bits each: the callers re-read their
-                             // coordinates from this exchange buffer instead of keeping 3 MAXP registers
-  // lane k keeps pick k for ONE store per output array (wave 0 writes)
-  int my_idx = 0;
-  float my_x = 0.f, my_y = 0.f, my_z = 0.f;
-  uint32_t my_d = 0u;
-#pragma unroll
-  for (int k = 0; k < MAXP; ++k) {
-    if (k >= limit) break;
-    const uint32_t bmax = row16_max_u32(v);
-    if (k > 0 && (bmax == 0u || bmax <= bnd)) break;
-    uint64_t win = __ballot(v == bmax) & first;
-    uint32_t btie;
-    if (__popcll(win) > 1) {
-      const uint32_t cand = (v == bmax) ? s.tie : 0xFFFFFFFFu;
-      btie = __builtin_amdgcn_readlane(row16_min_u32(cand), 0);
-      win = __ballot(v == bmax && s.tie == btie) & first;
-    } else {
-      btie = __builtin_amdgcn_readlane(s.tie, __ffsll((unsigned long long)win) - 1);
-    }
-    const int xl = __ffsll((unsigned long long)win) - 1;
-    cx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.x), xl));
-    cy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.y), xl));
-    cz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s.z), xl));
-    cur = (int)(btie & FPS_JMASK);
-    pw |= (uint32_t)xl << (4 * k);
-    np = k + 1;
-    if (lane == k) {
-      my_idx = cur;
-      my_x = cx;
-      my_y = cy;
-      my_z = cz;
-      my_d = bmax;   // the pick's min-distance at the time it is taken (re-ranked exactly for k > 0)
-    }
-    if (k == 0) {   // (callers that keep the pending centroids in registers: MAXP == 2)
-      fx = cx;
-      fy = cy;
-      fz = cz;
-    }
-    if (k + 1 < MAXP) {
-      // the picked wave is disturbed; the other candidates' values after this pick, exactly
-      const bool me = (lane & (WAVES - 1)) == xl;
-      const uint32_t nd = __float_as_uint(dist2<FMAD>(cx, cy, cz, s.x, s.y, s.z));
-      const bool lowered = !me && v != 0u && nd < v;
-      v = me ? 0u : (lowered ? nd : v);
-      const uint32_t dl = (me || lowered) ? s.d2 : 0u;
-      bnd = max(bnd, (uint32_t)__builtin_amdgcn_readlane(row16_max_u32(dl), 0));
-    }
-  }
-  if (wave == 0 && lane < np) {
-    out_i[lane] = (IdxT)my_idx;
-    if (cout_i) {
-      cout_i[lane] = my_x;
-      cout_i[M + lane] = my_y;
-      cout_i[2 * M + lane] = my_z;
-    }
-    if (dout_i) dout_i[lane] = __uint_as_float(my_d);
-  }
-  picked_waves = pw;
-  return np;
-}
-
-// The same decisions with a third of the instructions.  A wave issues at most one instruction per
-// four cycles and everything here is one dependent chain, so the exchange costs its instruction
-// COUNT (the form above: ~100 per pick, ~900 cycles; a version on the scalar unit with ~250 cheap
-// instructions per pick measured 8.1 instead of 4.8 ms).  What went: the pick-to-candidate distances
-// of ALL 8 x 8 pairs are one dist2 over 64 lanes before the first round (lane 8 i + j: entry i as the
-// pick, entry j as the candidate) and a round fetches its row with one ds_bpermute; the picks'
-// coordinates and indices are not carried through the rounds at all -- lane k of wave 0 re-reads
-// pick k's entry from the exchange buffer once at the end, the callers' centroid comes from three
-// readlanes after the loop; reductions run over the 8 distinct lanes (three DPP steps).
-template <int WAVES, bool FMAD, int MAXP, typename IdxT>
 __device__ __forceinline__ int fps_block_exchange_multi(FpsSlot* slots, int wave, int lane, uint32_t wmax,
                                                         uint32_t wtie, uint32_t wd2, float sx, float sy,
                                                         float sz, int limit, int& cur, float& cx, float& cy,
@@ -242,11 +147,6 @@ __device__ __forceinline__ int fps_block_exchange_multi(FpsSlot* slots, int wave
                                                         IdxT* __restrict__ out_i, float* __restrict__ cout_i,
                                                         int M, float& fx, float& fy, float& fz,
                                                         float* __restrict__ dout_i = nullptr) {
-#ifdef S4G_FPS_XCHG_OLD
-  return fps_block_exchange_multi_v<WAVES, FMAD, MAXP, IdxT>(slots, wave, lane, wmax, wtie, wd2, sx, sy, sz, limit,
-                                                             cur, cx, cy, cz, picked_waves, out_i, cout_i, M, fx,
-                                                             fy, fz, dout_i);
-#else
   static_assert(WAVES == 8, "eight entries: the pick x candidate matrix is the wave's 64 lanes");
   if (lane == 0) {
     FpsSlot s;
@@ -330,7 +230,6 @@ __device__ __forceinline__ int fps_block_exchange_multi(FpsSlot* slots, int wave
   }
   picked_waves = pw;
   return np;
-#endif
 }
 
 // Read (x[pw], y[pw], z[pw]) of lane `wl` into wave-uniform values.  `pw` is
@@ -492,335 +391,9 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(
   }
 }
 
-// Hybrid variant for 25 600 < N <= 51 200: x and the running min-distance of a
-// lane's 100 points stay in VGPRs (200 registers), y and z are re-read from L2 every
-// step (410 KB per step and scene, coalesced dword loads, batches of FB slots in
-// flight).  A step then moves 410 KB instead of the streaming kernel's 1 MB through the
-// CU's L2 port: 6.5 us per step (63 GB/s, the per-CU L2 read rate this access pattern
-// reaches; 8-byte (y, z) pair loads and 16 waves measured the same) against 16.6 us.  Same ownership
-// (j = t + 512 p), tie rule and exchange as fps_reg_kernel; the winner's coordinates
-// are re-read by index (three L2 hits) instead of through a 100-leaf register tree.
-template <int THREADS, int PPT, int FB, bool FMAD, typename IdxT>
-__global__ __launch_bounds__(THREADS) void fps_hybrid_kernel(const float* __restrict__ xyz, int N, int M,
-                                                             IdxT* __restrict__ idx,
-                                                             float* __restrict__ ctr, int lg_bs) {
-  constexpr int WAVES = THREADS / 64;
-  static_assert(PPT % FB == 0 && FB % 2 == 0, "batches of point pairs");
-  __shared__ FpsSlot slots[2][FPS_MAX_WAVES];
-  const int b = blockIdx.x;
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = t >> 6;
-  const float* __restrict__ px = xyz + (size_t)b * 3 * N;
-  const float* __restrict__ py = px + N;
-  const float* __restrict__ pz = py + N;
-  IdxT* __restrict__ out = idx + (size_t)b * M;
-  float* __restrict__ cout = ctr ? ctr + (size_t)b * 3 * M : nullptr;
-
-  float x[PPT], md[PPT];
-#pragma unroll
-  for (int p = 0; p < PPT; ++p) {
-    const int j = t + THREADS * p;
-    const bool ok = j < N;
-    x[p] = px[ok ? j : 0];
-    md[p] = ok ? __builtin_inff() : -1.0f;   // padding never beats best = 0
-  }
-  const uint32_t bs_mask = (1u << lg_bs) - 1u;
-  const uint32_t rkey = (__brev((uint32_t)t & bs_mask) >> (32 - lg_bs)) << 23;
-  const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)py, 0, N * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t z_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pz, 0, N * 4, 0x00020000);
-  const int voff = t * 4;
-
-  int cur = 0;
-  float cx = px[0], cy = py[0], cz = pz[0];
-  if (t == 0) {
-    out[0] = 0;
-    if (cout) {
-      cout[0] = cx;
-      cout[M] = cy;
-      cout[2 * M] = cz;
-    }
-  }
-
-  for (int i = 1; i < M; ++i) {
-    float best = 0.0f;
-    int bestp = -1;
-    const fps_v2f cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
-    // batches of FB slots, the next batch's loads in flight while this one is scanned
-    // (scheduling barriers keep the compiler from hoisting all 200 loads: spills)
-    float yb[2][FB], zb[2][FB];
-    // buffer loads: one VGPR lane offset (4 t), the slot offset is a scalar constant and the
-    // hardware range check returns 0 for padding slots -- no per-load address registers
-    auto fetch = [&](int p0, float (&yy)[FB], float (&zz)[FB]) {
-#pragma unroll
-      for (int e = 0; e < FB; ++e) {
-        const int soff = THREADS * 4 * (p0 + e);
-        yy[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(y_rsrc, voff, soff, 0));
-        zz[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(z_rsrc, voff, soff, 0));
-      }
-    };
-    fetch(0, yb[0], zb[0]);
-#pragma unroll
-    for (int p0 = 0; p0 < PPT; p0 += FB) {
-      constexpr int dummy = 0;
-      (void)dummy;
-      const int cb = (p0 / FB) & 1;
-      if (p0 + FB < PPT) fetch(p0 + FB, yb[cb ^ 1], zb[cb ^ 1]);
-#pragma unroll
-      for (int e = 0; e < FB; e += 2) {
-        const int p = p0 + e;
-        const fps_v2f xv = {x[p], x[p + 1]}, yv = {yb[cb][e], yb[cb][e + 1]}, zv = {zb[cb][e], zb[cb][e + 1]};
-        const fps_v2f dx = xv - cx2, dy = yv - cy2, dz = zv - cz2;
-        fps_v2f d;
-        if constexpr (FMAD) {
-          d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-        } else {
-          d = (dx * dx + dy * dy) + dz * dz;
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          float m;
-          asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(d[q]), "v"(md[p + q]));
-          md[p + q] = m;
-          if (m > best) {
-            best = m;
-            bestp = p + q;
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    const uint32_t jbest = (bestp < 0) ? (uint32_t)cur : (uint32_t)(t + THREADS * bestp);
-    // this lane's candidate coordinates (L2 hits: the whole cloud was just read)
-    const float bx = px[jbest], by = py[jbest], bz = pz[jbest];
-    const uint32_t tie = rkey | jbest;
-    const uint32_t dbits = __float_as_uint(best);
-    const uint32_t wmax = wave_max_u32(dbits);
-    uint64_t win = __ballot(dbits == wmax);
-    uint32_t wtie;
-    if (__popcll(win) > 1) {
-      wtie = wave_min_u32((dbits == wmax) ? tie : 0xFFFFFFFFu);
-      win = __ballot(dbits == wmax && tie == wtie);
-    } else {
-      wtie = __builtin_amdgcn_readlane(tie, __ffsll((unsigned long long)win) - 1);
-    }
-    const int wl = __ffsll((unsigned long long)win) - 1;
-    const float sx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bx), wl));
-    const float sy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(by), wl));
-    const float sz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bz), wl));
-    fps_block_exchange<WAVES>(slots[i & 1], wave, lane, wmax, wtie, sx, sy, sz, cur, cx, cy, cz);
-    if (t == 0) {
-      out[i] = (IdxT)cur;
-      if (cout) {
-        cout[i] = cx;
-        cout[M + i] = cy;
-        cout[2 * M + i] = cz;
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Two-CU cluster for 25 600 < N <= 51 200 points.
-//
-// One CU's register file holds 25 600 points (512 threads x 50 x 4 floats); the hybrid kernel
-// above keeps only x and the min-distances there and re-reads y / z from L2 every step (6.5 us
-// per step, bound by one CU's L2 read rate).  Here TWO workgroups share a scene, each with half
-// of the points entirely in registers (fps_reg_kernel's loop on q = h * PPT + p, so a thread's
-// points still share j mod bs and the tie rule is untouched), and the two local winners are
-// exchanged through L2 once per step:
-//   * wave 0, lanes 0..4 publish (distance bits, tie key, x, y, z) as five naturally aligned
-//     8-byte {payload, step} granules, each ONE write-through store (agent-scope relaxed atomic
-//     = global_store_dwordx2 sc1), into the slot of this step's parity;
-//   * the same lanes poll the partner's five granules with L1-bypassing loads until every tag
-//     equals the step number -- a granule validates itself, so no fence and no separate flag
-//     (MI355X_MICROARCH.md hand-off price list: ~1 us per hop);
-//   * both sides then pick the winner by the same rule (larger distance, then smaller tie key)
-//     and hand it to their other waves through LDS (one more barrier).
-// Slot reuse is safe without further synchronisation: a workgroup can be at most one step ahead
-// of its partner (it needs the partner's record of step i to leave step i), and step i + 2
-// reuses step i's slot.  The tags of a previous launch never match because the caller zeroes
-// the exchange buffer (step numbers start at 1).  Every poll loop is bounded: a partner that
-// never shows up (which would mean the two workgroups are not co-resident for seconds) sets an
-// error flag instead of hanging the device.
-struct FpsXch {
-  unsigned long long g[8];   // 5 granules used; 64 bytes per (scene, parity, half)
-};
-constexpr int FPS_XCH_SPIN = 1 << 24;
-
-template <int THREADS, int PPT, bool FMAD, typename IdxT>
-__global__ __launch_bounds__(THREADS) void fps_cluster_kernel(
-    const float* __restrict__ xyz, int N, int M, IdxT* __restrict__ idx, float* __restrict__ ctr,
-    int lg_bs, FpsXch* __restrict__ xch, int* __restrict__ err) {
-  constexpr int WAVES = THREADS / 64;
-  __shared__ FpsSlot slots[2][FPS_MAX_WAVES];
-  __shared__ FpsSlot glob[2];
-  const int b = blockIdx.x >> 1;
-  const int h = blockIdx.x & 1;           // which half of the points this workgroup owns
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = t >> 6;
-  const float* __restrict__ px = xyz + (size_t)b * 3 * N;
-  const float* __restrict__ py = px + N;
-  const float* __restrict__ pz = py + N;
-  IdxT* __restrict__ out = idx + (size_t)b * M;
-  float* __restrict__ cout = ctr ? ctr + (size_t)b * 3 * M : nullptr;
-  FpsXch* __restrict__ xb = xch + (size_t)b * 4;   // [parity][half]
-
-  float x[PPT], y[PPT], z[PPT], md[PPT];
-  const int jbase = t + THREADS * PPT * h;
-#pragma unroll
-  for (int p = 0; p < PPT; ++p) {
-    const int j = jbase + THREADS * p;
-    const bool ok = j < N;
-    const int jj = ok ? j : 0;
-    x[p] = px[jj];
-    y[p] = py[jj];
-    z[p] = pz[jj];
-    md[p] = ok ? __builtin_inff() : -1.0f;
-  }
-  const uint32_t bs_mask = (1u << lg_bs) - 1u;
-  const uint32_t rkey = (__brev((uint32_t)t & bs_mask) >> (32 - lg_bs)) << 23;
-
-  int cur = 0;
-  float cx = px[0], cy = py[0], cz = pz[0];
-  if (t == 0 && h == 0) {
-    out[0] = 0;
-    if (cout) {
-      cout[0] = cx;
-      cout[M] = cy;
-      cout[2 * M] = cz;
-    }
-  }
-  bool dead = false;   // the partner never answered: finish the loop without waiting again
-
-  for (int i = 1; i < M; ++i) {
-    float best = 0.0f;
-    int bestp = -1;
-    const fps_v2f cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
-#pragma unroll
-    for (int p = 0; p + 1 < PPT; p += 2) {
-      const fps_v2f xv = {x[p], x[p + 1]}, yv = {y[p], y[p + 1]}, zv = {z[p], z[p + 1]};
-      const fps_v2f dx = xv - cx2, dy = yv - cy2, dz = zv - cz2;
-      fps_v2f d;
-      if constexpr (FMAD) {
-        d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-      } else {
-        d = (dx * dx + dy * dy) + dz * dz;
-      }
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        float m;
-        asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(d[e]), "v"(md[p + e]));
-        md[p + e] = m;
-        if (m > best) {
-          best = m;
-          bestp = p + e;
-        }
-      }
-    }
-    static_assert((PPT & 1) == 0, "points are scanned in pairs");
-    const uint32_t jbest = (bestp < 0) ? (uint32_t)cur : (uint32_t)(jbase + THREADS * bestp);
-    const uint32_t tie = rkey | jbest;
-    const uint32_t dbits = __float_as_uint(best);
-    const uint32_t wmax = wave_max_u32(dbits);
-    uint64_t win = __ballot(dbits == wmax);
-    uint32_t wtie;
-    if (__popcll(win) > 1) {
-      wtie = wave_min_u32((dbits == wmax) ? tie : 0xFFFFFFFFu);
-      win = __ballot(dbits == wmax && tie == wtie);
-    } else {
-      wtie = __builtin_amdgcn_readlane(tie, __ffsll((unsigned long long)win) - 1);
-    }
-    const int wl = __ffsll((unsigned long long)win) - 1;
-    const int pw = __builtin_amdgcn_readlane(bestp, wl);
-    float sx = cx, sy = cy, sz = cz;
-    if (pw >= 0) fps_pick<PPT, 0, PPT>(x, y, z, pw, wl, sx, sy, sz);
-    // ---- this workgroup's winner (every wave computes it from the LDS slots)
-    if (lane == 0) {
-      FpsSlot s;
-      s.d = wmax;
-      s.tie = wtie;
-      s.x = sx;
-      s.y = sy;
-      s.z = sz;
-      s.pad[0] = s.pad[1] = s.pad[2] = 0;
-      slots[i & 1][wave] = s;
-    }
-    __syncthreads();
-    if (wave == 0) {
-      const FpsSlot s = slots[i & 1][lane & (WAVES - 1)];
-      const uint32_t bmax = row16_max_u32(s.d);
-      uint64_t w2 = __ballot(s.d == bmax) & ((1ull << WAVES) - 1ull);
-      uint32_t btie;
-      if (__popcll(w2) > 1) {
-        const uint32_t cand = (s.d == bmax) ? s.tie : 0xFFFFFFFFu;
-        btie = __builtin_amdgcn_readlane(row16_min_u32(cand), 0);
-        w2 = __ballot(s.d == bmax && s.tie == btie);
-      } else {
-        btie = __builtin_amdgcn_readlane(s.tie, __ffsll((unsigned long long)w2) - 1);
-      }
-      const int l2 = __ffsll((unsigned long long)w2) - 1;
-      const uint32_t ld = __builtin_amdgcn_readlane(bmax, 0);
-      const uint32_t lx = __builtin_amdgcn_readlane(__float_as_uint(s.x), l2);
-      const uint32_t ly = __builtin_amdgcn_readlane(__float_as_uint(s.y), l2);
-      const uint32_t lz = __builtin_amdgcn_readlane(__float_as_uint(s.z), l2);
-      // ---- exchange with the partner workgroup: five {payload, step} granules
-      const uint32_t mine = lane == 0 ? ld : lane == 1 ? btie : lane == 2 ? lx : lane == 3 ? ly : lz;
-      unsigned long long theirs = 0;
-      if (lane < 5) {
-        __hip_atomic_store(&xb[(i & 1) * 2 + h].g[lane], ((unsigned long long)(uint32_t)i << 32) | mine,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (!dead) {
-        int spins = 0;
-        for (;;) {
-          if (lane < 5)
-            theirs = __hip_atomic_load(&xb[(i & 1) * 2 + (h ^ 1)].g[lane], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-          const bool ready = lane >= 5 || (uint32_t)(theirs >> 32) == (uint32_t)i;
-          if (__all(ready)) break;
-          if (++spins > FPS_XCH_SPIN) {
-            dead = true;
-            if (lane == 0) atomicExch(err, 1);
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
-      const uint32_t tv = (uint32_t)theirs;
-      const uint32_t rd = __builtin_amdgcn_readlane(tv, 0), rtie = __builtin_amdgcn_readlane(tv, 1);
-      const bool remote = !dead && (rd > ld || (rd == ld && rtie < btie));
-      if (lane == 0) {
-        FpsSlot gsl;
-        gsl.d = dead ? 1u : 0u;
-        gsl.tie = remote ? rtie : btie;
-        gsl.x = __uint_as_float(remote ? __builtin_amdgcn_readlane(tv, 2) : lx);
-        gsl.y = __uint_as_float(remote ? __builtin_amdgcn_readlane(tv, 3) : ly);
-        gsl.z = __uint_as_float(remote ? __builtin_amdgcn_readlane(tv, 4) : lz);
-        gsl.pad[0] = gsl.pad[1] = gsl.pad[2] = 0;
-        glob[i & 1] = gsl;
-      }
-    }
-    __syncthreads();
-    {
-      const FpsSlot gsl = glob[i & 1];
-      cur = (int)(gsl.tie & FPS_JMASK);
-      cx = gsl.x;
-      cy = gsl.y;
-      cz = gsl.z;
-      dead = gsl.d != 0u;
-    }
-    if (t == 0 && h == 0) {
-      out[i] = dead ? (IdxT)-1 : (IdxT)cur;   // a scene whose partner never answered is marked, not guessed
-      if (cout) {
-        cout[i] = cx;
-        cout[M + i] = cy;
-        cout[2 * M + i] = cz;
-      }
-    }
-  }
-}
+#ifdef S4G_VARIANTS
+#include "variants/fps_fullscan_51k.inc"
+#endif
 
 // Streaming fallback: any N < 2^23.  min-distance in `temp` (B,N) fp32.
 template <bool FMAD, typename IdxT>
@@ -1830,11 +1403,15 @@ static int ref_block_lg(int64_t n) {
 // -1 (the caller sees an impossible index instead of a plausible wrong one).  Everything else in
 // this size range that cannot take the pruned kernel (M < 64, workspace too small) runs the
 // single-CU hybrid kernel, which has no such requirement.
+#ifdef S4G_VARIANTS
 static bool fps_use_cluster(int64_t B) {
   const char* e = getenv("S4G_FPS_MODE");
   return e && e[0] == 'c' && 2 * B <= 256;
 }
 static size_t fps_cluster_ws_bytes(int64_t B) { return (size_t)B * 4 * sizeof(FpsXch) + 64; }
+#else
+static size_t fps_cluster_ws_bytes(int64_t) { return 0; }
+#endif
 
 // ---------------------------------------------------------------------------
 // FPS of an FPS-ordered set is its own prefix.  Let c_0 .. c_{M1-1} be the picks of one FPS run in
@@ -1904,8 +1481,6 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
                       hipStream_t stream, FpsExtra ex = FpsExtra{nullptr, nullptr}) {
   const int lg = ref_block_lg(N);
   const dim3 grid((unsigned)B);
-  int variant = 0;  // S4G_FPS_THREADS=1024 (tuning knob)
-  if (const char* e = getenv("S4G_FPS_THREADS")) variant = atoi(e);
 
   // opt-in pruned variant: Morton order + group boxes, the first FPS_DENSE_STEPS steps by
   // the full-scan kernel (which leaves its min-distances in the workspace), the rest pruned
@@ -1942,9 +1517,6 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
     S4G_LAUNCH_CHECK();                                                      \
     launched = true;                                                         \
   }
-  if (variant == 1024) {
-    S4G_FPS_CASE(1024, 25)
-  }
   // small levels: fewer waves = cheaper exchange (measured: 512x2 beats 1024x1 at N=1024)
   S4G_FPS_CASE(256, 1)
   S4G_FPS_CASE(512, 1)
@@ -1956,8 +1528,7 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
   S4G_FPS_CASE(512, 50)
 #undef S4G_FPS_CASE
   if (launched && pruned) {
-  // picks one exchange may settle: S4G_FPS_SPEC=0 (or 1): one, 2: round 2's two, default 4
-  static const int spec = [] { const char* e = getenv("S4G_FPS_SPEC"); const int v = e ? atoi(e) : 4; return v <= 1 ? 1 : (v < 4 ? 2 : 4); }();
+  // up to four picks per exchange (one and two -- rounds 1 and 2 -- measured slower: 6.7 / 6.0 / 4.0 ms)
 #define S4G_FPS_PRUNED_LAUNCH(T, P, S)                                                             \
   {                                                                                                \
     static LdsAttrCache lds_cache;                                                                 \
@@ -1969,7 +1540,7 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
 #define S4G_FPS_PRUNED(T, P)                                                                       \
   if (N <= (int64_t)T * P) {                                                                       \
     const size_t lds = sizeof(uint16_t) * T * P;                                                   \
-    if (spec == 4) S4G_FPS_PRUNED_LAUNCH(T, P, 4) else if (spec == 2) S4G_FPS_PRUNED_LAUNCH(T, P, 2) else S4G_FPS_PRUNED_LAUNCH(T, P, 1) \
+    S4G_FPS_PRUNED_LAUNCH(T, P, 4)                                                                 \
     S4G_LAUNCH_CHECK();                                                                            \
     return S4G_OK;                                                                                 \
   }
@@ -1993,6 +1564,7 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
     }
   }
   if (ex.dist) return S4G_EUNSUPPORTED;   // the remaining kernels do not report pick distances
+#ifdef S4G_VARIANTS
   // opt-in: two workgroups per scene, all points in registers, winners exchanged through L2 once
   // per step (see fps_use_cluster for the co-residency requirement)
   if (N <= (int64_t)512 * 100 && fps_use_cluster(B) && ws && ws_bytes >= fps_cluster_ws_bytes(B)) {
@@ -2011,6 +1583,8 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
     S4G_LAUNCH_CHECK();
     return S4G_OK;
   }
+#endif
+  // (default build: what the pruned kernel cannot take in this range -- M < 64, no workspace -- streams)
   if (ws_bytes < (size_t)B * (size_t)N * sizeof(float) || ws == nullptr)
     return S4G_EWORKSPACE;
   hipLaunchKernelGGL((fps_stream_kernel<FMAD, IdxT>), grid, dim3(FPS_THREADS), 0, stream,

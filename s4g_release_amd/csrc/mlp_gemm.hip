@@ -28,7 +28,8 @@
 //   mlp_gemm_bf16x3_kernel           three bf16 planes, six products: exact-class alternative
 //   mlp_gemm_f16x2_kernel            two fp16 planes, three products (fp32-class; PL = 1: one bf16
 //                                    plane): the tiled single-layer form, both operands through LDS
-//   mlp_gemm_f16x2_resident_kernel   short contractions with the A panel resident in LDS
+//   mlp_gemm_f16x2_resident_kernel   short contractions with the A panel resident in LDS (measurement
+//                                    builds only: variants/gemm_resident.inc)
 //   mlp_chain_kernel                 two or three layers per launch, intermediates in LDS, W streamed
 //                                    in MFMA-fragment order: the kernels the shipped network runs on
 // (the four heads as one launch live in mlp_heads.hip, helpers shared by both in mlp_common.h).
@@ -998,277 +999,11 @@ static int launch_gemm_f16x2_cfg(GemmParams p, int groups, hipStream_t st) {
   return S4G_OK;
 }
 
-// ---------------------------------------------------------------------------
-// f16x2, resident-A variant for short contractions (K <= 256).
-//
-// A workgroup owns BM = 64 * RW positions and ALL output channels.  Its A panel
-// (BM x K) is loaded, scaled and split ONCE into two fp16 planes that stay in LDS;
-// the four waves then walk the channel strips on their own -- no barrier after the
-// prologue.  W never touches LDS: the host stores its planes in MFMA-fragment
-// order ([n/32][k/16][plane][lane][8 halves]), so a wave reads each fragment as one
-// coalesced 1 KB load straight into the operand registers, prefetched RING steps
-// (16 k each) ahead.  Per 16-deep step a wave issues 4 LDS reads + 4 global loads
-// for 12 MFMAs, and the A panel is neither re-fetched nor re-split per channel
-// tile (the tiled kernel does both Cout/128 times).
-//   RW x CW = 4 waves: CW = 4 (BM = 64) for Cout % 256 == 0, CW = 2 (BM = 128)
-//   for Cout % 128 == 0.  LDS = BM * (K + 8) * 4 bytes <= 80 KB: two workgroups
-//   per CU.
-// STORE epilogue: the MFMA operands are swapped (D = W A^T), so a lane holds four
-// CONSECUTIVE channels of one position per register quad -> float4 stores with
-// no LDS staging.  MAX keeps D = A W^T (the row max is an in-register max).
-// ---------------------------------------------------------------------------
-constexpr int GR_RING = 4;   // W fragment prefetch depth in 16-deep steps
-
-template <int LOADER, int EPI, int RW, int KT>
-__global__ __launch_bounds__(256, 2) void mlp_gemm_f16x2_resident_kernel(const GemmParams p) {
-  constexpr int CW = 4 / RW;
-  constexpr int BM = 64 * RW;
-  constexpr int RPT = BM / 32, RS = 32;
-  constexpr bool SWAP = EPI == EPI_STORE;
-  extern __shared__ __attribute__((aligned(16))) float smemf[];
-  uint16_t* Ah = reinterpret_cast<uint16_t*>(smemf);   // [2][BM][K + 8]
-  constexpr int K = KT;                   // compile time: every LDS / fragment offset is an immediate
-  constexpr int astr = K + 8;             // halves per row: (K/8 + 1) odd -> conflict-free reads
-  constexpr int aplane = BM * astr;
-
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = t >> 6;
-  const int g = blockIdx.y;
-  const int p0 = blockIdx.x * BM;
-  const float* __restrict__ bg = p.bias + (size_t)g * p.b_gstride;
-  const float* __restrict__ wsc = p.w_inv_scale + (size_t)g * p.b_gstride;
-
-  float amax = p.a_amax_floor;
-  constexpr bool ADD_BOUNDS = LOADER == LOAD_GATHER_ADD || LOADER == LOAD_INTERP_ADD;   // the loader SUMS its inputs
-  const int p_hi = min(p0 + BM, p.P) - 1;   // rows of this tile: [p0, p_hi]
-  if (p.a_amax) {
-    const float m = amax_rows(p.a_amax, lane, p0, p_hi, p.rps);
-    amax = ADD_BOUNDS ? amax + m : fmaxf(amax, m);
-  }
-  if (p.a_amax2) {
-    const float m = amax_rows(p.a_amax2, lane, p0, p_hi, p.rps);
-    amax = ADD_BOUNDS ? amax + m : fmaxf(amax, m);
-  }
-  uint32_t ex = __float_as_uint(amax) >> 23;
-  ex = ex < 15u ? 15u : (ex > 240u ? 240u : ex);
-  ex = __builtin_amdgcn_readfirstlane(ex);
-  const float sa = __uint_as_float((268u - ex) << 23);
-  const float inv_sa = __uint_as_float((ex - 14u) << 23);
-
-  const int wr = wave / CW, wc = wave % CW;
-  const int li = lane & 31, lh = lane >> 5;
-  constexpr int KS = K >> 4;                     // 16-deep steps per channel strip
-  const int nstrip = p.Cout / (64 * CW);         // strips this wave walks
-  // fragment address of flattened step s (strip s / KS, k-step s % KS):
-  // [n32 = (strip * CW + wc) * 2 + cb][ks][plane][lane][8 halves]
-  // wave-uniform base (SGPRs) + one constant 32-bit lane offset: saddr-form global loads
-  const int wc_u = __builtin_amdgcn_readfirstlane(wc);
-  const char* __restrict__ wf_u = reinterpret_cast<const char*>(p.Wfrag + (size_t)g * p.Cout * K * 2);
-  const uint32_t wf_lane = (uint32_t)lane * 16u;
-  constexpr size_t cb_stride = (size_t)KS * 2048;           // bytes between n32 and n32 + 1
-  constexpr size_t strip_stride = (size_t)CW * 2 * cb_stride;   // bytes between strips
-  auto wfrag_ptr = [&](int strip, int ks, int cb, int pl) {
-    const char* u = wf_u + ((size_t)strip * strip_stride + (size_t)(wc_u * 2 + cb) * cb_stride +
-                            (size_t)(ks * 2 + pl) * 1024);
-    return reinterpret_cast<const uint4*>(u + wf_lane);
-  };
-  uint4 ring[GR_RING][2][2];
-  // KS % RING == 0 and KS >= RING: the first RING steps are in strip 0
-#pragma unroll
-  for (int d = 0; d < GR_RING; ++d)
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) ring[d][cb][pl] = *wfrag_ptr(0, d, cb, pl);
-
-  // prologue: the A panel -> two fp16 planes in LDS
-  {
-    ALoader<LOADER, RPT, RS> ld;
-    ld.init(p, p0, g, t);
-    const int chunk = t & 7, srow = t >> 3;
-    // the whole panel is requested before any of it is split: ONE memory round
-    // trip per workgroup (K / 32 * RPT = 16 float4 per thread in flight)
-    constexpr int NKT = K / 32;
-    float4 ra[NKT][RPT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int s = 0; s < RPT; ++s) ra[kt][s] = ld.load(p, s, kt * 32 + chunk * 4, t);
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int s = 0; s < RPT; ++s) {
-        uint2 h, l;
-        split2_h<LOADER == LOAD_GATHER>(ra[kt][s], sa, h, l);
-        uint16_t* dst = Ah + (srow + RS * s) * astr + kt * 32 + chunk * 4;
-        *reinterpret_cast<uint2*>(dst) = h;
-        *reinterpret_cast<uint2*>(dst + aplane) = l;
-      }
-  }
-  __syncthreads();
-
-  const uint16_t* a_lane = Ah + (wr * 64 + li) * astr + 8 * lh;
-  float* epi_s = reinterpret_cast<float*>(Ah + 2 * aplane) + wave * 128;   // [scale 64 | bias 64] per wave
-  f32x16 acc[2][2];   // SWAP: [channel block][position block]; else [position block][channel block]
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  };
-  zero_acc();
-
-  f16x8 afn[2][2];
-#pragma unroll
-  for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
-      afn[rb][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(
-          a_lane + pl * aplane + rb * 32 * astr));
-  float e_sc = 0.f, e_bias = 0.f;     // epilogue scale / bias of channel n0 + lane (loaded a strip ahead)
-  // The K loop of a strip is fully unrolled: every LDS / fragment offset is an
-  // immediate off one wave-uniform strip pointer, ring slot = k-step % RING.
-  const char* wstrip = wf_u + (size_t)(wc_u * 2) * cb_stride;
-  for (int strip = 0; strip < nstrip; ++strip, wstrip += strip_stride) {
-    const int strip_done = strip;
-    {
-      const int n = (strip * CW + wc) * 64 + lane;
-      e_sc = inv_sa * wsc[n];
-      e_bias = bg[n];
-      if constexpr (SWAP) {   // read back as float4 per register quad in the epilogue (same wave: in order)
-        epi_s[lane] = e_sc;
-        epi_s[64 + lane] = e_bias;
-      }
-    }
-    // steps past this strip's end are the first steps of the next one (the last
-    // strip re-reads its own: harmless, never used)
-    const char* wnext = strip + 1 < nstrip ? wstrip + strip_stride : wstrip;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      constexpr int dummy = 0;
-      (void)dummy;
-      const int d = ks % GR_RING;
-      const int ksn = ks + 1 == KS ? 0 : ks + 1;   // next step's A fragments (k wraps: same panel)
-      f16x8 af[2][2], bf[2][2];
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-          af[rb][pl] = afn[rb][pl];
-          afn[rb][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(
-              a_lane + pl * aplane + rb * 32 * astr + ksn * 16));
-        }
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) bf[cb][pl] = __builtin_bit_cast(f16x8, ring[d][cb][pl]);
-      // refill this ring slot with the step RING ahead
-      {
-        const int kr = ks + GR_RING;
-        const char* src = kr < KS ? wstrip : wnext;
-        const int kk = kr < KS ? kr : kr - KS;
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl)
-            ring[d][cb][pl] = *reinterpret_cast<const uint4*>(
-                src + ((size_t)cb * cb_stride + (size_t)(kk * 2 + pl) * 1024) + wf_lane);
-      }
-#define S4G_R_TERM(PA, PB)                                                                              \
-  if constexpr (SWAP) {                                                                                 \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0][PB], af[0][PA], acc[0][0], 0, 0, 0);       \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0][PB], af[1][PA], acc[0][1], 0, 0, 0);       \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[1][PB], af[0][PA], acc[1][0], 0, 0, 0);       \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[1][PB], af[1][PA], acc[1][1], 0, 0, 0);       \
-  } else {                                                                                              \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][PA], bf[0][PB], acc[0][0], 0, 0, 0);       \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][PA], bf[1][PB], acc[0][1], 0, 0, 0);       \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][PA], bf[0][PB], acc[1][0], 0, 0, 0);       \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][PA], bf[1][PB], acc[1][1], 0, 0, 0);       \
-  }
-      S4G_R_TERM(0, 1)
-      S4G_R_TERM(1, 0)
-      S4G_R_TERM(0, 0)
-#undef S4G_R_TERM
-      // keep the scheduler from hoisting later steps' loads across this one (it would
-      // spill the ring); inside a step, spread the 4 reads + 4 loads over the MFMAs
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    const int n0 = (strip_done * CW + wc) * 64;
-    float tmax = 0.f;
-    if constexpr (SWAP) {
-      // lane: position li of position block pb; registers 4 j .. 4 j + 3 = channels
-      // n0 + 32 nb + 8 j + 4 lh + (0..3)
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int n = n0 + nb * 32 + 8 * j + 4 * lh;
-          // scale / bias of channels n .. n+3: staged per wave in LDS at strip start
-          const float4 sc4 = *reinterpret_cast<const float4*>(epi_s + nb * 32 + 8 * j + 4 * lh);
-          const float4 b4 = *reinterpret_cast<const float4*>(epi_s + 64 + nb * 32 + 8 * j + 4 * lh);
-          const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
-          const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-          for (int pb = 0; pb < 2; ++pb) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              // the scale is a power of two, so the fused form rounds exactly like mul-then-add
-              float x = __fmaf_rn(acc[nb][pb][4 * j + e], scv[e], bv[e]);
-              if (p.relu) x = fmaxf(x, 0.f);
-              v[e] = x;
-              tmax = fmaxf(tmax, fabsf(x));
-            }
-            const int row = p0 + wr * 64 + pb * 32 + li;
-            if (row < p.P)
-              *reinterpret_cast<float4*>(p.out + (size_t)row * p.ldc + p.c_coff + g * p.c_gcol + n) =
-                  make_float4(v[0], v[1], v[2], v[3]);
-          }
-        }
-      if (p.out_amax) {
-        const uint32_t wm = wave_max_u32(__float_as_uint(tmax));
-        if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave + strip_done, p0, p_hi, p.rps);
-      }
-    } else {
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        // channel n0 + cb*32 + li: lane cb*32 + li of e_sc / e_bias
-        const float sc = __shfl(e_sc, cb * 32 + li);
-        const float bias = __shfl(e_bias, cb * 32 + li);
-        float mx = -__builtin_inff(), mn = __builtin_inff();
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float v = acc[rb][cb][r] * sc;
-            acc[rb][cb][r] = v;
-            mx = fmaxf(mx, v);
-            mn = fminf(mn, v);
-          }
-        const float hi = mx + bias, lo = mn + bias;
-        tmax = fmaxf(tmax, p.relu ? hi : fmaxf(fabsf(hi), fabsf(lo)));
-      }
-      if (p.out_amax) {
-        const uint32_t wm = wave_max_u32(__float_as_uint(fmaxf(tmax, 0.f)));
-        if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave + strip_done, p0, p_hi, p.rps);
-      }
-      gemm_epilogue<EPI, 2>(p, acc, bg, g, p0, n0, wave, wr, 0, li, lh, smemf);
-    }
-    zero_acc();
-    }
-}
+#ifdef S4G_VARIANTS
+#define S4G_VARIANT_PART 1
+#include "variants/gemm_resident.inc"
+#undef S4G_VARIANT_PART
+#endif
 
 // ---------------------------------------------------------------------------
 // f16x2, two fused layers (the last two layers of an SA level whose widths allow it:
@@ -1850,22 +1585,16 @@ static int launch_mlp_chain(const GemmParams& p, int groups, hipStream_t st) {
   return S4G_OK;
 }
 
-template <int LOADER, int EPI, int RW, int KT>
-static int launch_gemm_f16x2_resident(const GemmParams& p, int groups, hipStream_t st) {
-  constexpr int BM = 64 * RW;
-  constexpr size_t lds = sizeof(uint16_t) * 2 * BM * (size_t)(KT + 8) + sizeof(float) * 4 * 128;
-  static_assert(lds <= 80 * 1024, "two workgroups per CU");
-  static LdsAttrCache lds_cache;
-  if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(&mlp_gemm_f16x2_resident_kernel<LOADER, EPI, RW, KT>), lds, lds_cache)) return rc;
-  const dim3 grid((unsigned)((p.P + BM - 1) / BM), (unsigned)groups);
-  hipLaunchKernelGGL((mlp_gemm_f16x2_resident_kernel<LOADER, EPI, RW, KT>), grid, dim3(256), lds, st, p);
-  S4G_LAUNCH_CHECK();
-  return S4G_OK;
-}
+#ifdef S4G_VARIANTS
+#define S4G_VARIANT_PART 2
+#include "variants/gemm_resident.inc"
+#undef S4G_VARIANT_PART
+#endif
 
 template <int LOADER, int EPI, int PL = 2>
 static int launch_gemm_f16x2(const GemmParams& p, int groups, hipStream_t st) {
-  static const int force = [] { const char* e = getenv("S4G_GEMM_NCB"); return e ? atoi(e) : 0; }();
+  constexpr int force = 0;   // (tile width by shape; forcing it was a tuning knob of round 1)
+#ifdef S4G_VARIANTS
   // S4G_GEMM_RESIDENT=0 never / 1 whenever the shape qualifies / unset: only where it
   // measured faster than the tiled kernel (Cout >= 1024: +6 %; short strips lose to
   // the per-workgroup prologue)
@@ -1886,6 +1615,7 @@ static int launch_gemm_f16x2(const GemmParams& p, int groups, hipStream_t st) {
         return launch_gemm_f16x2_resident<LOADER, EPI, 2, 128>(p, groups, st);
     }
   }
+#endif
   // the INTERP / GATHER loaders hold too much per-row state for the wide tile's
   // 128 accumulator registers (they would spill)
   // ... and 256-wide tiles only pay when they still fill the chip twice over: measured on the
@@ -2109,12 +1839,16 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   // 64 positions x 256 channels per workgroup, the 256-channel strips of a wider layer as groups that
   // share A (S4G_GEMM_SINGLE_CHAIN=0: the tiled kernel)
   {
-    static const bool single_chain = [] { const char* e = getenv("S4G_GEMM_SINGLE_CHAIN"); return !(e && e[0] == '0'); }();
+    const char* sc_env = getenv("S4G_GEMM_SINGLE_CHAIN");   // (read per launch: a test knob)
+    const bool single_chain = !(sc_env && sc_env[0] == '0');
     const bool bf1 = d->precision == S4G_GEMM_BF16;
     const int kc = d->Kpad16 / 256;
     if (single_chain && (h2 || bf1) && d->loader == S4G_GEMM_LOAD_PLAIN && d->epilogue == S4G_GEMM_EPI_STORE &&
         d->W_f16x2_frag && d->groups == 1 && d->Cout % 256 == 0 && d->Kpad16 % 256 == 0 &&
-        (kc == 1 || kc == 2 || kc == 4) && ((d->ldc | d->c_coff) & 3) == 0 && ((uintptr_t)d->out & 15) == 0) {
+        (kc == 1 || kc == 2 || kc == 4) && ((d->ldc | d->c_coff) & 3) == 0 && ((uintptr_t)d->out & 15) == 0 &&
+        // measured per launch (profiles/r04_single_layer.md): it wins from four 256-channel strips or a
+        // 1 024-deep contraction (fp0.0s / fp0.0d / fp0.1 / fp1.0s: -6 ... -25 %), the tiled kernel below that
+        (d->Cout >= 1024 || d->Kpad16 >= 1024 || (sc_env && sc_env[0] == '1'))) {
       GemmParams q = p;
       q.Cout = 256;
       q.a_gcol = 0;
@@ -2131,9 +1865,8 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
 #undef S4G_SINGLE_CASE
     }
   }
-  // single-product bf16: the swizzled-LDS tile kernel with one plane (S4G_BF16_TILED=0: the bf16x3
-  // kernel's hi-plane-only mode it replaced)
-  static const bool bf16_tiled = [] { const char* e = getenv("S4G_BF16_TILED"); return !(e && e[0] == '0'); }();
+  // single-product bf16: the swizzled-LDS tile kernel with one plane
+  constexpr bool bf16_tiled = true;
 #define S4G_GEMM_CASE(L, E)                                            \
   if (d->loader == L && d->epilogue == E)                              \
     return h2 ? launch_gemm_f16x2<L, E>(p, d->groups, st)              \

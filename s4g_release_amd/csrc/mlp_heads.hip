@@ -464,11 +464,8 @@ extern "C" int s4g_heads_chain_f32(const s4g_heads_desc_t* d, s4g_stream_t strea
   if (d->precision == S4G_GEMM_F16X2 && !d->a_amax && !(d->a_amax_floor > 0.f)) return S4G_EINVAL;
   if (d->P == 0) return S4G_OK;
   hipStream_t st = (hipStream_t)stream;
-  // W fragment prefetch depth in 16-deep steps (S4G_HEADS_RING=2|4: tuning knob)
-  static const int ring = [] { const char* e = getenv("S4G_HEADS_RING"); return e ? atoi(e) : 4; }();
-  if (d->precision == S4G_GEMM_F16X2) return ring == 2 ? launch_heads<2, 2, 2>(p, st) : launch_heads<2, 4, 2>(p, st);
-  // single-plane bf16: 128 positions per workgroup (S4G_HEADS_BM=64: the 64-position form)
-  static const int bm = [] { const char* e = getenv("S4G_HEADS_BM"); return e ? atoi(e) : 128; }();
-  if (bm == 64) return ring == 2 ? launch_heads<1, 2, 2>(p, st) : launch_heads<1, 4, 2>(p, st);
-  return ring == 2 ? launch_heads<1, 2, 4>(p, st) : launch_heads<1, 4, 4>(p, st);
+  // W fragment ring four 16-deep steps deep (two and eight measured 1-4 % slower in rounds 3 and 4); the
+  // single-plane bf16 form owns 128 positions per workgroup (its 64-position form spilled)
+  if (d->precision == S4G_GEMM_F16X2) return launch_heads<2, 4, 2>(p, st);
+  return launch_heads<1, 4, 4>(p, st);
 }

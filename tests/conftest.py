@@ -25,3 +25,21 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def _variants_built():
+    """True for a measurement build of the library (-DS4G_VARIANTS: csrc/variants/*.inc compiled in)."""
+    try:
+        from s4g_release_amd import _cabi
+        return bool(_cabi.lib().s4g_build_variants())
+    except Exception:
+        return False
+
+
+# the measured-slower kernel variants are exercised only where they exist (tools/build_variant.sh all -DS4G_VARIANTS)
+VARIANTS = _variants_built()
+
+
+def with_variants(default, extra):
+    """Parameter list: `default` always, `extra` only when the library carries the variants."""
+    return list(default) + (list(extra) if VARIANTS else [])

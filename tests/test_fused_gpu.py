@@ -10,19 +10,25 @@ import pytest
 import torch
 
 from tests import golden_util as GU
+from tests.conftest import with_variants
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.fixture(params=["tiled", "resident"])
+@pytest.fixture(params=with_variants(["chain", "tiled"], ["resident"]))
 def gemm_variant(request, monkeypatch):
-    """Unit tests run twice: default dispatch, and with the resident-A kernel
-    forced for every shape it supports (S4G_GEMM_RESIDENT is read per launch)."""
+    """Unit tests run per single-layer kernel: default dispatch (plain layers whose widths allow it on the
+    chain kernel's first-layer machinery), the tiled kernel for every shape (S4G_GEMM_SINGLE_CHAIN=0) and --
+    measurement builds only -- the resident-A kernel forced wherever it applies (S4G_GEMM_RESIDENT=1)."""
     if request.param == "resident":
+        monkeypatch.setenv("S4G_GEMM_SINGLE_CHAIN", "0")
         monkeypatch.setenv("S4G_GEMM_RESIDENT", "1")
-    else:
+    elif request.param == "tiled":
+        monkeypatch.setenv("S4G_GEMM_SINGLE_CHAIN", "0")
         monkeypatch.setenv("S4G_GEMM_RESIDENT", "0")
+    else:
+        monkeypatch.setenv("S4G_GEMM_SINGLE_CHAIN", "1")     # every shape the chain form supports, not only where it wins
     return request.param
 
 

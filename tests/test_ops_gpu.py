@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from s4g_release_amd import synth
+from tests.conftest import with_variants
 
 pytestmark = pytest.mark.gpu
 
@@ -60,7 +61,7 @@ def test_fps_pruned_variant_is_exact(F, oracle, dev, monkeypatch, N, M, variant)
     assert np.array_equal(F.farthest_point_sample(_t(pts, dev), M).cpu().numpy(), got)
 
 
-@pytest.mark.parametrize("mode", ["auto", "cluster", "hybrid"])
+@pytest.mark.parametrize("mode", with_variants(["auto"], ["cluster", "hybrid"]))
 def test_fps_hybrid_kernel_large_cloud(F, oracle, dev, monkeypatch, mode):
     """25 600 < N <= 51 200.  auto (default): one workgroup per scene, pruned, min-distances in
     registers and the coordinates of touched groups read from the Morton-sorted records in L2;
@@ -77,7 +78,7 @@ def test_fps_hybrid_kernel_large_cloud(F, oracle, dev, monkeypatch, mode):
         assert np.array_equal(got, oracle.fps(pts, 200)), (n, variant)
 
 
-@pytest.mark.parametrize("mode", ["auto", "cluster"])
+@pytest.mark.parametrize("mode", with_variants(["auto"], ["cluster"]))
 @pytest.mark.parametrize("variant", ["tabletop-v1", "dup-heavy"])
 def test_fps_cluster_full_size_batch_ties_and_fmad(F, oracle, dev, monkeypatch, variant, mode):
     """configs[4] geometry: FPS 51 200 -> 5 120 with ALL 5 119 steps, three scenes, exact ties
@@ -154,7 +155,7 @@ def bq_mode(monkeypatch):
     return set_mode
 
 
-@pytest.mark.parametrize("mode", ["cell", "grid", "scan"])
+@pytest.mark.parametrize("mode", with_variants(["grid", "scan"], ["cell"]))
 @pytest.mark.parametrize("variant,N,M,r,K", [
     ("tabletop-v1", 25600, 5120, 0.02, 64),    # SA1
     ("tabletop-v1", 25600, 2000, 0.01, 32),    # scene wider than 32 cells: toroidal aliasing
@@ -176,7 +177,7 @@ def test_ball_query_grid_and_scan_paths(F, oracle, dev, bq_mode, mode, variant, 
     assert cnt[0, 0].item() == 0 and (idx[0, 0] == 0).all()
 
 
-@pytest.mark.parametrize("mode", ["cell", "grid"])
+@pytest.mark.parametrize("mode", with_variants(["grid"], ["cell"]))
 def test_ball_query_grid_out_of_range_scene_falls_back(F, oracle, dev, bq_mode, mode):
     """A scene spanning > 4096 cells trips the exactness flag: its centroids take
     the index-order scan inside the grid kernel; the other scene stays on the grid."""
@@ -193,7 +194,7 @@ def test_ball_query_grid_out_of_range_scene_falls_back(F, oracle, dev, bq_mode, 
     assert np.array_equal(g2.cpu().numpy(), oracle.group_points(pts, ridx))
 
 
-@pytest.mark.parametrize("mode", ["auto", "scan", "cell", "grid"])
+@pytest.mark.parametrize("mode", with_variants(["auto", "scan", "grid"], ["cell"]))
 @pytest.mark.parametrize("N,M,r", [(25600, 5120, 0.02), (5120, 1024, 0.08)])
 def test_query_and_group_equals_operator_pair(F, oracle, dev, bq_mode, mode, N, M, r):
     bq_mode(mode)
