@@ -69,3 +69,21 @@ def test_oracle_crop_equals_reference():
     idx = OPre.filter_work_space(px["cloud"], px["workspace"])
     assert np.array_equal(idx, np.nonzero(px["valid"])[0])
     assert np.array_equal(px["cloud"].T[idx].astype(np.float64), px["kept"])
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_oracle_demo_top_frames_equals_reference(case):
+    """utils/file_logger_cls.py `loggin_to_file(with_label=False)`: expected score, translation, top-50,
+    fp32 Gram-Schmidt, float64 inverse, collision filter -- the reference's own return value."""
+    from oracle import postprocess as OP
+    dx = np.load(os.path.join(GOLDEN, "post_demo.npz"))
+    pred = {k: dx["%s_%s" % (case, k)] for k in ("score", "frame_R", "frame_t")}
+    H, s, idx = OP.demo_top_frames(pred, dx[case + "_points"], K=50)
+    assert 0 < H.shape[0] < 50 and H.shape == dx[case + "_top_H"].shape      # the filter cut, and not everything
+    assert np.array_equal(s, dx[case + "_top_score"]) and (np.diff(s) < 0).all()
+    assert np.array_equal(H, dx[case + "_top_H"])                            # bit for bit
+    # the batched decode without the filter agrees on the kept frames up to its float64 Gram-Schmidt
+    H2, s2, i2 = OP.decode_top_poses(pred, dx[case + "_points"], K=50)
+    keep = np.isin(i2[0], idx)
+    assert np.array_equal(i2[0][keep], idx) and np.array_equal(s2[0][keep], s)
+    assert np.abs(H2[0][keep] - H).max() < 1e-6

@@ -222,3 +222,32 @@ def test_collision_check_equals_the_reference_verdicts(dev, case):
     assert np.array_equal(ok[~edge], ref_ok[~edge])
     assert (ok == ref_ok).mean() >= 0.97 and 0 < ref_ok.sum() < ref_ok.size
     assert np.abs(counts[0].cpu().numpy().astype(np.int64) - rc[0]).max() <= 2
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_demo_decode_and_filter_equal_the_reference(dev, case):
+    """`decode_top_poses(..., "demo")` + `view_non_collision` (the product's counterpart of the demo's
+    `loggin_to_file(with_label=False)`, utils/file_logger_cls.py:27-47,66-68,196-241) against what the
+    reference's own function returned: the same viable frames in the same order, scores to 1e-6, frames
+    to 3e-5 (fp32 decode on the device vs fp32 / float64 numpy)."""
+    from oracle import postprocess as OP
+    from s4g_release_amd import postprocess as PP
+    dx = np.load(os.path.join(_GOLDEN, "post_demo.npz"))
+    pred_np = {k: dx["%s_%s" % (case, k)] for k in ("score", "frame_R", "frame_t")}
+    pred = {k: torch.from_numpy(v).to(dev) for k, v in pred_np.items()}
+    pts = torch.from_numpy(dx[case + "_points"]).to(dev)
+    H, s, idx = PP.decode_top_poses(pred, pts, 50, "demo")
+    ok, counts = PP.view_non_collision(H, pts)                     # float64 inverse, like the demo's caller
+    ref_H, ref_s = dx[case + "_top_H"], dx[case + "_top_score"]
+    # the reference's 50 candidates, its verdicts and counts through the pinned oracle
+    oH, os_, oi = OP.decode_top_poses(pred_np, dx[case + "_points"], K=50)
+    assert np.array_equal(idx[0].cpu().numpy(), oi[0])             # same 50 points, best first
+    _, rc = OP.view_non_collision(oH.astype(np.float64), dx[case + "_points"])
+    edge = (np.abs(rc[0, :, 0] - 10 * np.sqrt(8)) <= 1.0) | (np.abs(rc[0, :, 1] - 10) <= 1.0)
+    _, _, ref_idx = OP.demo_top_frames(pred_np, dx[case + "_points"], 50)
+    ref_ok = np.isin(oi[0], ref_idx)
+    got_ok = ok[0].cpu().numpy()
+    assert np.array_equal(got_ok[~edge], ref_ok[~edge]) and 0 < ref_ok.sum() < 50
+    both = got_ok & ref_ok
+    assert np.allclose(s[0].cpu().numpy()[both], ref_s[np.isin(ref_idx, oi[0][both])], atol=1e-6)
+    assert np.allclose(H[0].cpu().numpy()[both], ref_H[np.isin(ref_idx, oi[0][both])], atol=3e-5)
