@@ -492,6 +492,9 @@ int s4g_group_rel_xyz_i32(const float *xyz_b3n, const float *ctr_b3m, const int3
  *   seg4          (B M K / 4) int32: b M + m per group of 4 rows, -1 for the filler rows
  *   row_start_bm  (B, M) int32: first row of every centroid relative to its scene's base
  *   rows_b        (B) int32: rows of scene b, rounded up to 128
+ * A scene whose rows would exceed 7/8 of M K keeps the PLAIN layout instead (centroid m at row m K, all K
+ * slots, rows_b[b] == M K): the segmented epilogue would cost more than the few copies save; the
+ * contraction takes its 64-row epilogue for such a scene.  The choice depends on the scene alone.
  * K % 4 == 0 and (M K) % 128 == 0, else S4G_EUNSUPPORTED. */
 int s4g_group_rel_xyz_unique_i32(const float *xyz_b3n, const float *ctr_b3m, const int32_t *idx_bmk,
                                  const int32_t *cnt_bm, int64_t B, int64_t N, int64_t M, int64_t K,

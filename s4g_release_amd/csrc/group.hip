@@ -97,7 +97,8 @@ __global__ __launch_bounds__(GP_THREADS) void group_rel_xyz_kernel(const float* 
 //   row_start[b M + m]   first row of centroid m, relative to the scene's base (exclusive scan of c4)
 //   seg4[row / 4]        b M + m for every group of 4 rows; -1 behind the scene's last centroid
 //   rows[b]              the scene's rows rounded up to GU_TILE (the contraction's tile height); the rows
-//                        between the last centroid and that edge are zero records of segment -1
+//                        between the last centroid and that edge are zero records of segment -1.
+//                        rows[b] == M K: the scene keeps the PLAIN layout (see the scan kernel)
 constexpr int GU_THREADS = 1024, GU_TILE = 128;
 __global__ __launch_bounds__(GU_THREADS) void group_unique_scan_kernel(const int* __restrict__ cnt, int M, int K,
                                                                        int* __restrict__ row_start,
@@ -140,8 +141,20 @@ __global__ __launch_bounds__(GU_THREADS) void group_unique_scan_kernel(const int
       start += (max(cnt[(size_t)b * M + m], 1) + 3) & ~3;
     }
   }
+  // A scene whose balls are mostly full gains nothing (the segmented epilogue costs ~9 % of the launch): from
+  // 7/8 of the capacity on it keeps the plain layout -- centroid m at row m K, all K slots -- and says so with
+  // rows[b] == M K; the contraction then takes its 64-row epilogue for that scene.  Decided per scene, from
+  // the scene alone: results never depend on the rest of the batch.
+  if (total_s > (int)((int64_t)M * K / 8 * 7)) {
+    for (int i = 0; i < per; ++i) {
+      const int m = m0 + i;
+      if (m < M) row_start[(size_t)b * M + m] = m * K;
+    }
+    if (t == 0) rows[b] = M * K;
+    return;
+  }
   const int total = total_s;                                   // a multiple of 4
-  const int padded = (total + GU_TILE - 1) / GU_TILE * GU_TILE;   // <= M K (a multiple of GU_TILE)
+  const int padded = (total + GU_TILE - 1) / GU_TILE * GU_TILE;   // < M K (a multiple of GU_TILE)
   if (t == 0) rows[b] = padded;
   const size_t base = (size_t)b * M * K;
   for (int r = total + t; r < padded; r += GU_THREADS) {
@@ -154,7 +167,8 @@ __global__ __launch_bounds__(GP_THREADS) void group_rel_unique_kernel(const floa
                                                                       const float* __restrict__ ctr,
                                                                       const int* __restrict__ idx,
                                                                       const int* __restrict__ cnt,
-                                                                      const int* __restrict__ row_start, int N,
+                                                                      const int* __restrict__ row_start,
+                                                                      const int* __restrict__ rows, int N,
                                                                       int M, int K, float4* __restrict__ out,
                                                                       int* __restrict__ seg4) {
   const int b = blockIdx.y;
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(GP_THREADS) void group_rel_unique_kernel(const floa
   const int64_t t = (int64_t)blockIdx.x * GP_THREADS + threadIdx.x;
   if (t >= MK) return;
   const int m = (int)(t / K), k = (int)(t - (int64_t)m * K);
-  const int c4 = (max(cnt[(size_t)b * M + m], 1) + 3) & ~3;
+  const int c4 = rows[b] == M * K ? K : (max(cnt[(size_t)b * M + m], 1) + 3) & ~3;   // (plain layout: every slot)
   if (k >= c4) return;
   const int j = idx[(size_t)b * MK + t];          // slots past the count repeat slot 0 (or hold 0: empty ball)
   const float* __restrict__ x = xyz + (size_t)b * 3 * N;
@@ -291,7 +305,7 @@ extern "C" int s4g_group_rel_xyz_unique_i32(const float* xyz_b3n, const float* c
   S4G_LAUNCH_CHECK();
   hipLaunchKernelGGL(s4g::group_rel_unique_kernel,
                      dim3((unsigned)((MK + s4g::GP_THREADS - 1) / s4g::GP_THREADS), (unsigned)B),
-                     dim3(s4g::GP_THREADS), 0, st, xyz_b3n, ctr_b3m, idx_bmk, cnt_bm, row_start_bm, (int)N, (int)M,
+                     dim3(s4g::GP_THREADS), 0, st, xyz_b3n, ctr_b3m, idx_bmk, cnt_bm, row_start_bm, rows_b, (int)N, (int)M,
                      (int)K, reinterpret_cast<float4*>(rel_pk4), seg4);
   S4G_LAUNCH_CHECK();
   return S4G_OK;

@@ -1070,11 +1070,14 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
 
   constexpr bool ADD_BOUNDS = LOADER == LOAD_GATHER_ADD || LOADER == LOAD_INTERP_ADD;   // the loader SUMS its inputs
   constexpr bool SEGMAX = LOADER == LOAD_GATHER_MLP1 && EPI2 == EPI_MAX;   // may run on distinct rows only (seg4)
+  bool seg_scene = false;   // this tile's scene is in the distinct-row layout (a mostly-full scene keeps the plain one)
   if constexpr (SEGMAX) {
     // distinct-row form: a scene's rows end before its base + rps; the tiles behind them have nothing to do
     if (p.seg_rows) {
       const int sc = p0 / p.rps;
-      if (p0 - sc * p.rps >= p.seg_rows[sc]) return;
+      const int nrows = p.seg_rows[sc];
+      if (p0 - sc * p.rps >= nrows) return;
+      seg_scene = nrows < p.rps;
     }
   }
   const int p_hi = min(p0 + BM, p.P) - 1;   // rows of this tile: [p0, p_hi]
@@ -1414,7 +1417,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
   // distinct-row form: the output rows of this half-wave's eight 4-row groups (rows 64 wr + 32 lh + 4 i ..)
   int sidv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if constexpr (SEGMAX) {
-    if (p.seg4) {
+    if (seg_scene) {
       const int4* sp = reinterpret_cast<const int4*>(p.seg4 + ((p0 + wr * 64 + lh * 32) >> 2));
       const int4 s0 = sp[0], s1 = sp[1];
       sidv[0] = s0.x; sidv[1] = s0.y; sidv[2] = s0.z; sidv[3] = s0.w;
@@ -1469,7 +1472,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
         const uint32_t wm = wave_max_u32(__float_as_uint(omax));
         if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave + strip, p0, p_hi, p.rps);
       }
-    } else if (SEGMAX && p.seg4) {
+    } else if (SEGMAX && seg_scene) {
       // distinct-row form: the wave's 64 rows are pieces of several centroids, each a run of 4-row groups
       // with one output row (seg4).  Per channel block: the group maxima (4 -> 1 in registers), one
       // half-exchange per pair (v_permlane32_swap: afterwards the lower half-wave holds the 8 groups of

@@ -892,6 +892,9 @@ class FusedPointNet2:
                 inter["fps%d" % li], inter["ball%d" % li], inter["cnt%d" % li] = idx, gidx, gcnt
             for fi, (nidx, nw) in enumerate(h.geo["fp"]):
                 inter["nn%d" % fi], inter["nnw%d" % fi] = nidx, nw
+            for li, rel in enumerate(h.geo["rel"]):
+                if isinstance(rel, tuple):      # distinct-row form: rows each scene occupies (M K = plain layout)
+                    inter["sa%d_rows" % li] = rel[2]
             return pred, inter
         return pred
 

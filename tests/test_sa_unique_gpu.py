@@ -22,9 +22,11 @@ def _unique_reference(pts, ctr, gidx, cnt, K):
     row_start = np.zeros((B, M), np.int32)
     rows = np.zeros((B,), np.int32)
     for b in range(B):
+        total = sum((max(int(c), 1) + 3) // 4 * 4 for c in cnt[b])
+        dense = total > cap // 8 * 7        # a mostly-full scene keeps the plain layout: every slot, rows == M K
         r = 0
         for m in range(M):
-            c4 = (max(int(cnt[b, m]), 1) + 3) // 4 * 4
+            c4 = K if dense else (max(int(cnt[b, m]), 1) + 3) // 4 * 4
             row_start[b, m] = r
             j = gidx[b, m, :c4]
             rel[b * cap + r:b * cap + r + c4, :3] = (pts[b][:, j] - ctr[b][:, m:m + 1]).T
@@ -36,7 +38,8 @@ def _unique_reference(pts, ctr, gidx, cnt, K):
 
 
 @pytest.mark.parametrize("variant,N,M,radius", [("tabletop-v1", 4096, 512, 0.03), ("uniform-box", 2048, 256, 0.05),
-                                                ("dup-heavy", 4096, 512, 0.02)])
+                                                ("dup-heavy", 4096, 512, 0.02),
+                                                ("tabletop-v1", 8192, 256, 0.06)])     # balls mostly full: plain layout
 def test_group_rel_xyz_unique_layout(dev, variant, N, M, radius):
     from oracle import oracle as O
     from s4g_release_amd import _cabi, synth
@@ -49,6 +52,7 @@ def test_group_rel_xyz_unique_layout(dev, variant, N, M, radius):
         ctr[0, :, 5] += 10.0                 # a centroid far from every point: an EMPTY ball (count 0)
     gidx, cnt = O.ball_query(pts, ctr, radius, K)
     assert cnt.min() < K, "the case must contain padded balls"
+    dense_case = radius == 0.06
     B = pts.shape[0]
     t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if dt is None else \
         torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
@@ -64,6 +68,7 @@ def test_group_rel_xyz_unique_layout(dev, variant, N, M, radius):
     torch.cuda.synchronize()
     r_rel, r_seg, r_start, r_rows = _unique_reference(pts, ctr, gidx, cnt, K)
     assert np.array_equal(rows.cpu().numpy(), r_rows)
+    assert (r_rows == M * K).any() == dense_case, r_rows
     assert np.array_equal(row_start.cpu().numpy(), r_start)
     assert np.array_equal(seg4.cpu().numpy(), r_seg)
     got = rel.cpu().numpy()
@@ -102,15 +107,20 @@ def test_model_on_distinct_rows_equals_the_full_rows_model(dev, monkeypatch, pre
     from s4g_release_amd import synth
     from s4g_release_amd.fused import FusedPointNet2
     net = _net(dev)
+    crowded = synth.make_batch([8], 25600) * np.float32(0.55)       # the same cloud shrunk: balls mostly full
     pts = torch.from_numpy(np.concatenate([synth.make_batch([5, 6], 25600),
-                                           synth.make_batch([7], 25600, variant="uniform-box")])).to(dev)
+                                           synth.make_batch([7], 25600, variant="uniform-box"), crowded])).to(dev)
     a, ia = FusedPointNet2(net, precision=precision)({"scene_points": pts}, return_intermediates=True)
     assert int(ia["cnt0"].min()) < 64      # padded balls exist (the uniform scene is almost all padding)
+    rows = ia.pop("sa0_rows").cpu().numpy()
+    # per scene: the two table-top scenes and the sparse one are compacted, the crowded one keeps the plain layout
+    assert (rows[:3] < 0.875 * 5120 * 64).all() and rows[3] == 5120 * 64 and rows[2] < 0.15 * 5120 * 64
     monkeypatch.setenv("S4G_SA_UNIQUE", "0")
     b, ib = FusedPointNet2(net, precision=precision)({"scene_points": pts}, return_intermediates=True)
     for k in ia:
         assert torch.equal(ia[k], ib[k]), k
     for k in a:
+        assert torch.equal(a[k][3], b[k][3]), k      # the plain-layout scene runs the very same arithmetic
         if precision == "bf16":
             assert torch.equal(a[k], b[k]), k
         else:
