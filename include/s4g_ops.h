@@ -362,8 +362,8 @@ typedef struct s4g_gemm_desc {
    * layer (W2_f16x2_frag) + S4G_GEMM_EPI_MAX with K == 64 and relu2: the DISTINCT-row form.  rel_xyz4 then
    * holds what s4g_group_rel_xyz_unique_i32 wrote -- per centroid only the rows ball_query did not pad
    * (ball_query_kernel.cu:64-67 repeats the first hit; modules.py:243's max over the neighbours cannot
-   * see the copies) -- scene b's rows at b * rows_per_scene .. + seg_rows[b] (a multiple of 128, the
-   * tile height; rows_per_scene % 128 == 0), seg4[row / 4] the OUTPUT row (b M + m) of every group of
+   * see the copies) -- scene b's rows at b * rows_per_scene .. + seg_rows[b] (a multiple of 256, the
+   * tallest tile; rows_per_scene % 256 == 0), seg4[row / 4] the OUTPUT row (b M + m) of every group of
    * four rows, -1 for filler.  `out` must be zero-filled by the caller: a centroid's pieces are merged
    * with an unsigned atomicMax on the post-ReLU values.  Same maxima as the 64-row form; the hidden
    * layer's per-tile power-of-two scales see other rows, so outputs agree to fp32 round-off, not bitwise. */
@@ -491,11 +491,11 @@ int s4g_group_rel_xyz_i32(const float *xyz_b3n, const float *ctr_b3m, const int3
  *                 rows_b[b] are zero records
  *   seg4          (B M K / 4) int32: b M + m per group of 4 rows, -1 for the filler rows
  *   row_start_bm  (B, M) int32: first row of every centroid relative to its scene's base
- *   rows_b        (B) int32: rows of scene b, rounded up to 128
+ *   rows_b        (B) int32: rows of scene b, rounded up to 256
  * A scene whose rows would exceed 7/8 of M K keeps the PLAIN layout instead (centroid m at row m K, all K
  * slots, rows_b[b] == M K): the segmented epilogue would cost more than the few copies save; the
  * contraction takes its 64-row epilogue for such a scene.  The choice depends on the scene alone.
- * K % 4 == 0 and (M K) % 128 == 0, else S4G_EUNSUPPORTED. */
+ * K % 4 == 0 and (M K) % 256 == 0, else S4G_EUNSUPPORTED. */
 int s4g_group_rel_xyz_unique_i32(const float *xyz_b3n, const float *ctr_b3m, const int32_t *idx_bmk,
                                  const int32_t *cnt_bm, int64_t B, int64_t N, int64_t M, int64_t K,
                                  float *rel_pk4, int32_t *seg4, int32_t *row_start_bm, int32_t *rows_b,

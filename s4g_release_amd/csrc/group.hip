@@ -99,7 +99,7 @@ __global__ __launch_bounds__(GP_THREADS) void group_rel_xyz_kernel(const float* 
 //   rows[b]              the scene's rows rounded up to GU_TILE (the contraction's tile height); the rows
 //                        between the last centroid and that edge are zero records of segment -1.
 //                        rows[b] == M K: the scene keeps the PLAIN layout (see the scan kernel)
-constexpr int GU_THREADS = 1024, GU_TILE = 128;
+constexpr int GU_THREADS = 1024, GU_TILE = 256;   // (the tallest contraction tile: 256 rows in the single-plane form)
 __global__ __launch_bounds__(GU_THREADS) void group_unique_scan_kernel(const int* __restrict__ cnt, int M, int K,
                                                                        int* __restrict__ row_start,
                                                                        int* __restrict__ rows,

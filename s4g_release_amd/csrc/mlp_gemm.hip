@@ -1044,18 +1044,26 @@ constexpr int GF_RING_F16X2 = 2;
 #ifndef S4G_CHAIN_RING1
 #define S4G_CHAIN_RING1 2
 #endif
+// 32-row blocks a wave of the single-plane (bf16) form owns: 4 (round 4: a W fragment then feeds four MFMAs
+// instead of two -- with ONE product per MAC the W stream is the form's bottleneck) or 2 (rounds 2-3)
+#ifndef S4G_CHAIN_BF16_NRB
+#define S4G_CHAIN_BF16_NRB 4
+#endif
 
 // PL = planes per operand: 2 = the f16x2 split above (three fp16 products per step, power-of-two
 // scales), 1 = ONE bf16 plane and one product (S4G_GEMM_BF16, the reduced-precision roofline
 // configuration: bf16 has fp32's exponent range, so there are no scales, no maxima and no
 // barrier for them; the panel is half as large, so twice as many workgroups fit a CU).
 template <int LOADER, int EPI2, int RW, int KC, int PL>
-__global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) void mlp_chain_kernel(const GemmParams p) {
+__global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHAIN_BF16_NRB == 2) ? 3 : 2) void mlp_chain_kernel(const GemmParams p) {
   // RW = 2: 128 positions, 128-wide layers, 4 waves; RW = 1: 64 positions, 256-wide layers, 4 waves;
-  // RW = 8: 64 positions, 512-wide layers, EIGHT waves (one workgroup per CU: its 133 KB panel)
+  // RW = 8: 64 positions, 512-wide layers, EIGHT waves (one workgroup per CU: its 133 KB panel).
+  // A wave owns NRB 32-row blocks x 64 channels: 2 blocks in the f16x2 form (the positions above), 4 in
+  // the single-plane form (twice the positions: the same LDS bytes, half the W bytes per MFMA).
   constexpr int GF_RING = PL == 2 ? GF_RING_F16X2 : S4G_CHAIN_RING1;
+  constexpr int NRB = PL == 1 ? S4G_CHAIN_BF16_NRB : 2, WROWS = 32 * NRB;
   constexpr int CW = RW == 8 ? 8 : 4 / RW, RWN = RW == 8 ? 1 : RW;
-  constexpr int BM = 64 * RWN, K = 64 * CW, NW = RWN * CW;
+  constexpr int BM = WROWS * RWN, K = 64 * CW, NW = RWN * CW;
   constexpr int RS = 8 * NW, RPT = BM / RS;   // loader: 8 lanes per row, RS rows per pass
   constexpr int astr = K + 8, aplane = BM * astr, KS = K >> 4;
   extern __shared__ __attribute__((aligned(16))) float smemf[];
@@ -1178,26 +1186,27 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
       if (DEPTH < NKT) __builtin_amdgcn_sched_barrier(0);
     }
   };
-  if (!(S4G_CHAIN_ABLATE & 16)) load_panel(0, std::integral_constant<int, K / 32>{});
+  // (64 loaded values per thread in flight at most: one round trip for the 2-block form, two for the 4-block one)
+  if (!(S4G_CHAIN_ABLATE & 16)) load_panel(0, std::integral_constant<int, (K / 32) / (NRB / 2)>{});
   S4G_STAMP(2);
   __syncthreads();
   S4G_STAMP(3);
 
-  const uint16_t* a_lane = Ah + (wr * 64 + li) * astr + 8 * lh;
+  const uint16_t* a_lane = Ah + (wr * WROWS + li) * astr + 8 * lh;
   float* epi_s = scr + wave * 128;
-  f32x16 acc[2][2];
+  f32x16 acc[2][NRB];   // [32-channel block][32-row block], in every phase
   auto zero_acc = [&]() {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NRB; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   };
-  uint4 afn[2][PL];
+  uint4 afn[NRB][PL];
   auto prime_a = [&]() {
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
       for (int pl = 0; pl < PL; ++pl)
         afn[rb][pl] = *reinterpret_cast<const uint4*>(a_lane + pl * aplane + rb * 32 * astr);
@@ -1209,8 +1218,8 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
   _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                  \
     const int d = ks % GF_RING;                                                                        \
     const int ksn = ks + 1 == KS ? 0 : ks + 1;                                                         \
-    uint4 af[2][PL], bf[2][PL];                                                                        \
-    _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) { \
+    uint4 af[NRB][PL], bf[2][PL];                                                                      \
+    _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb) _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) { \
       af[rb][pl] = afn[rb][pl];                                                                        \
       if (!(S4G_CHAIN_ABLATE & 2))                                                                     \
         afn[rb][pl] = *reinterpret_cast<const uint4*>(a_lane + pl * aplane + rb * 32 * astr + ksn * 16); \
@@ -1240,22 +1249,22 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                               \
     }                                                                                                  \
     if constexpr (PL == 2) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                          \
+    if constexpr (PL == 1 && NRB == 4) {   /* 8 MFMAs, 4 LDS reads, 2 fragment loads per step */          \
+      _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                             \
+      }                                                                                                \
+    }                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
   }
 // Z: start from a literal zero accumulator (the MFMA's C operand as an inline constant: no
 // register zeroing); only ever true in a fully unrolled first step
 #define S4G_F2_TERM(SWAPPED, PA, PB, Z)                                                                \
-  if constexpr (SWAPPED) {                                                                             \
-    acc[0][0] = chain_mfma<PL>(bf[0][PB], af[0][PA], (Z) ? zero16 : acc[0][0]);                        \
-    acc[0][1] = chain_mfma<PL>(bf[0][PB], af[1][PA], (Z) ? zero16 : acc[0][1]);                        \
-    acc[1][0] = chain_mfma<PL>(bf[1][PB], af[0][PA], (Z) ? zero16 : acc[1][0]);                        \
-    acc[1][1] = chain_mfma<PL>(bf[1][PB], af[1][PA], (Z) ? zero16 : acc[1][1]);                        \
-  } else {                                                                                             \
-    acc[0][0] = chain_mfma<PL>(af[0][PA], bf[0][PB], (Z) ? zero16 : acc[0][0]);                        \
-    acc[0][1] = chain_mfma<PL>(af[0][PA], bf[1][PB], (Z) ? zero16 : acc[0][1]);                        \
-    acc[1][0] = chain_mfma<PL>(af[1][PA], bf[0][PB], (Z) ? zero16 : acc[1][0]);                        \
-    acc[1][1] = chain_mfma<PL>(af[1][PA], bf[1][PB], (Z) ? zero16 : acc[1][1]);                        \
-  }
+  _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int rb = 0; rb < NRB; ++rb)  \
+    if constexpr (SWAPPED)                                                                             \
+      acc[cb][rb] = chain_mfma<PL>(bf[cb][PB], af[rb][PA], (Z) ? zero16 : acc[cb][rb]);                \
+    else                                                                                               \
+      acc[cb][rb] = chain_mfma<PL>(af[rb][PA], bf[cb][PB], (Z) ? zero16 : acc[cb][rb]);
   f32x16 zero16;
 #pragma unroll
   for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
@@ -1295,46 +1304,6 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
     S4G_F2_STRIP(true, true, wcur, cb_stride, wnxt, cb_stride)
   }
   S4G_STAMP(4 + 4 * ph);
-  if constexpr (LOADER == LOAD_PLAIN && EPI2 == EPI_STORE) {
-    if (!p.Wfrag2) {
-      // ONE layer (the plain single-layer launches of a step run here instead of on the tiled kernel: the
-      // A panel is staged K columns at a time, W streams through the register ring, two barriers per
-      // K-wide chunk instead of two per 32 columns): out = act(scale * acc + bias), this workgroup's
-      // 64 positions x this group's K channels (the caller maps 256-channel strips of a wider layer to
-      // groups that share A).  Operands are swapped: a lane holds 4 consecutive channels of a position.
-      float omax1 = 0.f;
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int nn = wc * 64 + nb * 32 + 8 * j + 4 * lh;
-          const float4 sc4 = *reinterpret_cast<const float4*>(epi_s + nb * 32 + 8 * j + 4 * lh);
-          const float4 b4 = *reinterpret_cast<const float4*>(epi_s + 64 + nb * 32 + 8 * j + 4 * lh);
-          const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
-          const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-          for (int pb = 0; pb < 2; ++pb) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float x = __fmaf_rn(acc[nb][pb][4 * j + e], scv[e], bv[e]);
-              if (p.relu) x = fmaxf(x, 0.f);
-              v[e] = x;
-              omax1 = fmaxf(omax1, fabsf(x));
-            }
-            const int row = p0 + wr * 64 + pb * 32 + li;
-            if (row < p.P)
-              *reinterpret_cast<float4*>(p.out + (size_t)row * p.ldc + p.c_coff + g * p.c_gcol + nn) =
-                  make_float4(v[0], v[1], v[2], v[3]);
-          }
-        }
-      if (PL == 2 && p.out_amax) {
-        const uint32_t wm = wave_max_u32(__float_as_uint(omax1));
-        if (lane == 0) amax_publish(p.out_amax, wm, (blockIdx.x * 4 + wave) * 5 + g, p0, p_hi, p.rps);
-      }
-      return;
-    }
-  }
   if (S4G_CHAIN_ABLATE & 4) {
     chain_keep_alive(acc[0][0]); chain_keep_alive(acc[0][1]); chain_keep_alive(acc[1][0]); chain_keep_alive(acc[1][1]);
     __syncthreads();
@@ -1350,7 +1319,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
       const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
       const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-      for (int pb = 0; pb < 2; ++pb)
+      for (int pb = 0; pb < NRB; ++pb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float x = __fmaf_rn(acc[nb][pb][4 * j + e], scv[e], bv[e]);
@@ -1359,6 +1328,33 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
           if constexpr (PL == 2) tmax = fmaxf(tmax, fabsf(x));
         }
     }
+  if constexpr (LOADER == LOAD_PLAIN && EPI2 == EPI_STORE) {
+    if (!p.Wfrag2) {
+      // ONE layer (the plain single-layer launches of a step run here instead of on the tiled kernel where
+      // that is faster: the A panel is staged K columns at a time, W streams through the register ring, two
+      // barriers per K-wide chunk instead of two per 32 columns): the activated values above ARE the output --
+      // this workgroup's positions x this group's K channels (the caller maps 256-channel strips of a wider
+      // layer to groups that share A).  Operands are swapped: a lane holds 4 consecutive channels of a position.
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int nn = wc * 64 + nb * 32 + 8 * j + 4 * lh;
+#pragma unroll
+          for (int pb = 0; pb < NRB; ++pb) {
+            const int row = p0 + wr * WROWS + pb * 32 + li;
+            if (row < p.P)
+              *reinterpret_cast<float4*>(p.out + (size_t)row * p.ldc + p.c_coff + g * p.c_gcol + nn) =
+                  make_float4(acc[nb][pb][4 * j], acc[nb][pb][4 * j + 1], acc[nb][pb][4 * j + 2], acc[nb][pb][4 * j + 3]);
+          }
+        }
+      if (PL == 2 && p.out_amax) {
+        const uint32_t wm = wave_max_u32(__float_as_uint(tmax));
+        if (lane == 0) amax_publish(p.out_amax, wm, (blockIdx.x * 4 + wave) * 5 + g, p0, p_hi, p.rps);
+      }
+      return;
+    }
+  }
   float sh = 1.f;
   if constexpr (PL == 2) {
     const uint32_t wm = wave_max_u32(__float_as_uint(tmax));
@@ -1382,8 +1378,8 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int pb = 0; pb < 2; ++pb) {
-        uint16_t* dst = Ah + (wr * 64 + pb * 32 + li) * astr + wc * 64 + nb * 32 + 8 * j + 4 * lh;
+      for (int pb = 0; pb < NRB; ++pb) {
+        uint16_t* dst = Ah + (wr * WROWS + pb * 32 + li) * astr + wc * 64 + nb * 32 + 8 * j + 4 * lh;
         if constexpr (PL == 2) {
           const float4 v = make_float4(acc[nb][pb][4 * j], acc[nb][pb][4 * j + 1], acc[nb][pb][4 * j + 2],
                                        acc[nb][pb][4 * j + 3]);
@@ -1414,14 +1410,17 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
   prime_a();
   WRef wstrip = w2;
   const float* __restrict__ bg2 = bgF;
-  // distinct-row form: the output rows of this half-wave's eight 4-row groups (rows 64 wr + 32 lh + 4 i ..)
-  int sidv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // distinct-row form: the output rows of this half-wave's eight 4-row groups per 64 rows (rows WROWS wr + 64 c + 32 lh + 4 i ..)
+  int sidv[NRB / 2][8] = {};
   if constexpr (SEGMAX) {
     if (seg_scene) {
-      const int4* sp = reinterpret_cast<const int4*>(p.seg4 + ((p0 + wr * 64 + lh * 32) >> 2));
-      const int4 s0 = sp[0], s1 = sp[1];
-      sidv[0] = s0.x; sidv[1] = s0.y; sidv[2] = s0.z; sidv[3] = s0.w;
-      sidv[4] = s1.x; sidv[5] = s1.y; sidv[6] = s1.z; sidv[7] = s1.w;
+#pragma unroll
+      for (int c = 0; c < NRB / 2; ++c) {
+        const int4* sp = reinterpret_cast<const int4*>(p.seg4 + ((p0 + wr * WROWS + c * 64 + lh * 32) >> 2));
+        const int4 s0 = sp[0], s1 = sp[1];
+        sidv[c][0] = s0.x; sidv[c][1] = s0.y; sidv[c][2] = s0.z; sidv[c][3] = s0.w;
+        sidv[c][4] = s1.x; sidv[c][5] = s1.y; sidv[c][6] = s1.z; sidv[c][7] = s1.w;
+      }
     }
   }
   for (int strip = 0; strip < nstrip2; ++strip, wstrip = wstrip + strip_stride) {
@@ -1453,7 +1452,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
           const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
           const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-          for (int pb = 0; pb < 2; ++pb) {
+          for (int pb = 0; pb < NRB; ++pb) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1462,7 +1461,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
               v[e] = x;
               omax = fmaxf(omax, fabsf(x));
             }
-            const int row = p0 + wr * 64 + pb * 32 + li;
+            const int row = p0 + wr * WROWS + pb * 32 + li;
             if (row < p.P)
               *reinterpret_cast<float4*>(p.out + (size_t)row * p.ldc + p.c_coff + g * p.c_gcol + nn) =
                   make_float4(v[0], v[1], v[2], v[3]);
@@ -1487,14 +1486,16 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
         const float sc = __shfl(e_sc, cb * 32 + li);
         const float bias = __shfl(e_bias, cb * 32 + li);
         const int nn = n0 + cb * 32 + li;
+#pragma unroll
+        for (int c = 0; c < NRB / 2; ++c) {      // every 64 rows of the wave: two 32-row blocks
         float v[8];
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
-          // rows 32 rb + 8 qd + 4 lh + (0..3) = group 8 rb + 2 qd + lh of the wave's 16
-          const float o0 = fmaxf(fmaxf(acc[0][cb][4 * qd], acc[0][cb][4 * qd + 1]),
-                                 fmaxf(acc[0][cb][4 * qd + 2], acc[0][cb][4 * qd + 3]));
-          const float o1 = fmaxf(fmaxf(acc[1][cb][4 * qd], acc[1][cb][4 * qd + 1]),
-                                 fmaxf(acc[1][cb][4 * qd + 2], acc[1][cb][4 * qd + 3]));
+          // rows 32 rb + 8 qd + 4 lh + (0..3) = group 8 rb + 2 qd + lh of the 64 rows' 16
+          const float o0 = fmaxf(fmaxf(acc[cb][2 * c][4 * qd], acc[cb][2 * c][4 * qd + 1]),
+                                 fmaxf(acc[cb][2 * c][4 * qd + 2], acc[cb][2 * c][4 * qd + 3]));
+          const float o1 = fmaxf(fmaxf(acc[cb][2 * c + 1][4 * qd], acc[cb][2 * c + 1][4 * qd + 1]),
+                                 fmaxf(acc[cb][2 * c + 1][4 * qd + 2], acc[cb][2 * c + 1][4 * qd + 3]));
           const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(o0), __float_as_uint(o1), false, false);
           v[2 * qd] = __uint_as_float(r[0]);       // lower half: block 0's group 2 qd;     upper: block 1's
           v[2 * qd + 1] = __uint_as_float(r[1]);   // lower half: block 0's group 2 qd + 1; upper: block 1's
@@ -1505,16 +1506,17 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
           omax = fmaxf(omax, x);
           if (nn < CoutF) atomicMax(outu + (size_t)seg * p.ldc + p.c_coff + nn, __float_as_uint(x));
         };
-        int cur = sidv[0];
+        int cur = sidv[c][0];
         float m = v[0];
 #pragma unroll
         for (int i = 1; i < 8; ++i) {
-          const bool chg = sidv[i] != cur;
+          const bool chg = sidv[c][i] != cur;
           if (chg) emit(cur, m);
           m = chg ? v[i] : fmaxf(m, v[i]);
-          cur = sidv[i];
+          cur = sidv[c][i];
         }
         emit(cur, m);
+        }
       }
       if (PL == 2 && p.out_amax) {
         const uint32_t wm = wave_max_u32(__float_as_uint(omax));
@@ -1523,28 +1525,33 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
     } else if (q.relu && p.K == 64) {
       // max over the 64 neighbours FIRST, on the raw accumulators (the scales are positive powers
       // of two, so max commutes with them exactly), then one scale + bias + ReLU per channel:
-      // 1 instead of 4 vector instructions per accumulator element
+      // 1 instead of 4 vector instructions per accumulator element.  A wave's rows are NRB / 2 centroids.
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
         const float sc = __shfl(e_sc, cb * 32 + li);
         const float bias = __shfl(e_bias, cb * 32 + li);
-        float m = acc[0][cb][0];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[rb][cb][r]);
-        m = fmaxf(m, __shfl_xor(m, 32));
-        const float v = fmaxf(m * sc + bias, 0.f);
-        omax = fmaxf(omax, v);
         const int nn = n0 + cb * 32 + li;
-        if (nn < CoutF && lh == 0 && p0 + wr * 64 < p.P)
-          p.out[(size_t)((p0 + wr * 64) >> 6) * p.ldc + p.c_coff + nn] = v;
+#pragma unroll
+        for (int c = 0; c < NRB / 2; ++c) {
+          float m = acc[cb][2 * c][0];
+#pragma unroll
+          for (int rb = 2 * c; rb < 2 * c + 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[cb][rb][r]);
+          m = fmaxf(m, __shfl_xor(m, 32));
+          const float v = fmaxf(m * sc + bias, 0.f);
+          omax = fmaxf(omax, v);
+          const int row0 = p0 + wr * WROWS + c * 64;
+          if (nn < CoutF && lh == 0 && row0 < p.P) p.out[(size_t)(row0 >> 6) * p.ldc + p.c_coff + nn] = v;
+        }
       }
       if (PL == 2 && p.out_amax) {
         const uint32_t wm = wave_max_u32(__float_as_uint(omax));
         if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave + strip, p0, p_hi, p.rps);
       }
-    } else {
+    } else if constexpr (NRB == 2) {
+      // (no ReLU behind the last layer: the generic max epilogue, which takes [row block][channel block])
+      f32x16 acct[2][2];
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
         const float sc = __shfl(e_sc, cb * 32 + li);
@@ -1554,8 +1561,8 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float v = acc[rb][cb][r] * sc;
-            acc[rb][cb][r] = v;
+            const float v = acc[cb][rb][r] * sc;
+            acct[rb][cb][r] = v;
             mx = fmaxf(mx, v);
             mn = fminf(mn, v);
           }
@@ -1566,7 +1573,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
         const uint32_t wm = wave_max_u32(__float_as_uint(fmaxf(omax, 0.f)));
         if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave + strip, p0, p_hi, p.rps);
       }
-      gemm_epilogue<EPI_MAX, 2>(q, acc, bg2, g, p0, n0, wave, wr, 0, li, lh, smemf);
+      gemm_epilogue<EPI_MAX, 2>(q, acct, bg2, g, p0, n0, wave, wr, 0, li, lh, smemf);
     }
   }
   S4G_STAMP(11);
@@ -1577,7 +1584,8 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8) ? 3 : 2) 
 template <int LOADER, int EPI2, int RW, int KC, int PL>
 static int launch_mlp_chain(const GemmParams& p, int groups, hipStream_t st) {
   constexpr int CW = RW == 8 ? 8 : 4 / RW, RWN = RW == 8 ? 1 : RW;
-  constexpr int BM = 64 * RWN, K = 64 * CW, NW = RWN * CW;
+  constexpr int NRB = PL == 1 ? S4G_CHAIN_BF16_NRB : 2;
+  constexpr int BM = 32 * NRB * RWN, K = 64 * CW, NW = RWN * CW;
   constexpr size_t lds = sizeof(uint16_t) * PL * BM * (size_t)(K + 8) + sizeof(float) * (NW * 128 + 16);
   static_assert(lds <= (RW == 8 ? 160 : 80) * 1024, "two workgroups per CU (one for the 8-wave form)");
   static LdsAttrCache lds_cache;
@@ -1783,7 +1791,7 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
     // distinct-row form: only the fused chain with the max epilogue knows how to merge a centroid's pieces
     if ((d->seg4 != nullptr) != (d->seg_rows != nullptr)) return S4G_EINVAL;
     if (d->seg4 && (!d->rel_xyz4 || !d->W2_f16x2_frag || d->epilogue != S4G_GEMM_EPI_MAX || d->K != 64 ||
-                    d->rows_per_scene <= 0 || (d->rows_per_scene & 127) || !d->relu2 || d->W3_f16x2_frag))
+                    d->rows_per_scene <= 0 || (d->rows_per_scene & 255) || !d->relu2 || d->W3_f16x2_frag))
       return S4G_EINVAL;
   } else if (d->loader == S4G_GEMM_LOAD_GATHER_ADD) {
     if (!d->gidx || !d->xyz || !d->ctr || !d->mlp1_w || !d->feat || (d->Cin & 3) || d->Cf != d->Cin ||

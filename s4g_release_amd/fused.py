@@ -471,7 +471,7 @@ class FusedPointNet2:
         where the shape is not supported."""
         B, _, N = xyz.shape
         _, M, K = gidx.shape
-        if K % 4 or (M * K) % 128:
+        if K % 4 or (M * K) % 256:
             return None
         dev = xyz.device
         rel = torch.empty((B * M * K, 4), dtype=torch.float32, device=dev)

@@ -32,7 +32,7 @@ def _unique_reference(pts, ctr, gidx, cnt, K):
             rel[b * cap + r:b * cap + r + c4, :3] = (pts[b][:, j] - ctr[b][:, m:m + 1]).T
             seg4[(b * cap + r) // 4:(b * cap + r + c4) // 4] = b * M + m
             r += c4
-        rows[b] = (r + 127) // 128 * 128
+        rows[b] = (r + 255) // 256 * 256
         seg4[(b * cap + r) // 4:(b * cap + rows[b]) // 4] = -1
     return rel, seg4, row_start, rows
 
@@ -89,7 +89,7 @@ def test_unsupported_shapes_are_refused(dev):
     a = (z.data_ptr(), z.data_ptr(), zi.data_ptr(), zi.data_ptr())
     o = (z.data_ptr(), zi.data_ptr(), zi.data_ptr(), zi.data_ptr(), st)
     assert f(*a, 1, 64, 4, 30, *o) == _cabi.S4G_EUNSUPPORTED      # K % 4
-    assert f(*a, 1, 64, 3, 16, *o) == _cabi.S4G_EUNSUPPORTED      # M K % 128
+    assert f(*a, 1, 64, 3, 16, *o) == _cabi.S4G_EUNSUPPORTED      # M K % 256
 
 
 def _net(dev, seed=3):
