@@ -57,7 +57,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3      # fp32-in MFMA = fp32 vector peak
 BF16_MFMA_PEAK_TF = 2500.0     # dense bf16 / fp16 MFMA (no sparsity)
 GFLOP_PER_SCENE = 203.48       # SURVEY.md Appendix B (BN folded, 2*MAC), N = 25 600
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
 
 
 def parse(argv=None):
@@ -161,7 +161,7 @@ def source_stamp():
 
 
 def load_traffic(key):
-    """(bytes, source, None) of `key` in profiles/r03_traffic.json when its stamp matches this
+    """(bytes, source, None) of `key` in profiles/r04_traffic.json when its stamp matches this
     tree, else (None, None, reason)."""
     try:
         with open(TRAFFIC_FILE) as f:
@@ -537,18 +537,18 @@ def main():
                                         "warmup": p_warm, "roofline_frac": p_roof["frac"] if p_roof else None,
                                         "roofline_peak_TFLOPs": p_roof["peak"] if p_roof else None}
                 del p_runner
-            # ---- a batch that is NOT all "proven": 2 of the 16 scenes are `dup-heavy` clouds (exact
-            # distance ties), so the FPS prefix check refuses them and the level-2 / level-3 samplers
-            # run inside the timed region (the headline's tabletop scenes all pass the check)
+            # ---- a batch that is NOT all "proven": 2 of the 16 scenes are `lattice` clouds (coordinates
+            # snapped to a 3.9 mm lattice: exact distance ties), so the FPS prefix check refuses them and
+            # the level-2 / level-3 samplers run inside the timed region (the headline's scenes all pass)
             n_tie = min(2, B)
             mix = synth.make_batch(scene_ids, args.points, variant=args.variant)
-            mix[:n_tie] = synth.make_batch(scene_ids[:n_tie], args.points, variant="dup-heavy")
+            mix[:n_tie] = synth.make_batch(scene_ids[:n_tie], args.points, variant="lattice")
             mix_batch = {"scene_points": torch.from_numpy(mix).to(dev)}
             x_steps, x_warm = 10, 3
             x_el, x_step, x_sum, _ = timed_region(x_steps, x_warm, collective=False, run=runner, data=mix_batch,
                                                   gathered=False)
             lv = [k for k in x_sum if k.startswith("fps[") and not k.startswith("fps[N=%d," % args.points)]
-            mixed_batch = {"workload": "%d `dup-heavy` + %d `%s` scenes per step: the tie-heavy scenes fail the FPS "
+            mixed_batch = {"workload": "%d `lattice` + %d `%s` scenes per step: the tie-heavy scenes fail the FPS "
                                        "prefix proof, their level-2 / level-3 samplers run in the timed region"
                                        % (n_tie, B - n_tie, args.variant),
                            "value": round(B * x_steps / x_el, 2), "unit": "scenes/sec",

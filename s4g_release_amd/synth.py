@@ -137,6 +137,12 @@ def make_scene(scene_id, num_points=25600, seed=DEFAULT_SEED, variant="tabletop-
         uniq = _permute(seed, scene_id, _tabletop_points(seed, scene_id, 10000))
         pick = (_u01(seed, scene_id, np.arange(num_points, dtype=np.uint64), 50) * 10000)
         pts = uniq[np.minimum(pick.astype(np.int64), 9999)]
+    elif variant == "lattice":
+        # the table-top scene snapped to a 2^-8 m (3.9 mm) lattice: exact distance ties everywhere, so FPS
+        # over the level-1 centroids is NOT their prefix in general (the tie rule decides) -- the scenes
+        # that make the conditional level-2 / level-3 samplers run
+        pts = _permute(seed, scene_id, _tabletop_points(seed, scene_id, num_points))
+        pts = np.round(pts * 256.0) / 256.0
     else:
         raise ValueError("unknown variant %r" % (variant,))
     return np.ascontiguousarray(pts.T.astype(np.float32))

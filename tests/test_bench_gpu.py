@@ -55,7 +55,8 @@ def test_bench_prints_one_contract_line():
     assert set(legs) == {"fp32", "bf16x3"} and all(0 < v["value"] < d["value"] * 1.05 for v in legs.values())
     assert legs["fp32"]["roofline_peak_TFLOPs"] == 157.3
     x = d["mixed_batch"]
-    assert x["value"] > 0 and any(v > 0 for v in x["deeper_fps_launches_ms"].values())
+    # the lattice scenes fail the prefix proof: the level-2 sampler (a 1 023-step chain, ~0.9 ms) really ran
+    assert x["value"] > 0 and max(x["deeper_fps_launches_ms"].values()) > 0.3
     sh = d["distributed"]
     assert sh["world"] == 1 and sh["communicator_size"] == 1 and sh["per_rank"][0]["scenes"] == [0, 16]
 
