@@ -214,6 +214,8 @@ def main():
     torch.cuda.synchronize()
     lib.s4g_mlp_gemm_f32, lib.s4g_heads_chain_f32 = real_gemm, real_heads
     F._timed.__enter__ = real_timed_enter
+    # (a launch with a data-dependent row count -- the distinct-row SA level -- reports its flops lazily)
+    recorded = [(n, f() if callable(f) else f, fn, d) for n, f, fn, d in recorded]
 
     st = torch.cuda.current_stream().cuda_stream
     rows = []
