@@ -603,6 +603,33 @@ int s4g_radius_outlier_mask_f32(const float *xyz_3n, int64_t N, float radius,
                                 int32_t nb_points, uint8_t *keep_n, void *ws, size_t ws_bytes,
                                 int flags, s4g_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * The operators in DOUBLE (ABI >= 8).  The reference's extension dispatches every kernel over float and
+ * double (AT_DISPATCH_FLOATING_TYPES: sampling_kernel.cu:148-167, ball_query_kernel.cu:116-128,
+ * grouping_kernel.cu:48-51,136-150, interpolate_kernel.cu:114-126,212-232,317-338).  Same layouts, index
+ * types, tie rules and padding as the *_f32 entry points; plain kernels (S4G never uses double).
+ *   s4g_fps_f64: ws = (B, N) doubles (the reference's `temp`), ws_bytes >= 8 B N.
+ *   s4g_ball_query_f64: `radius` is a C float as in ball_query.h and is cast to double before squaring.
+ *   gather_points = group_points with K == 1.  Inverse-distance weights: torch ops in the caller.
+ * ------------------------------------------------------------------------- */
+int s4g_fps_f64(const double *xyz_b3n, int64_t B, int64_t N, int64_t M, int64_t *idx_bm, void *ws,
+                size_t ws_bytes, int flags, s4g_stream_t stream);
+int s4g_ball_query_f64(const double *xyz_b3n, const double *ctr_b3m, int64_t B, int64_t N, int64_t M,
+                       float radius, int64_t K, int64_t *idx_bmk, int64_t *cnt_bm, int flags,
+                       s4g_stream_t stream);
+int s4g_three_nn_f64(const double *query_b3n1, const double *key_b3n2, int64_t B, int64_t N1, int64_t N2,
+                     int64_t *idx_bn3, double *d2_bn3, int flags, s4g_stream_t stream);
+int s4g_group_points_f64(const double *in_bcn, const int64_t *idx_bmk, int64_t B, int64_t C, int64_t N,
+                         int64_t M, int64_t K, double *out_bcmk, s4g_stream_t stream);
+int s4g_group_points_backward_f64(const double *gout_bcmk, const int64_t *idx_bmk, int64_t B, int64_t C,
+                                  int64_t N, int64_t M, int64_t K, double *gin_bcn, s4g_stream_t stream);
+int s4g_three_interpolate_f64(const double *feat_bcn2, const int64_t *idx_bn3, const double *w_bn3,
+                              int64_t B, int64_t C, int64_t N2, int64_t N1, double *out_bcn1, int flags,
+                              s4g_stream_t stream);
+int s4g_three_interpolate_backward_f64(const double *gout_bcn1, const int64_t *idx_bn3,
+                                       const double *w_bn3, int64_t B, int64_t C, int64_t N2, int64_t N1,
+                                       double *gin_bcn2, s4g_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

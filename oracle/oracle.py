@@ -6,7 +6,7 @@ may import this module, and only as the checker / reported CPU baseline.  The
 product package (``s4g_release_amd``) never imports it.
 
 Every function takes and returns numpy arrays in the reference's Python-level
-layouts (``(B,3,N)`` fp32 clouds, int64 indices) and mirrors one reference
+layouts (``(B,3,N)`` fp32 -- or, like the reference's extension, fp64 -- clouds, int64 indices) and mirrors one reference
 operator (PN2U = inference/grasp_proposal/network_models/models/pointnet2_utils):
 
   fps / fps_literal     PN2U/csrc/sampling_kernel.cu:49-172
@@ -28,6 +28,7 @@ _LIB_PATH = os.path.join(_HERE, "libs4g_oracle.so")
 _lib = None
 
 _f32p = ctypes.POINTER(ctypes.c_float)
+_f64p = ctypes.POINTER(ctypes.c_double)
 _i64p = ctypes.POINTER(ctypes.c_int64)
 _i64 = ctypes.c_int64
 
@@ -64,11 +65,35 @@ def lib():
         L.s4g_oracle_three_interpolate_backward.argtypes = [_f32p, _i64p, _f32p, _i64, _i64, _i64,
                                                             _i64, _f32p]
         L.s4g_oracle_interp_weights.argtypes = [_f32p, _i64, _i64, ctypes.c_float, _f32p]
+        # scalar_t = double: the same source compiled with -DS4G_ORACLE_F64 (AT_DISPATCH_FLOATING_TYPES' other case)
+        d, dbl = _f64p, ctypes.c_double
+        for name in ("s4g_oracle_fps_f64", "s4g_oracle_fps_literal_f64"):
+            getattr(L, name).argtypes = [d, _i64, _i64, _i64, _i64p, ctypes.c_int]
+        L.s4g_oracle_ball_query_f64.argtypes = [d, d, _i64, _i64, _i64, dbl, _i64, _i64p, _i64p, ctypes.c_int]
+        L.s4g_oracle_group_points_f64.argtypes = [d, _i64p, _i64, _i64, _i64, _i64, _i64, d]
+        L.s4g_oracle_group_points_backward_f64.argtypes = [d, _i64p, _i64, _i64, _i64, _i64, _i64, d]
+        L.s4g_oracle_gather_points_f64.argtypes = [d, _i64p, _i64, _i64, _i64, _i64, d]
+        L.s4g_oracle_three_nn_f64.argtypes = [d, d, _i64, _i64, _i64, _i64p, d, ctypes.c_int]
+        L.s4g_oracle_three_interpolate_f64.argtypes = [d, _i64p, d, _i64, _i64, _i64, _i64, d, ctypes.c_int]
+        L.s4g_oracle_three_interpolate_backward_f64.argtypes = [d, _i64p, d, _i64, _i64, _i64, _i64, d]
+        L.s4g_oracle_interp_weights_f64.argtypes = [d, _i64, _i64, dbl, d]
     return _lib
 
 
 def _f32(a):
-    return np.ascontiguousarray(a, dtype=np.float32)
+    """float32, or float64 where the caller passes float64 (the operators' second dispatch case)."""
+    a = np.asarray(a)
+    return np.ascontiguousarray(a, dtype=np.float64 if a.dtype == np.float64 else np.float32)
+
+
+def _fn(name, a):
+    """The entry point for a's scalar type."""
+    return getattr(lib(), name + ("_f64" if a.dtype == np.float64 else ""))
+
+
+def _scalar(v, a):
+    """A C `float` argument of the float build; the double build's `scalar_t` otherwise."""
+    return ctypes.c_double(v) if a.dtype == np.float64 else ctypes.c_float(v)
 
 
 def _i64a(a):
@@ -76,7 +101,7 @@ def _i64a(a):
 
 
 def _fp(a):
-    return a.ctypes.data_as(_f32p)
+    return a.ctypes.data_as(_f64p if a.dtype == np.float64 else _f32p)
 
 
 def _ip(a):
@@ -94,7 +119,7 @@ def fps(points, num_centroids, fmad=0, literal=False):
     if C != 3:
         raise RuntimeError("points.size(1) must be 3")
     idx = np.zeros((B, num_centroids), dtype=np.int64)
-    fn = lib().s4g_oracle_fps_literal if literal else lib().s4g_oracle_fps
+    fn = _fn("s4g_oracle_fps_literal" if literal else "s4g_oracle_fps", points)
     _check(fn(_fp(points), B, N, num_centroids, _ip(idx), fmad), "fps")
     return idx
 
@@ -110,8 +135,9 @@ def ball_query(points, centroids, radius, num_neighbours, fmad=0):
     K = int(num_neighbours)
     idx = np.zeros((B, M, K), dtype=np.int64)
     cnt = np.zeros((B, M), dtype=np.int64)
-    _check(lib().s4g_oracle_ball_query(_fp(points), _fp(centroids), B, N, M,
-                                       ctypes.c_float(radius), K, _ip(idx), _ip(cnt), fmad),
+    # (the extension's `radius` is a C float whatever the tensors' type: ball_query.h; it is cast to scalar_t)
+    _check(_fn("s4g_oracle_ball_query", points)(_fp(points), _fp(centroids), B, N, M,
+                                                _scalar(float(np.float32(radius)), points), K, _ip(idx), _ip(cnt), fmad),
            "ball_query")
     return idx, cnt
 
@@ -120,8 +146,8 @@ def group_points(points, index):
     points, index = _f32(points), _i64a(index)
     B, C, N = points.shape
     _, M, K = index.shape
-    out = np.empty((B, C, M, K), dtype=np.float32)
-    _check(lib().s4g_oracle_group_points(_fp(points), _ip(index), B, C, N, M, K, _fp(out)),
+    out = np.empty((B, C, M, K), dtype=points.dtype)
+    _check(_fn("s4g_oracle_group_points", points)(_fp(points), _ip(index), B, C, N, M, K, _fp(out)),
            "group_points")
     return out
 
@@ -129,8 +155,8 @@ def group_points(points, index):
 def group_points_backward(grad_out, index, num_points):
     grad_out, index = _f32(grad_out), _i64a(index)
     B, C, M, K = grad_out.shape
-    gin = np.empty((B, C, num_points), dtype=np.float32)
-    _check(lib().s4g_oracle_group_points_backward(_fp(grad_out), _ip(index), B, C, num_points,
+    gin = np.empty((B, C, num_points), dtype=grad_out.dtype)
+    _check(_fn("s4g_oracle_group_points_backward", grad_out)(_fp(grad_out), _ip(index), B, C, num_points,
                                                   M, K, _fp(gin)), "group_points_backward")
     return gin
 
@@ -139,8 +165,8 @@ def gather_points(points, index):
     points, index = _f32(points), _i64a(index)
     B, C, N = points.shape
     M = index.shape[1]
-    out = np.empty((B, C, M), dtype=np.float32)
-    _check(lib().s4g_oracle_gather_points(_fp(points), _ip(index), B, C, N, M, _fp(out)),
+    out = np.empty((B, C, M), dtype=points.dtype)
+    _check(_fn("s4g_oracle_gather_points", points)(_fp(points), _ip(index), B, C, N, M, _fp(out)),
            "gather_points")
     return out
 
@@ -151,8 +177,8 @@ def three_nn(query_xyz, key_xyz, fmad=0):
     B, _, N1 = q.shape
     N2 = k.shape[2]
     idx = np.empty((B, N1, 3), dtype=np.int64)
-    d2 = np.empty((B, N1, 3), dtype=np.float32)
-    _check(lib().s4g_oracle_three_nn(_fp(q), _fp(k), B, N1, N2, _ip(idx), _fp(d2), fmad),
+    d2 = np.empty((B, N1, 3), dtype=q.dtype)
+    _check(_fn("s4g_oracle_three_nn", q)(_fp(q), _fp(k), B, N1, N2, _ip(idx), _fp(d2), fmad),
            "three_nn")
     return idx, d2
 
@@ -161,7 +187,7 @@ def interp_weights(d2, eps=1e-10):
     d2 = _f32(d2)
     B, N1, _ = d2.shape
     w = np.empty_like(d2)
-    _check(lib().s4g_oracle_interp_weights(_fp(d2), B, N1, ctypes.c_float(eps), _fp(w)),
+    _check(_fn("s4g_oracle_interp_weights", d2)(_fp(d2), B, N1, _scalar(eps, d2), _fp(w)),
            "interp_weights")
     return w
 
@@ -170,8 +196,9 @@ def three_interpolate(feature, index, weight, fmad=0):
     feature, index, weight = _f32(feature), _i64a(index), _f32(weight)
     B, C, N2 = feature.shape
     N1 = index.shape[1]
-    out = np.empty((B, C, N1), dtype=np.float32)
-    _check(lib().s4g_oracle_three_interpolate(_fp(feature), _ip(index), _fp(weight), B, C, N2,
+    weight = weight.astype(feature.dtype, copy=False)
+    out = np.empty((B, C, N1), dtype=feature.dtype)
+    _check(_fn("s4g_oracle_three_interpolate", feature)(_fp(feature), _ip(index), _fp(weight), B, C, N2,
                                               N1, _fp(out), fmad), "three_interpolate")
     return out
 
@@ -179,8 +206,9 @@ def three_interpolate(feature, index, weight, fmad=0):
 def three_interpolate_backward(grad_out, index, weight, num_inst):
     grad_out, index, weight = _f32(grad_out), _i64a(index), _f32(weight)
     B, C, N1 = grad_out.shape
-    gin = np.empty((B, C, num_inst), dtype=np.float32)
-    _check(lib().s4g_oracle_three_interpolate_backward(_fp(grad_out), _ip(index), _fp(weight),
+    weight = weight.astype(grad_out.dtype, copy=False)
+    gin = np.empty((B, C, num_inst), dtype=grad_out.dtype)
+    _check(_fn("s4g_oracle_three_interpolate_backward", grad_out)(_fp(grad_out), _ip(index), _fp(weight),
                                                        B, C, num_inst, N1, _fp(gin)),
            "three_interpolate_backward")
     return gin

@@ -85,6 +85,14 @@ SIGNATURES = {
     "s4g_fps_gather_ex_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp]),
     "s4g_fps_prefix_check_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _int, _vp]),
     "s4g_build_variants": (_int, []),
+    # double dispatch of the five operators (csrc/ops_f64.hip)
+    "s4g_fps_f64": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _sz, _int, _vp]),
+    "s4g_ball_query_f64": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _int, _vp]),
+    "s4g_three_nn_f64": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _vp]),
+    "s4g_group_points_f64": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "s4g_group_points_backward_f64": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "s4g_three_interpolate_f64": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp]),
+    "s4g_three_interpolate_backward_f64": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "s4g_group_rel_xyz_i32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "s4g_group_rel_xyz_unique_i32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "s4g_expected_score_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),

@@ -12,7 +12,8 @@ North-star spellings (``furthest_point_sample``, ``three_nn``,
 Like the reference, there is no CPU path: tensors must live on a HIP device
 (the reference's CHECK_CUDA), and a missing HIP library is an error.
 Differences, all deliberate:
-  * fp32 only (the reference also dispatches double; S4G never uses it);
+  * double tensors are accepted like in the reference (AT_DISPATCH_FLOATING_TYPES) and take plain
+    kernels (csrc/ops_f64.hip); the tuned kernels and the fused fast path are fp32 -- S4G never leaves it;
   * kernels run on torch's CURRENT stream and on the tensor's device (the
     reference launches on the legacy default stream without a device guard);
   * inputs are consumed channel-first as they come -- no transposed copies.
@@ -45,6 +46,21 @@ def _f32c(t, name):
     if t.dtype != torch.float32:
         raise RuntimeError("%s must be float32 (got %s)" % (name, t.dtype))
     return t.contiguous()
+
+
+def _is_f64(*tensors):
+    """The reference's extension dispatches over float and double (AT_DISPATCH_FLOATING_TYPES): double
+    tensors take the *_f64 entry points (csrc/ops_f64.hip: plain kernels, same semantics; the tuned
+    kernels are the float ones).  Mixed float / double arguments are an error, as in the reference."""
+    kinds = {t.dtype for t in tensors if t is not None and t.is_floating_point()}
+    if kinds == {torch.float64}:
+        for t in tensors:
+            if t is not None:
+                _check_dev(t, "tensor")
+        return True
+    if torch.float64 in kinds:
+        raise RuntimeError("expected all floating-point arguments to share one dtype (float or double)")
+    return False
 
 
 def _i64c(t, name):
@@ -135,6 +151,23 @@ def _workspace(op, dev, B, d0, d1, d2):
 # (reference csrc/main.cpp:7-13)
 # ----------------------------------------------------------------------------
 def _farthest_point_sample(points, num_centroids):
+    if _is_f64(points):
+        points = points.contiguous()
+        if points.dim() != 3 or points.size(1) != 3:
+            raise RuntimeError("points.size(1) does not equal to 3")
+        B, _, N = points.shape
+        M = int(num_centroids)
+        if not M > 0:
+            raise RuntimeError("num_centroids is not greater than 0")
+        if not N >= M:
+            raise RuntimeError("num_points is not greater than or equal to num_centroids")
+        index = torch.empty((B, M), dtype=torch.int64, device=points.device)
+        ws = torch.empty((B, N), dtype=torch.float64, device=points.device)     # `temp` of sampling_kernel.cu:144
+        with torch.cuda.device(points.device):
+            rc = _cabi.lib().s4g_fps_f64(_ptr(points), B, N, M, _ptr(index), _ptr(ws), ws.numel() * 8,
+                                         _DIST_FLAGS, _stream())
+        _cabi.check(rc, "farthest_point_sample (double)")
+        return index
     points = _f32c(points, "points")
     if points.dim() != 3 or points.size(1) != 3:
         raise RuntimeError("points.size(1) does not equal to 3")  # sampling_kernel.cu:137
@@ -155,8 +188,12 @@ def _farthest_point_sample(points, num_centroids):
 
 
 def _ball_query(points, centroids, radius, num_neighbours):
-    points = _f32c(points, "points")
-    centroids = _f32c(centroids, "centroids")
+    f64 = _is_f64(points, centroids)
+    if f64:
+        points, centroids = points.contiguous(), centroids.contiguous()
+    else:
+        points = _f32c(points, "points")
+        centroids = _f32c(centroids, "centroids")
     if points.dim() != 3 or points.size(1) != 3:
         raise RuntimeError("points.size(1) does not equal to 3")  # ball_query_kernel.cu:102
     if centroids.dim() != 3 or centroids.size(1) != 3:
@@ -170,6 +207,12 @@ def _ball_query(points, centroids, radius, num_neighbours):
         raise RuntimeError("num_neighbours must be positive")
     index = torch.empty((B, M, K), dtype=torch.int64, device=points.device)
     count = torch.empty((B, M), dtype=torch.int64, device=points.device)
+    if f64:
+        with torch.cuda.device(points.device):
+            rc = _cabi.lib().s4g_ball_query_f64(_ptr(points), _ptr(centroids), B, N, M, float(radius), K,
+                                                _ptr(index), _ptr(count), _DIST_FLAGS, _stream())
+        _cabi.check(rc, "ball_query (double)")
+        return index, count
     with torch.cuda.device(points.device):
         ws, nbytes = _workspace(_cabi.S4G_OP_BALL_QUERY, points.device, B, N, M, K)
         with _timed("ball_query[N=%d,M=%d,K=%d]" % (N, M, K),
@@ -187,6 +230,9 @@ def query_and_group(points, centroids, radius, num_neighbours):
     Returns (index (B,M,K) int64, count (B,M) int64, grouped xyz (B,3,M,K) fp32),
     identical to the two reference operators called in sequence
     (QueryGrouper.forward, modules.py:39-42)."""
+    if _is_f64(points, centroids):
+        index, count = _ball_query(points, centroids, radius, num_neighbours)
+        return index, count, _group_points_forward(points, index)
     points = _f32c(points, "points")
     centroids = _f32c(centroids, "centroids")
     if points.dim() != 3 or points.size(1) != 3 or centroids.dim() != 3 or centroids.size(1) != 3:
@@ -211,6 +257,17 @@ def query_and_group(points, centroids, radius, num_neighbours):
 
 
 def _group_points_forward(points, index):
+    if _is_f64(points):
+        points, index = points.contiguous(), _i64c(index, "index")
+        if points.dim() != 3 or index.dim() != 3 or index.size(0) != points.size(0):
+            raise RuntimeError("input / index must be 3-d and share the batch size")
+        B, C, N = points.shape
+        _, M, K = index.shape
+        out = torch.empty((B, C, M, K), dtype=torch.float64, device=points.device)
+        with torch.cuda.device(points.device):
+            rc = _cabi.lib().s4g_group_points_f64(_ptr(points), _ptr(index), B, C, N, M, K, _ptr(out), _stream())
+        _cabi.check(rc, "group_points_forward (double)")
+        return out
     points = _f32c(points, "input")
     index = _i64c(index, "index")
     if points.dim() != 3:
@@ -250,6 +307,15 @@ def _group_points_forward(points, index):
 
 
 def _group_points_backward(grad_output, index, num_points):
+    if _is_f64(grad_output):
+        grad_output, index = grad_output.contiguous(), _i64c(index, "index")
+        B, C, M, K = grad_output.shape
+        gin = torch.empty((B, C, int(num_points)), dtype=torch.float64, device=grad_output.device)
+        with torch.cuda.device(grad_output.device):
+            rc = _cabi.lib().s4g_group_points_backward_f64(_ptr(grad_output), _ptr(index), B, C, int(num_points), M, K,
+                                                           _ptr(gin), _stream())
+        _cabi.check(rc, "group_points_backward (double)")
+        return gin
     grad_output = _f32c(grad_output, "grad_output")
     index = _i64c(index, "index")
     if grad_output.dim() != 4 or index.dim() != 3:
@@ -266,6 +332,18 @@ def _group_points_backward(grad_output, index, num_points):
 
 
 def _point_search(query_xyz, key_xyz, num_neighbours):
+    if _is_f64(query_xyz, key_xyz):
+        query_xyz, key_xyz = query_xyz.contiguous(), key_xyz.contiguous()
+        B, N1, N2 = query_xyz.size(0), query_xyz.size(2), key_xyz.size(2)
+        if key_xyz.size(0) != B or query_xyz.size(1) != 3 or key_xyz.size(1) != 3 or int(num_neighbours) != 3 or N2 < 3:
+            raise RuntimeError("search_nn_distance: (B, 3, N1) queries, (B, 3, N2 >= 3) keys, 3 neighbours")
+        index = torch.empty((B, N1, 3), dtype=torch.int64, device=query_xyz.device)
+        dist = torch.empty((B, N1, 3), dtype=torch.float64, device=query_xyz.device)
+        with torch.cuda.device(query_xyz.device):
+            rc = _cabi.lib().s4g_three_nn_f64(_ptr(query_xyz), _ptr(key_xyz), B, N1, N2, _ptr(index), _ptr(dist),
+                                              _DIST_FLAGS, _stream())
+        _cabi.check(rc, "point_search (double)")
+        return index, dist
     query_xyz = _f32c(query_xyz, "query_xyz")
     key_xyz = _f32c(key_xyz, "key_xyz")
     B = query_xyz.size(0)
@@ -304,6 +382,18 @@ def _point_search(query_xyz, key_xyz, num_neighbours):
 
 
 def _interpolate_forward(feature, index, weight):
+    if _is_f64(feature, weight):
+        feature, index, weight = feature.contiguous(), _i64c(index, "index"), weight.contiguous()
+        B, C, N2 = feature.shape
+        N1 = index.size(1)
+        if tuple(index.shape) != (B, N1, 3) or tuple(weight.shape) != (B, N1, 3):
+            raise RuntimeError("index / weight must be (batch_size, N, 3)")
+        out = torch.empty((B, C, N1), dtype=torch.float64, device=feature.device)
+        with torch.cuda.device(feature.device):
+            rc = _cabi.lib().s4g_three_interpolate_f64(_ptr(feature), _ptr(index), _ptr(weight), B, C, N2, N1, _ptr(out),
+                                                       _DIST_FLAGS, _stream())
+        _cabi.check(rc, "interpolate_forward (double)")
+        return out
     feature = _f32c(feature, "input")
     index = _i64c(index, "index")
     weight = _f32c(weight, "weight")
@@ -334,6 +424,15 @@ def _interpolate_forward(feature, index, weight):
 
 
 def _interpolate_backward(grad_output, index, weight, num_inst):
+    if _is_f64(grad_output, weight):
+        grad_output, index, weight = grad_output.contiguous(), _i64c(index, "index"), weight.contiguous()
+        B, C, N1 = grad_output.shape
+        gin = torch.empty((B, C, int(num_inst)), dtype=torch.float64, device=grad_output.device)
+        with torch.cuda.device(grad_output.device):
+            rc = _cabi.lib().s4g_three_interpolate_backward_f64(_ptr(grad_output), _ptr(index), _ptr(weight), B, C,
+                                                                int(num_inst), N1, _ptr(gin), _stream())
+        _cabi.check(rc, "interpolate_backward (double)")
+        return gin
     grad_output = _f32c(grad_output, "grad_output")
     index = _i64c(index, "index")
     weight = _f32c(weight, "weight")
@@ -394,6 +493,9 @@ def three_nn_weights(query_xyz, key_xyz, eps=1e-10):
 def interp_weights(distance, eps=1e-10):
     """Inverse-distance weights of FeatureInterpolator.forward (modules.py:118-120)
     in one launch instead of three elementwise ones."""
+    if _is_f64(distance):      # modules.py:118-120 as written, in the tensor's own type
+        inv = 1.0 / torch.clamp(distance, min=eps)
+        return inv / inv.sum(dim=2, keepdim=True)
     distance = _f32c(distance, "distance")
     B, N1, _ = distance.shape
     w = torch.empty_like(distance)
@@ -416,6 +518,8 @@ def gather_points(points, index):
     if points.requires_grad:
         index_expand = index.unsqueeze(1).expand(points.size(0), points.size(1), index.size(1))
         return points.gather(2, index_expand)
+    if _is_f64(points):
+        return _group_points_forward(points, _i64c(index, "index").unsqueeze(-1)).squeeze(-1)
     points = _f32c(points, "points")
     index = _i64c(index, "index")
     B, C, N = points.shape
