@@ -36,6 +36,7 @@
 namespace s4g {
 
 constexpr int FPS_THREADS = 1024;  // streaming fallback
+constexpr int FPS_TIE_PAR = 5;     // tying groups per wave from which the pruned kernel resolves ties lane-parallel
 constexpr int FPS_MAX_WAVES = 16;
 constexpr uint32_t FPS_JMASK = 0x7FFFFFu;  // 23 bits of point index
 
@@ -1049,9 +1050,47 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
     } else {
       uint32_t best_key = 0xFFFFFFFFu;
       int nbest = 0;                               // groups / lanes that hold the maximum
+      // Tie-heavy clouds (coordinates on a lattice: many groups of a wave hold the SAME maximum): the
+      // group-by-group walk below costs ~80 instructions per tying group -- 42 ms instead of 4 for a batch
+      // of lattice scenes of 25 600 points (round 4's `mixed_batch` leg found it).  From FPS_TIE_PAR tying
+      // groups on, every lane looks through its OWN slots instead: 26 ms (ties also rule out a second
+      // pick per exchange, which alone is 2.8 x); the tie-free path is unchanged (4.10 -> 4.14 ms).
+      bool tie_par = false;
+      if constexpr (GPL == 1) {
+        tie_par = __popcll(__ballot(gbits[0] == wmax)) > FPS_TIE_PAR;
+        if (tie_par) {
+          // (through LDS: this thread's min-distances into its own column, then a ROLLED loop over them --
+          // unrolled over the registers the block costs the common path 13 spilled registers and 4 %)
+          float* __restrict__ mdl = reinterpret_cast<float*>(orig + THREADS * PPT) + t;
+#pragma unroll
+          for (int pp = 0; pp < PPT; ++pp) mdl[pp * THREADS] = md[pp];
+          uint32_t kl = 0xFFFFFFFFu;
+          int pl = 0;
+#pragma unroll 1
+          for (int pp = 0; pp < PPT; ++pp) {
+            const int s = 64 * (WAVES * pp + wave) + lane;
+            const uint32_t kk = tie_key(orig[s < N ? s : 0]);
+            const bool hit = s < N && __float_as_uint(mdl[pp * THREADS]) == wmax;
+            if (hit && kk < kl) {
+              kl = kk;
+              pl = pp;
+            }
+          }
+          const uint32_t kmin = wave_min_u32(kl);
+          const int wl = __ffsll((unsigned long long)__ballot(kl == kmin)) - 1;
+          const int pw = __builtin_amdgcn_readlane(pl, wl);
+          float vx, vy, vz, vm;
+          fps_pick_slot<PPT, 0, PPT>(x, y, z, md, pw, vx, vy, vz, vm);
+          sx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vx), wl));
+          sy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vy), wl));
+          sz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vz), wl));
+          best_key = kmin;
+          nbest = 2;                               // several holders of the maximum: no second pick is provable
+        }
+      }
 #pragma unroll
       for (int r = 0; r < GPL; ++r) {
-        uint64_t gmask = __ballot(gbits[r] == wmax);
+        uint64_t gmask = tie_par ? 0ull : __ballot(gbits[r] == wmax);
         if constexpr (SPEC) nbest += __popcll(gmask);
         while (gmask) {                          // one group unless maxima tie across groups
           const int gl = __ffsll((unsigned long long)gmask) - 1;
@@ -1539,7 +1578,7 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
   }
 #define S4G_FPS_PRUNED(T, P)                                                                       \
   if (N <= (int64_t)T * P) {                                                                       \
-    const size_t lds = sizeof(uint16_t) * T * P;                                                   \
+    const size_t lds = (sizeof(uint16_t) + sizeof(float)) * T * P;   /* original indices + the tie path's min-distance columns */ \
     S4G_FPS_PRUNED_LAUNCH(T, P, 4)                                                                 \
     S4G_LAUNCH_CHECK();                                                                            \
     return S4G_OK;                                                                                 \
