@@ -1053,21 +1053,26 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
       // Tie-heavy clouds (coordinates on a lattice: many groups of a wave hold the SAME maximum): the
       // group-by-group walk below costs ~80 instructions per tying group -- 42 ms instead of 4 for a batch
       // of lattice scenes of 25 600 points (round 4's `mixed_batch` leg found it).  From FPS_TIE_PAR tying
-      // groups on, every lane looks through its OWN slots instead: 26 ms (ties also rule out a second
+      // groups on, every lane looks through its OWN tying slots instead: 21 ms (ties also rule out a second
       // pick per exchange, which alone is 2.8 x); the tie-free path is unchanged (4.10 -> 4.14 ms).
       bool tie_par = false;
       if constexpr (GPL == 1) {
-        tie_par = __popcll(__ballot(gbits[0] == wmax)) > FPS_TIE_PAR;
+        const uint64_t gtie = __ballot(gbits[0] == wmax);     // bit = slot (group) of this wave that holds the maximum
+        tie_par = __popcll(gtie) > FPS_TIE_PAR;
         if (tie_par) {
           // (through LDS: this thread's min-distances into its own column, then a ROLLED loop over them --
           // unrolled over the registers the block costs the common path 13 spilled registers and 4 %)
           float* __restrict__ mdl = reinterpret_cast<float*>(orig + THREADS * PPT) + t;
 #pragma unroll
-          for (int pp = 0; pp < PPT; ++pp) mdl[pp * THREADS] = md[pp];
+          for (int pp = 0; pp < PPT; ++pp)
+            if ((gtie >> pp) & 1ull) mdl[pp * THREADS] = md[pp];      // (wave-uniform: only the tying slots)
           uint32_t kl = 0xFFFFFFFFu;
           int pl = 0;
+          uint64_t gleft = gtie;
 #pragma unroll 1
-          for (int pp = 0; pp < PPT; ++pp) {
+          while (gleft) {
+            const int pp = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)gleft) - 1);
+            gleft &= gleft - 1;
             const int s = 64 * (WAVES * pp + wave) + lane;
             const uint32_t kk = tie_key(orig[s < N ? s : 0]);
             const bool hit = s < N && __float_as_uint(mdl[pp * THREADS]) == wmax;
