@@ -656,6 +656,21 @@ def test_fps_tie_heavy_large(F, oracle, dev):
     assert np.array_equal(got, oracle.fps(pts, 700))
 
 
+def test_fps_lattice_scene_all_picks(F, oracle, dev):
+    """The `lattice` table-top scene (coordinates snapped to 2^-8 m: bench.py's `mixed_batch` leg), all 5 119
+    picks through the pruned kernel: most waves hold many groups with the SAME maximum, i.e. the lane-parallel
+    tie resolution (FPS_TIE_PAR) decides nearly every pick; beside a tie-free scene, and in the fmad contract."""
+    pts = np.concatenate([synth.make_batch([3], 25600, variant="lattice"), synth.make_batch([4], 25600)])
+    got = F.farthest_point_sample(_t(pts, dev), 5120).cpu().numpy()
+    assert np.array_equal(got, oracle.fps(pts, 5120))
+    try:
+        F.set_distance_mode("fmad")
+        got = F.farthest_point_sample(_t(pts[:1], dev), 2000).cpu().numpy()
+    finally:
+        F.set_distance_mode("strict")
+    assert np.array_equal(got, oracle.fps(pts[:1], 2000, fmad=1))
+
+
 def test_runs_on_current_stream(F, oracle, dev):
     pts = synth.make_batch([1], 2048)
     s = torch.cuda.Stream(device=dev)

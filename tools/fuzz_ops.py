@@ -31,7 +31,7 @@ def main():
              16384, 19999, 25599, 25600, 25601, 30011, 40000, 51200, 51201, 60000, 65536, 70001]
     while time.time() - t0 < a.seconds:
         case += 1
-        variant = ["tabletop-v1", "dup-heavy", "uniform-box"][int(rng.integers(3))]
+        variant = ["tabletop-v1", "dup-heavy", "uniform-box", "lattice"][int(rng.integers(4))]
         N = int(rng.choice(sizes))
         B = int(rng.integers(1, 3))
         M = int(rng.integers(1, min(N, 3000) + 1))
