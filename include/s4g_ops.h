@@ -369,6 +369,15 @@ typedef struct s4g_gemm_desc {
    * layer's per-tile power-of-two scales see other rows, so outputs agree to fp32 round-off, not bitwise. */
   const int32_t *seg4;
   const int32_t *seg_rows;
+  /* ABI >= 8, optional: a SECOND output tensor for a plain single layer (loader PLAIN, epilogue STORE, groups 1,
+   * no fused layers; f16x2 / bf16 precision): two layers that read the same input run as one launch with W, bias
+   * and scales concatenated along Cout -- output channels [0, split_n) go to `out` (row stride ldc, c_coff 0),
+   * channels [split_n, Cout) to `out2` (row stride ldc2, column n - split_n) and their per-scene maxima to
+   * out_amax2.  split_n and Cout multiples of 256.  (The network's first SA layer on features and the first FP
+   * layer on the skip features read the same level: modules.py:242 / :505.) */
+  float *out2;
+  int32_t ldc2, split_n;
+  float *out_amax2;
 } s4g_gemm_desc_t;
 
 int s4g_mlp_gemm_f32(const s4g_gemm_desc_t *desc, s4g_stream_t stream);

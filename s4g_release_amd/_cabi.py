@@ -46,6 +46,7 @@ class GemmDesc(ctypes.Structure):
         ("W2_f16x2_frag", _vp), ("w2_inv_scale", _vp), ("bias2", _vp), ("Cout2", _i32), ("relu2", _i32),
         ("W3_f16x2_frag", _vp), ("w3_inv_scale", _vp), ("bias3", _vp), ("Cout3", _i32), ("relu3", _i32),
         ("loader_bias", _vp), ("rows_per_scene", _i32), ("rel_xyz4", _vp), ("seg4", _vp), ("seg_rows", _vp),
+        ("out2", _vp), ("ldc2", _i32), ("split_n", _i32), ("out_amax2", _vp),
     ]
 
 

@@ -91,6 +91,12 @@ struct GemmParams {
   // seg_rows[scene] = rows the scene occupies behind its base scene * rps
   const int* seg4;
   const int* seg_rows;
+  // optional second output tensor of a plain single layer (two layers that read the SAME input as one launch,
+  // W / bias concatenated): output channels >= split_n (a multiple of 256) go to out2 (row stride ldc2, column
+  // n - split_n) and publish their maxima to out_amax2
+  float* out2;
+  int ldc2, split_n;
+  uint32_t* out_amax2;
   // INTERP: sparse (B*N2, C2), dense (B*N1, C1), nidx/nw (B*N1, 3)
   const int* nidx;
   const float* nw;
@@ -826,6 +832,14 @@ __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP || LOADER =
   const int n0 = nt * BN;
   const float* __restrict__ bg = p.bias + (size_t)g * p.b_gstride;
   const uint16_t* __restrict__ Wg = (PL == 2 ? p.Wh2 : p.W3) + (size_t)g * p.Cout * p.Kpad16;
+  // two output tensors (split_n is a multiple of the tile width): this tile's columns belong to one of them
+  GemmParams po = p;
+  if (EPI == EPI_STORE && p.split_n > 0 && n0 >= p.split_n) {
+    po.out = p.out2;
+    po.ldc = p.ldc2;
+    po.c_coff = -p.split_n;
+    po.out_amax = p.out_amax2;
+  }
 
   // activation scale: the power of two that puts the tensor maximum in [2^14, 2^15)
   float amax = PL == 2 ? p.a_amax_floor : 1.f;
@@ -977,11 +991,11 @@ __global__ __launch_bounds__(256, (NCB == 4 || LOADER == LOAD_INTERP || LOADER =
     const float hi = mx + bias, lo = mn + bias;
     tmax = fmaxf(tmax, p.relu ? hi : fmaxf(fabsf(hi), fabsf(lo)));
   }
-  if (PL == 2 && p.out_amax) {
+  if (PL == 2 && po.out_amax) {
     const uint32_t wm = wave_max_u32(__float_as_uint(fmaxf(tmax, 0.f)));
-    if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave, p0, p_hi, p.rps);
+    if (lane == 0) amax_publish(po.out_amax, wm, blockIdx.x * 4 + wave, p0, p_hi, p.rps);
   }
-  gemm_epilogue<EPI, NCB>(p, acc, bg, g, p0, n0, wave, wr, wc, li, lh, smemf);
+  gemm_epilogue<EPI, NCB>(po, acc, bg, g, p0, n0, wave, wr, wc, li, lh, smemf);
 }
 
 template <int LOADER, int EPI, int NCB, int PL>
@@ -1335,6 +1349,11 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
       // barriers per K-wide chunk instead of two per 32 columns): the activated values above ARE the output --
       // this workgroup's positions x this group's K channels (the caller maps 256-channel strips of a wider
       // layer to groups that share A).  Operands are swapped: a lane holds 4 consecutive channels of a position.
+      // (two output tensors: this group's 256 channels belong to one of them)
+      const bool second = p.split_n > 0 && g * p.c_gcol >= p.split_n;
+      float* __restrict__ obase = second ? p.out2 - p.split_n : p.out + p.c_coff;
+      const int old = second ? p.ldc2 : p.ldc;
+      uint32_t* __restrict__ oamax = second ? p.out_amax2 : p.out_amax;
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -1344,13 +1363,13 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
           for (int pb = 0; pb < NRB; ++pb) {
             const int row = p0 + wr * WROWS + pb * 32 + li;
             if (row < p.P)
-              *reinterpret_cast<float4*>(p.out + (size_t)row * p.ldc + p.c_coff + g * p.c_gcol + nn) =
+              *reinterpret_cast<float4*>(obase + (size_t)row * old + g * p.c_gcol + nn) =
                   make_float4(acc[nb][pb][4 * j], acc[nb][pb][4 * j + 1], acc[nb][pb][4 * j + 2], acc[nb][pb][4 * j + 3]);
           }
         }
-      if (PL == 2 && p.out_amax) {
+      if (PL == 2 && oamax) {
         const uint32_t wm = wave_max_u32(__float_as_uint(tmax));
-        if (lane == 0) amax_publish(p.out_amax, wm, (blockIdx.x * 4 + wave) * 5 + g, p0, p_hi, p.rps);
+        if (lane == 0) amax_publish(oamax, wm, (blockIdx.x * 4 + wave) * 5 + g, p0, p_hi, p.rps);
       }
       return;
     }
@@ -1616,7 +1635,7 @@ static int launch_gemm_f16x2(const GemmParams& p, int groups, hipStream_t st) {
     // resident-A kernel: short contractions whose A panel fits LDS twice per CU
     const bool vec_ok = ((p.ldc | p.c_coff | p.c_gcol) & 3) == 0 &&
                         ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
-    if (PL == 2 && !no_resident && !force && p.Wfrag && (EPI != EPI_STORE || vec_ok) &&
+    if (PL == 2 && !no_resident && !force && !p.out2 && p.Wfrag && (EPI != EPI_STORE || vec_ok) &&
         (EPI != EPI_MAX || p.K == 64) && (any_resident || p.Cout >= 1024)) {
       if (p.Kpad16 == 256 && p.Cout % 256 == 0)
         return launch_gemm_f16x2_resident<LOADER, EPI, 1, 256>(p, groups, st);
@@ -1743,6 +1762,10 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   p.rel4 = (const float4*)d->rel_xyz4;
   p.seg4 = d->seg4;
   p.seg_rows = d->seg_rows;
+  p.out2 = d->out2;
+  p.ldc2 = d->ldc2;
+  p.split_n = d->out2 ? d->split_n : 0;
+  p.out_amax2 = (uint32_t*)d->out_amax2;
   p.nidx = d->nidx; p.nw = d->nw; p.sparse = d->sparse; p.dense = d->dense;
   p.C2 = d->C2; p.C1 = d->C1; p.N2 = d->N2; p.N1 = d->N1;
   p.out = d->out; p.ldc = d->ldc; p.c_coff = d->c_coff; p.c_gcol = d->c_gcol;
@@ -1811,6 +1834,13 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
     return S4G_EINVAL;
   }
   if (d->loader != S4G_GEMM_LOAD_GATHER_MLP1 && (d->seg4 || d->seg_rows)) return S4G_EINVAL;
+  if (d->out2) {   // second output tensor: plain single layers of the f16x2 / bf16 kernels only
+    const bool bf1_ = d->precision == S4G_GEMM_BF16;
+    if (!(h2 || bf1_) || d->loader != S4G_GEMM_LOAD_PLAIN || d->epilogue != S4G_GEMM_EPI_STORE || d->W2_f16x2_frag ||
+        d->groups != 1 || d->split_n <= 0 || (d->split_n & 255) || d->split_n >= d->Cout || (d->Cout & 255) ||
+        (d->ldc2 & 3) || ((uintptr_t)d->out2 & 15) || d->c_coff != 0 || (d->ldc & 3) || ((uintptr_t)d->out & 15))
+      return S4G_EINVAL;
+  }
   if (d->epilogue == S4G_GEMM_EPI_MAX) {
     if (!(d->K == 16 || d->K == 32 || d->K == 64) || d->groups != 1 || !d->out) return S4G_EINVAL;
   } else if (d->epilogue == S4G_GEMM_EPI_STORE) {

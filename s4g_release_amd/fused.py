@@ -171,6 +171,9 @@ class FusedPointNet2:
         # first hit, the max over the neighbours cannot see them): S4G_SA_UNIQUE=0 contracts all K rows
         self.sa_unique = os.environ.get("S4G_SA_UNIQUE", "1") != "0"
         self.heads_pre = os.environ.get("S4G_HEADS_PRE", "1") != "0"
+        # layers that read the SAME tensor as one launch with two outputs (an SA level's per-point layer and
+        # the mirror FP level's skip-feature layer both read that level's features): S4G_MERGE_SHARED=0 splits
+        self.merge_shared = os.environ.get("S4G_MERGE_SHARED", "1") != "0"
         self.fp_chain_next = os.environ.get("S4G_FP_CHAIN_NEXT", "1") != "0"
         self.fps_prefix = os.environ.get("S4G_FPS_PREFIX", "1") != "0"
         p = next(net.parameters())
@@ -303,6 +306,27 @@ class FusedPointNet2:
             lb = _Layer(_pad_k(w[:, c2:].contiguous()), zero, c1) if c1 > 0 else None
             sp = fp["split"] = (la, lb, (c2, c1))
         return sp
+
+    def _shared_input_layer(self, li, c1):
+        """SA level li's per-point layer (`sa{li}.0f`) and FP level n_sa-1-li's skip-feature layer
+        (`fp{fi}.0d`) read the same (B N_li, c1) tensor: (merged layer with W rows concatenated, the FP
+        half) or None.  Per-channel weight scales: every output channel is bit-identical to the two
+        separate launches."""
+        sa, fi = self.sa[li], len(self.sa) - 1 - li
+        if (not self.merge_shared or self.precision not in ("f16x2", "bf16") or sa["pre"] is None or
+                not 0 <= fi < len(self.fp) or not self.fp_linear_first):
+            return None
+        fp, la = self.fp[fi], sa["pre"]["la"]
+        l0 = fp["layers"][0]
+        c2 = l0.cin - c1
+        if c2 <= 0 or la.cin != c1 or la.cout % 256 or l0.cout % 256 or l0.cout > 1024 or len(fp["layers"]) < 2:
+            return None
+        _, lb, _ = self._fp_split(fp, l0, c2, c1)
+        m = sa.get("merged")
+        if m is None or m[1] is not lb:
+            w = torch.cat([la.W[:, :c1], lb.W[:, :c1]], dim=0).contiguous()
+            m = sa["merged"] = (_Layer(_pad_k(w), w.new_zeros(w.shape[0]), c1), lb)
+        return m
 
     def _heads_take_tail(self, fi, fl, pending):
         """Last FP level, heads as one launch, the level = (linear-first layer, 256 -> 256, 256 -> 256)
@@ -588,6 +612,7 @@ class FusedPointNet2:
         amax = torch.zeros((n_launch, B, 64), dtype=torch.float32, device=dev)
         rows = iter(amax.unbind(0))
         level_feat = [(None, None)]                  # (tensor, amax row)
+        shared = {}       # FP level -> (skip-feature product, amax row) made by the SA launch that read the tensor
         feat = feat_amax = None
         cur = torch.cuda.current_stream()
         for li, sa in enumerate(self.sa):
@@ -609,9 +634,20 @@ class FusedPointNet2:
                 # F = W_feat . features, one row per point of the level
                 fpre = torch.empty((B * level_n[li], layers[0].cout), dtype=torch.float32, device=dev)
                 fpre_amax = next(rows)
-                self._gemm("sa%d.0f" % li, pre["la"], B * level_n[li], LOAD_PLAIN, EPI_STORE, relu=False,
-                           out=fpre, ldc=layers[0].cout, A=feat, lda=feat.shape[1], a_amax=feat_amax,
-                           out_amax=fpre_amax)
+                mg = self._shared_input_layer(li, feat.shape[1])
+                if mg is not None:
+                    fi = len(self.sa) - 1 - li
+                    y = torch.empty((B * level_n[li], mg[1].cout), dtype=torch.float32, device=dev)
+                    y_amax = next(rows)
+                    self._gemm("sa%d.0f|fp%d.0d" % (li, fi), mg[0], B * level_n[li], LOAD_PLAIN, EPI_STORE,
+                               relu=False, out=fpre, ldc=layers[0].cout, A=feat, lda=feat.shape[1],
+                               a_amax=feat_amax, out_amax=fpre_amax, out2=y, ldc2=mg[1].cout,
+                               split_n=layers[0].cout, out_amax2=y_amax)
+                    shared[fi] = (y, y_amax)
+                else:
+                    self._gemm("sa%d.0f" % li, pre["la"], B * level_n[li], LOAD_PLAIN, EPI_STORE, relu=False,
+                               out=fpre, ldc=layers[0].cout, A=feat, lda=feat.shape[1], a_amax=feat_amax,
+                               out_amax=fpre_amax)
             for l, layer in enumerate(layers):
                 if l == 0 and (sa["mlp1"] is not None or pre is not None):
                     continue                      # folded into layer 1's loader
@@ -742,7 +778,9 @@ class FusedPointNet2:
                                    out=s_out, ldc=layer.cout, A=sparse_feat, lda=c2, a_amax=sparse_amax,
                                    out_amax=s_amax)
                     y = y_amax = None
-                    if lb is not None:
+                    if lb is not None and fi in shared:
+                        y, y_amax = shared.pop(fi)   # made by sa{li}.0f's launch (same input tensor)
+                    elif lb is not None:
                         y = torch.empty((P, layer.cout), dtype=torch.float32, device=dev)
                         y_amax = next(rows) if in_loader else None
                         self._gemm("fp%d.0d" % fi, lb, P, LOAD_PLAIN, EPI_STORE, relu=False, out=y,

@@ -123,6 +123,65 @@ def test_gemm_plain_store(dev, P, Cin, Cout, relu, prec, gemm_variant):
     assert (out.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("P,Cin,split,Cout", [(1000, 256, 256, 768), (4096, 512, 512, 1536), (333, 256, 512, 768)])
+@pytest.mark.parametrize("prec", [2, 3])
+def test_gemm_two_output_tensors(dev, P, Cin, split, Cout, prec, gemm_variant):
+    """Two layers that read the same input as ONE launch (descriptor fields out2 / ldc2 / split_n / out_amax2):
+    every output channel bit-identical to the two separate launches of the same kernel, and the per-scene
+    maxima of each tensor in its own row."""
+    from s4g_release_amd.fused import fragment_order, split_bf16x3
+    if gemm_variant == "resident":
+        pytest.skip("the resident-A measurement kernel has one output tensor")
+    g = torch.Generator(device="cpu").manual_seed(P + Cout)
+    A = torch.randn(P, Cin, generator=g).to(dev)
+    W = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).to(dev)
+    W[split:] *= 7.0                      # the halves have different per-channel weight scales
+    zero = torch.zeros(Cout, device=dev)
+
+    def launch(w, outs, amaxs, split_n=0):
+        k16, w3 = _w3(w)
+        h2 = _h2(w, A)
+        h2["out_amax"] = amaxs[0]
+        kw = dict(loader=0, epilogue=0, groups=1, relu=0, P=P, Cin=Cin, Kpad=Cin, Cout=w.shape[0], W=_padk(w),
+                  bias=zero, A=A, lda=Cin, out=outs[0], ldc=outs[0].shape[1], precision=prec, Kpad16=k16,
+                  W_bf16x3=w3, rows_per_scene=0, **h2)
+        if prec == 2:
+            kw["W_f16x2_frag"] = fragment_order(split_bf16x3(w)[:1].unsqueeze(1))[:, :, :, 0].contiguous()
+        if split_n:
+            kw.update(out2=outs[1], ldc2=outs[1].shape[1], split_n=split_n, out_amax2=amaxs[1])
+        _run(kw, dev)
+
+    both = [torch.full((P, split), float("nan"), device=dev), torch.full((P, Cout - split), float("nan"), device=dev)]
+    am_both = [torch.zeros(64, device=dev), torch.zeros(64, device=dev)]
+    launch(W, both, am_both, split_n=split)
+    for half, (lo, hi) in enumerate(((0, split), (split, Cout))):
+        alone, am = torch.full((P, hi - lo), float("nan"), device=dev), torch.zeros(64, device=dev)
+        launch(W[lo:hi].contiguous(), [alone], [am])
+        assert torch.equal(both[half], alone), half
+        ref = A.double() @ W[lo:hi].double().t()
+        tol = (2e-2 if prec == 2 else 1e-5) * max(1.0, ref.abs().max().item())
+        assert (both[half].double() - ref).abs().max().item() < tol
+        if prec == 3:
+            assert am_both[half].max().item() >= both[half].abs().max().item() > 0
+            assert am_both[half].max().item() == am.max().item()
+
+
+def test_gemm_two_output_tensors_rejects_other_shapes(dev):
+    from s4g_release_amd import _cabi
+    A = torch.randn(256, 256, device=dev)
+    W = torch.randn(768, 256, device=dev) / 16
+    k16, w3 = _w3(W)
+    out, out2 = torch.empty(256, 256, device=dev), torch.empty(256, 512, device=dev)
+    base = dict(loader=0, epilogue=0, groups=1, relu=0, P=256, Cin=256, Kpad=256, Cout=768, W=W,
+                bias=torch.zeros(768, device=dev), A=A, lda=256, out=out, ldc=256, precision=3, Kpad16=k16,
+                W_bf16x3=w3, out2=out2, ldc2=512, out_amax2=torch.zeros(64, device=dev), **_h2(W, A))
+    for bad in (dict(split_n=0), dict(split_n=128), dict(split_n=768), dict(precision=0), dict(precision=1),
+                dict(split_n=256, epilogue=1, K=64), dict(split_n=256, c_coff=4)):
+        with pytest.raises(RuntimeError):
+            _run(dict(base, **bad), dev)
+    _run(dict(base, split_n=256), dev)
+
+
 @pytest.mark.parametrize("Cin,Cout", [(64, 48), (64, 128), (128, 256)])
 @pytest.mark.parametrize("prec", PRECISIONS)
 def test_gemm_grouped_column_slices(dev, prec, Cin, Cout, gemm_variant):
@@ -907,3 +966,33 @@ def test_fused_layer_pairs_match_layer_by_layer(dev, monkeypatch):
     for k in a:
         scale = max(1.0, b[k].abs().max().item())
         assert (a[k] - b[k]).abs().max().item() < 2e-5 * scale, k
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "bf16"])
+def test_shared_input_layers_as_one_launch_match_separate_launches(dev, monkeypatch, precision):
+    """`sa{l}.0f` and `fp{f}.0d` read the same level's features: one launch with two output tensors
+    (S4G_MERGE_SHARED=0 keeps two launches).  Per-channel weight scales: the same values either way, up to the
+    accumulation order of the kernel a shape dispatches to."""
+    from s4g_release_amd import functions as F
+    from s4g_release_amd import synth
+    from s4g_release_amd.fused import FusedPointNet2
+    from s4g_release_amd.model import S4GConfig, build_pointnet2_cls, randomize_bn_
+    torch.manual_seed(5)
+    net = randomize_bn_(build_pointnet2_cls(S4GConfig()), 5).to(dev).eval()
+    batch = {"scene_points": torch.from_numpy(synth.make_batch([3, 4], 25600)).to(dev)}
+
+    def run():
+        F.OpTimer.reset(enabled=True)
+        out = FusedPointNet2(net, precision=precision)(batch)
+        torch.cuda.synchronize()
+        F.OpTimer.enabled = False
+        return out, sorted(F.OpTimer.summary())
+
+    merged, names = run()
+    assert any("sa1.0f|fp1.0d" in n for n in names) and any("sa2.0f|fp0.0d" in n for n in names)
+    assert not any("[fp1.0d " in n or "[fp0.0d " in n for n in names)
+    monkeypatch.setenv("S4G_MERGE_SHARED", "0")
+    apart, names = run()
+    assert any("[fp1.0d " in n for n in names) and any("[sa1.0f " in n for n in names)
+    for k in merged:
+        assert (merged[k] - apart[k]).abs().max().item() < (2e-2 if precision == "bf16" else 2e-6), k
