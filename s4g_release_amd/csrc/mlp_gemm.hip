@@ -1063,6 +1063,10 @@ constexpr int GF_RING_F16X2 = 2;
 #ifndef S4G_CHAIN_BF16_NRB
 #define S4G_CHAIN_BF16_NRB 4
 #endif
+// (The f16x2 form stays at two: four blocks there mean a 133 KB panel and ONE workgroup per CU at 128- and 256-wide
+// layers, and losing the second workgroup's phase overlap costs more than the halved W stream returns -- measured in
+// round 4, one box, in step: sa0 chain 1.15 -> 1.64 ms, sa1 chain 1.07 -> 1.20 ms, the chain-form single layers
+// 0.57 -> 0.67 ms, 1 988 -> 1 863 scenes/s.)
 
 // PL = planes per operand: 2 = the f16x2 split above (three fp16 products per step, power-of-two
 // scales), 1 = ONE bf16 plane and one product (S4G_GEMM_BF16, the reduced-precision roofline
