@@ -130,7 +130,11 @@ class GemmCapture:
     def __enter__(self):
         def spy(name, layer, P, loader, epi, **kw):
             self._orig(name, layer, P, loader, epi, **kw)
-            if kw.get("out") is not None:
+            if kw.get("out2") is not None:
+                # two layers that read the same tensor as one launch ("a|b"): each half under its own name
+                first, second = name.split("|")
+                self.out[first], self.out[second] = kw["out"].clone(), kw["out2"].clone()
+            elif kw.get("out") is not None:
                 self.out[name + ("+L2" if kw.get("layer2") is not None else "")] = kw["out"].clone()
         self.model._gemm = spy
         return self
