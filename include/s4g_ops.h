@@ -45,7 +45,8 @@ extern "C" {
  * 6: pre_* members of s4g_heads_desc_t (the last FP level's tail in front of the heads).
  * 7: s4g_fps_gather_ex_i32, s4g_fps_prefix_check_f32, s4g_fps_prepass_f32 (no layout change).
  * 8: s4g_group_rel_xyz_unique_i32 and the seg4 / seg_rows fields of s4g_gemm_desc_t (the first SA level
- *    contracts a centroid's distinct rows only). */
+ *    contracts a centroid's distinct rows only); out2 / ldc2 / split_n / out_amax2 (two layers that read the
+ *    same tensor as one launch); the operators in double (*_f64); s4g_build_variants. */
 #define S4G_ABI_VERSION 8
 
 /* ---------------------------------------------------------------------------
@@ -76,6 +77,7 @@ extern "C" {
  *   S4G_SA_LINEAR_FIRST=0, S4G_FP_LINEAR_FIRST=0   no linear-layer-before-grouping / -interpolation
  *   S4G_FP_LOADER_ADD=auto|none|levels, S4G_FP_CHAIN_NEXT=0   where the FP sums are formed
  *   S4G_GEMM_FUSE2=0, S4G_GEMM_FUSE3=0, S4G_GEMM_FUSE512=0    layer chains as separate launches
+ *   S4G_MERGE_SHARED=0             sa{l}.0f and fp{f}.0d (same input tensor) as two launches instead of one
  *   S4G_HEADS_FUSED=0, S4G_HEADS_PRE=0   heads layer by layer / FP tail outside the heads launch
  *   S4G_FPS_PREFIX=0               always sample SA levels 2 and 3 (no prefix proof)
  *   S4G_NN_MODE=scan               3-NN: never the cell-grid search
