@@ -406,7 +406,9 @@ def main():
 
     N, M, K = args.points, cfg.num_centroids[0], cfg.num_neighbours[0]
     roofline = latency = io = configs4 = modules_path = precision_legs = mixed_batch = None
-    if not args.no_extras:
+    # (the single-GPU probes below run at N = 1 only: at N > 1 the other ranks have left, rank 0 prints its line
+    #  and tears the communicator down without making the job wait for figures the N = 1 line already carries)
+    if not args.no_extras and world == 1:
         # ---- one batch alone / one scene: the figures the pipeline hides
         def timed_forward(data, reps):
             ts = []
