@@ -420,6 +420,15 @@ def main():
                     torch.cuda.synchronize()
                     ts.append(1e3 * (time.perf_counter() - t1))
             return percentile(ts, 0.5)
+        def timed_forward_with(fn, data, reps):
+            ts = []
+            for _ in range(2 + reps):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                fn(data)
+                torch.cuda.synchronize()
+                ts.append(1e3 * (time.perf_counter() - t1))
+            return percentile(ts[2:], 0.5)
         one = {"scene_points": pts[:1].contiguous()}
         latency = {"latency_ms_one_batch": round(timed_forward(batch, 5), 3), "batch": B,
                    "latency_ms_b1": round(timed_forward(one, 5), 3)}
@@ -431,6 +440,13 @@ def main():
             torch.cuda.synchronize()
             latency["scenes_per_sec_b1"] = round(30 / (time.perf_counter() - t1), 2)
         latency["scenes_per_sec_one_batch_at_a_time"] = round(1e3 * B / latency["latency_ms_one_batch"], 2)
+        if impl == "fused":
+            # the same two figures with the pass recorded as ONE HIP graph (FusedPointNet2.graph: the ~45 launches of
+            # a pass replayed by one host call; outputs bit-identical, tests/test_fused_gpu.py)
+            g1, g16 = runner.graph(one), runner.graph(batch)
+            latency["latency_ms_b1_graph"] = round(timed_forward_with(g1, one, 10), 3)
+            latency["latency_ms_one_batch_graph"] = round(timed_forward_with(g16, batch, 5), 3)
+            del g1, g16
 
         # ---- host <-> device transfers of one step, apart from `value`
         with torch.no_grad():

@@ -996,3 +996,25 @@ def test_shared_input_layers_as_one_launch_match_separate_launches(dev, monkeypa
     assert any("[fp1.0d " in n for n in names) and any("[sa1.0f " in n for n in names)
     for k in merged:
         assert (merged[k] - apart[k]).abs().max().item() < (2e-2 if precision == "bf16" else 2e-6), k
+
+
+def test_forward_recorded_as_a_hip_graph_replays_bit_identically(dev):
+    """`FusedPointNet2.graph`: one pass (geometry streams, contraction stream, ~45 launches) captured as a HIP graph;
+    replays on other clouds of the same shape give the eager path's tensors bit for bit, a wrong shape is refused."""
+    from s4g_release_amd import synth
+    from s4g_release_amd.fused import FusedPointNet2
+    from s4g_release_amd.model import S4GConfig, build_pointnet2_cls, randomize_bn_
+    torch.manual_seed(8)
+    net = randomize_bn_(build_pointnet2_cls(S4GConfig()), 9).to(dev).eval()
+    run = FusedPointNet2(net)
+    a = torch.from_numpy(synth.make_batch([0, 1], 25600)).to(dev)
+    b = torch.from_numpy(synth.make_batch([7, 8], 25600, variant="dup-heavy")).to(dev)
+    g = run.graph({"scene_points": a})
+    for x in (a, b, a):
+        ref = {k: v.clone() for k, v in run({"scene_points": x}).items()}
+        got = g({"scene_points": x})
+        torch.cuda.synchronize()
+        for k in ref:
+            assert torch.equal(ref[k], got[k]), k
+    with pytest.raises(RuntimeError):
+        g({"scene_points": a[:1]})
