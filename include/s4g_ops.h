@@ -459,10 +459,16 @@ int s4g_three_nn_weights_i32(const float *q_b3n1, const float *k_b3n2, int64_t B
  * the keys came from), the queries are binned into the same cells by the same launch
  * and walked in cell order (a wave's 64 queries share their key rows), each searches
  * 27 cells, unanswered queries fall back to the index-order scan in the same call --
- * identical results for every input.
+ * identical results for every input.  cell < 0 (round 4, what the fast path passes): the edge is chosen on
+ * the device, 1.75 x the mean distance from a key to its third-nearest other key over 64 sample keys (one
+ * wave each) -- the SA radius is the right edge on surface-like clouds only.
  * Workspace: s4g_three_nn_grid_workspace_bytes(B, N1, N2) (keys' grid + fail list +
  * the binned queries: ~128 bytes per query + 0.6 MB per scene); N2 <= 65536. */
 size_t s4g_three_nn_grid_workspace_bytes(int64_t B, int64_t N1, int64_t N2);
+/* Diagnostic (ABI >= 8): byte offset, inside that workspace, of the fail list's header of int32 words -- word 0:
+ * the queries the 27 cells could not answer in the last call (they took the all-keys scan), words 4 / 5: the
+ * device-chosen 1 / edge and acceptance bound (floats) when cell < 0. */
+size_t s4g_three_nn_grid_header_offset(int64_t B, int64_t N2);
 int s4g_three_nn_weights_grid_i32(const float *q_b3n1, const float *k_b3n2, int64_t B,
                                   int64_t N1, int64_t N2, float eps, float cell,
                                   int32_t *idx_bn3, float *w_bn3, void *ws,

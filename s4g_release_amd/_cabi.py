@@ -73,6 +73,7 @@ SIGNATURES = {
     "s4g_three_nn_weights_i32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _sz,
                                         _int, _vp]),
     "s4g_three_nn_grid_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "s4g_three_nn_grid_header_offset": (_sz, [_i64, _i64]),
     "s4g_three_nn_weights_grid_i32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _f32, _vp, _vp, _vp,
                                              _sz, _int, _vp]),
     "s4g_three_nn_grid_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _sz, _int, _vp]),

@@ -211,25 +211,44 @@ static int launch_three_nn_scan(const float* q, const float* k, int64_t B, int64
 // positive finite spacing comes out (all keys coincide, NaN / inf coordinates).
 constexpr int NN_SAMPLES = 64;
 
-__global__ __launch_bounds__(1024) void nn_auto_cell_kernel(const float* __restrict__ key, int B,
-                                                            int N2, float* __restrict__ out,
-                                                            float factor) {
-  __shared__ float d3s[NN_SAMPLES];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int s = wave; s < NN_SAMPLES; s += 16) {
+// hdr: the fail list's header -- word 0 the fail count, 4 / 5 the result (1 / cell, bound), 8 the arrival
+// counter, 16 .. 16 + NN_SAMPLES the samples' third-neighbour distances.  One wave per sample (round 4: the
+// first version ran all 64 scans in ONE workgroup, 0.09 ms of latency per call); the last workgroup to
+// arrive sums the samples in index order, so the edge is the same run to run.
+constexpr int NN_HDR_WORDS = 16 + NN_SAMPLES;
+
+__global__ __launch_bounds__(64) void nn_auto_cell_kernel(const float* __restrict__ key, int B, int N2,
+                                                          int* __restrict__ hdr, float factor) {
+  const int lane = threadIdx.x, s = blockIdx.x;
+  float* __restrict__ d3s = reinterpret_cast<float*>(hdr + 16);
+  float* __restrict__ out = reinterpret_cast<float*>(hdr + 4);
+  {
     const int b = s % B;
     const int j = (int)(((unsigned long long)s * 2654435761ull + 12345ull) % (unsigned)N2);
     const float* __restrict__ kx = key + (size_t)b * 3 * N2;
     const float x = kx[j], y = kx[N2 + j], z = kx[2 * N2 + j];
     float a0 = __builtin_inff(), a1 = a0, a2 = a0, a3 = a0;   // ascending
-    for (int i = lane; i < N2; i += 64) {
-      const float dx = kx[i] - x, dy = kx[N2 + i] - y, dz = kx[2 * N2 + i] - z;
-      const float d = dx * dx + dy * dy + dz * dz;
-      if (d < a3) {
-        a3 = d;
-        if (a3 < a2) { const float q = a2; a2 = a3; a3 = q; }
-        if (a2 < a1) { const float q = a1; a1 = a2; a2 = q; }
-        if (a1 < a0) { const float q = a0; a0 = a1; a1 = q; }
+    // eight keys per lane in flight: the scan is a chain of L2 round trips otherwise (80 of them for 5 120 keys)
+    for (int i0 = lane; i0 < N2; i0 += 64 * 8) {
+      float kxv[8], kyv[8], kzv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 64 * u;
+        const int ic = i < N2 ? i : j;          // past the end: the sample itself (distance 0 is discarded below)
+        kxv[u] = kx[ic];
+        kyv[u] = kx[N2 + ic];
+        kzv[u] = kx[2 * N2 + ic];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float dx = kxv[u] - x, dy = kyv[u] - y, dz = kzv[u] - z;
+        const float d = i0 + 64 * u < N2 ? dx * dx + dy * dy + dz * dz : __builtin_inff();
+        if (d < a3) {
+          a3 = d;
+          if (a3 < a2) { const float q = a2; a2 = a3; a3 = q; }
+          if (a2 < a1) { const float q = a1; a1 = a2; a2 = q; }
+          if (a1 < a0) { const float q = a0; a0 = a1; a1 = q; }
+        }
       }
     }
     float kth = 0.f;   // 4th smallest over the wave = third-nearest OTHER key (self is 0)
@@ -244,14 +263,21 @@ __global__ __launch_bounds__(1024) void nn_auto_cell_kernel(const float* __restr
         a3 = __builtin_inff();
       }
     }
-    if (lane == 0) d3s[s] = kth;
+    if (lane == 0) {
+      __hip_atomic_store(d3s + s, kth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence();
+    }
   }
-  __syncthreads();
-  if (t == 0) {
+  int last = 0;
+  if (lane == 0) last = atomicAdd(hdr + 8, 1) == NN_SAMPLES - 1;
+  last = __builtin_amdgcn_readfirstlane(last);
+  if (!last) return;
+  __threadfence();
+  if (lane == 0) {
     float sum = 0.f;
     int n = 0;
-    for (int s = 0; s < NN_SAMPLES; ++s) {
-      const float d = d3s[s];
+    for (int q = 0; q < NN_SAMPLES; ++q) {
+      const float d = __hip_atomic_load(d3s + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (d > 0.f && d < __builtin_inff()) {
         sum += sqrtf(d);
         ++n;
@@ -542,12 +568,16 @@ extern "C" int s4g_three_nn_weights_i32(const float* q_b3n1, const float* k_b3n2
 
 // workspace: [keys' grid][fail header (16 ints) + fail list][queries binned into the keys' grid]
 static size_t nn_fail_bytes(int64_t B, int64_t N1) {
-  return (sizeof(int) * ((size_t)B * N1 + 16) + 63) & ~(size_t)63;
+  return (sizeof(int) * ((size_t)B * N1 + s4g::NN_HDR_WORDS) + 63) & ~(size_t)63;
 }
 
 extern "C" size_t s4g_three_nn_grid_workspace_bytes(int64_t B, int64_t N1, int64_t N2) {
   return s4g::grid_ws_bytes(B, N2) + nn_fail_bytes(B, N1) + s4g::cell_ws_bytes(B, N1);
 }
+
+// Diagnostic: byte offset of the fail list's header inside that workspace (int32 words: 0 = queries the 27 cells
+// could not answer in the last call, 4 / 5 = the device-chosen 1 / edge and acceptance bound as floats).
+extern "C" size_t s4g_three_nn_grid_header_offset(int64_t B, int64_t N2) { return s4g::grid_ws_bytes(B, N2); }
 
 namespace s4g {
 
@@ -566,15 +596,15 @@ static int launch_three_nn_grid(const float* q, const float* k, int64_t B, int64
   if (ws_bytes < s4g_three_nn_grid_workspace_bytes(B, N1, N2)) return S4G_EWORKSPACE;
   const GridWs g = grid_ws_carve(ws, B, N2);
   int* fail_count = reinterpret_cast<int*>((char*)ws + grid_ws_bytes(B, N2));
-  int* fail_list = fail_count + 16;
+  int* fail_list = fail_count + NN_HDR_WORDS;
   const CellWs cw = cell_ws_carve((char*)fail_count + nn_fail_bytes(B, N1), B, N1);
-  hipError_t e = hipMemsetAsync(fail_count, 0, sizeof(int), st);
+  hipError_t e = hipMemsetAsync(fail_count, 0, sizeof(int) * 16, st);   // fail count + the edge search's arrival counter
   if (e != hipSuccess) return (int)e;
   float* cell_dev = nullptr;   // header words 4, 5 of the fail list
   if (auto_cell) {
     cell_dev = reinterpret_cast<float*>(fail_count + 4);
     static const float factor = [] { const char* e = getenv("S4G_NN_CELL_FACTOR"); return e ? (float)atof(e) : 1.75f; }();
-    hipLaunchKernelGGL(nn_auto_cell_kernel, dim3(1), dim3(1024), 0, st, k, (int)B, (int)N2, cell_dev, factor);
+    hipLaunchKernelGGL(nn_auto_cell_kernel, dim3(NN_SAMPLES), dim3(64), 0, st, k, (int)B, (int)N2, fail_count, factor);
     S4G_LAUNCH_CHECK();
     cell = 1.0f;
   }
@@ -610,7 +640,8 @@ extern "C" int s4g_three_nn_weights_grid_i32(const float* q_b3n1, const float* k
                                              float cell, int32_t* idx_bn3, float* w_bn3,
                                              void* ws, size_t ws_bytes, int flags,
                                              s4g_stream_t stream) {
-  if (!(cell > 0.f)) return S4G_EINVAL;   // no device-chosen edge through this entry
+  // cell < 0: the edge is chosen on the device from the keys' measured spacing (nn_auto_cell_kernel), as in
+  // s4g_three_nn_grid_f32; cell == 0 / NaN is refused
   return s4g::launch_three_nn_grid<true, int32_t>(q_b3n1, k_b3n2, B, N1, N2, eps, cell, idx_bn3,
                                                   w_bn3, ws, ws_bytes, flags, (hipStream_t)stream);
 }

@@ -475,6 +475,9 @@ def test_three_nn_operator_api_grid_routing(F, oracle, dev, monkeypatch, variant
     ("uniform-box", 25600, 5120, 0.02),     # sparse: most queries need the fallback scan
     ("tabletop-v1", 25600, 5120, 0.004),    # cell far too small: everything falls back
     ("tabletop-v1", 25600, 5120, 0.5),      # cell as big as the scene: all keys are candidates
+    ("tabletop-v1", 25600, 5120, -1.0),     # edge chosen on the device from the keys' spacing (the fast path's call)
+    ("uniform-box", 25600, 5120, -1.0),     # ... where the SA radius would send nearly every query to the scan
+    ("dup-heavy", 5120, 2048, -1.0),
 ])
 def test_three_nn_grid_matches_oracle(F, oracle, dev, variant, N1, N2, cell):
     pts = synth.make_batch([1, 8], N1, variant=variant)
@@ -485,6 +488,32 @@ def test_three_nn_grid_matches_oracle(F, oracle, dev, variant, N1, N2, cell):
     assert idx.dtype == torch.int32
     assert np.array_equal(idx.cpu().numpy().astype(np.int64), ridx)
     assert np.array_equal(w.cpu().numpy(), oracle.interp_weights(rd2))
+
+
+def test_three_nn_device_chosen_edge_keeps_the_fallback_list_short(F, oracle, dev):
+    """The measured edge (1.75 x the mean distance from a key to its third-nearest other key) answers all but a
+    handful of queries from the 27 cells on a surface-like AND on a uniformly filled cloud (with the SA radius as the
+    edge 98 % of a uniform box's queries took the all-keys scan: 4.8 ms instead of 0.1); the fail count is word 0 of
+    the workspace's fail-list header."""
+    from s4g_release_amd import _cabi
+    for variant in ("tabletop-v1", "uniform-box"):
+        pts = synth.make_batch([4], 25600, variant=variant)
+        keys = oracle.gather_points(pts, oracle.fps(pts, 5120))
+        q, k = _t(pts, dev), _t(keys, dev)
+        idx = torch.empty((1, 25600, 3), dtype=torch.int32, device=dev)
+        w = torch.empty((1, 25600, 3), dtype=torch.float32, device=dev)
+        nbytes = _cabi.lib().s4g_three_nn_grid_workspace_bytes(1, 25600, 5120)
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        rc = _cabi.lib().s4g_three_nn_weights_grid_i32(q.data_ptr(), k.data_ptr(), 1, 25600, 5120, 1e-10, -1.0,
+                                                       idx.data_ptr(), w.data_ptr(), ws.data_ptr(), nbytes, 0,
+                                                       torch.cuda.current_stream().cuda_stream)
+        _cabi.check(rc, "three_nn_weights_grid")
+        torch.cuda.synchronize()
+        grid_bytes = _cabi.lib().s4g_three_nn_grid_header_offset(1, 5120)
+        hdr = ws[grid_bytes:grid_bytes + 64].view(torch.int32).cpu()
+        ridx, _ = oracle.three_nn(pts, keys)
+        assert np.array_equal(idx.cpu().numpy().astype(np.int64), ridx)
+        assert 0 <= int(hdr[0]) < 256, (variant, int(hdr[0]))
 
 
 def test_three_nn_grid_out_of_range_scene(F, oracle, dev):
