@@ -460,7 +460,7 @@ int s4g_three_nn_weights_i32(const float *q_b3n1, const float *k_b3n2, int64_t B
  * and walked in cell order (a wave's 64 queries share their key rows), each searches
  * 27 cells, unanswered queries fall back to the index-order scan in the same call --
  * identical results for every input.  cell < 0 (round 4, what the fast path passes): the edge is chosen on
- * the device, 1.75 x the mean distance from a key to its third-nearest other key over 64 sample keys (one
+ * the device, 1.75 x the median distance from a key to its third-nearest other key over 64 sample keys (one
  * wave each) -- the SA radius is the right edge on surface-like clouds only.
  * Workspace: s4g_three_nn_grid_workspace_bytes(B, N1, N2) (keys' grid + fail list +
  * the binned queries: ~128 bytes per query + 0.6 MB per scene); N2 <= 65536. */
@@ -476,7 +476,7 @@ int s4g_three_nn_weights_grid_i32(const float *q_b3n1, const float *k_b3n2, int6
 
 /* s4g_three_nn_f32's outputs (int64 indices, squared distances) through the same grid:
  * for operator-API callers.  cell > 0: the caller names the cell edge; cell < 0: the call
- * derives one on the device (1.75 x the mean third-neighbour distance of 64 sample keys,
+ * derives one on the device (1.75 x the median third-neighbour distance of 64 sample keys,
  * no host read).  Same workspace; identical results for any cell. */
 int s4g_three_nn_grid_f32(const float *q_b3n1, const float *k_b3n2, int64_t B, int64_t N1,
                           int64_t N2, float cell, int64_t *idx_bn3, float *d2_bn3, void *ws,

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(FPS_SORT_THREADS) void fps_cell_sort_kernel(
   uint32_t* __restrict__ H = sort_lds;                  // [2^14] packed counters
   uint32_t* __restrict__ dep = H + FPS_SORT_WORDS;      // [3][256] an axis value's bits at their key positions
   uint16_t* __restrict__ hil = reinterpret_cast<uint16_t*>(dep + 3 * 256);   // [64 * 64] Hilbert index of an (a, b) cell
-  uint32_t* __restrict__ red = dep + 3 * 256 + 64 * 64 / 2;   // [6][NW] + [NW]
+  uint32_t* __restrict__ red = dep + 3 * 256 + 64 * 64 / 2;   // [6][NW] + [NW] + the re-boxed ranges [3][2]
   const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const float* __restrict__ p = xyz + (size_t)b * 3 * N;
   int* __restrict__ pm = perm + (size_t)b * N;
@@ -591,6 +591,95 @@ __global__ __launch_bounds__(FPS_SORT_THREADS) void fps_cell_sort_kernel(
     ext[a] = ordered_f32(h) - bl[a];
     if (!(ext[a] > 0.f) || !(ext[a] < 3.0e38f)) ext[a] = 0.f;   // degenerate / non-finite axis: never split
   }
+  // Robust box (round 4).  A few far outliers -- 50 background points 50 m behind a 0.8 m table-top scene --
+  // stretched the box so far that the whole scene fell into a handful of cells: no spatial order, group boxes as
+  // large as the scene, every group touched by every pick (25 ms instead of 5.4 for 16 scenes, slower than the full
+  // scan).  Per axis a 256-bin histogram over [min, max] gives the range that leaves N / 128 points outside on
+  // either side; where that range is under half of the extent the axis is re-boxed to it plus a quarter of its
+  // width on both sides (twice: the second histogram refines a first one whose bins were as wide as the scene),
+  // and the points outside any re-boxed axis share ONE key -- they sort into groups of their own, which die as soon
+  // as FPS has picked them (it picks far points first), instead of poisoning 50 groups of regular points.  Compact
+  // clouds (uniform, Gaussian, the bench scenes) keep min / max: a trimmed box there would put the whole rim into
+  // the outlier groups.  Ordering only: the result is exact for any box.
+  float cut_lo[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  float cut_hi[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+  {
+    uint32_t* __restrict__ hist = H;               // [3][256], zeroed above; re-zeroed before the cell counters use it
+    float* __restrict__ rb = reinterpret_cast<float*>(red + 7 * NW);   // [3][2] the re-boxed ranges
+    for (int round = 0; round < 2; ++round) {
+      __syncthreads();
+      float hinv[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) hinv[a] = ext[a] > 0.f ? 256.0f / ext[a] : 0.f;
+      for_points([&](int, const float (&c)[3]) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const float sc = (c[a] - bl[a]) * hinv[a];
+          if (sc >= 0.f && sc <= 256.0f) atomicAdd(&hist[a * 256 + (int)(sc < 255.f ? sc : 255.f)], 1u);   // (outside an earlier round's box, NaN: not counted)
+        }
+      });
+      __syncthreads();
+      if (wave < 3) {   // one wave per axis: 4 bins per lane, inclusive scan, first / last bin past the cut
+        const int a = wave;
+        uint32_t c4[4], tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          c4[k] = hist[a * 256 + 4 * lane + k];
+          tot += c4[k];
+        }
+        uint32_t incl = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t o2 = __shfl_up(incl, off);
+          if (lane >= off) incl += o2;
+        }
+        const uint32_t all = __builtin_amdgcn_readlane(incl, 63);
+        const uint32_t cut = (uint32_t)N >> 7;
+        uint32_t run = incl - tot;
+        int first = 256, last = -1;            // first bin whose inclusive count exceeds the cut, last bin with > cut behind-or-in it
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t before = run;
+          run += c4[k];
+          if (run > cut && first == 256) first = 4 * lane + k;
+          if (all - before > cut) last = 4 * lane + k;
+        }
+        const int f = (int)wave_min_u32((uint32_t)first);
+        const int l = (int)wave_max_u32((uint32_t)(last + 1)) - 1;
+        if (lane == 0) {
+          const float e = a == 0 ? ext[0] : (a == 1 ? ext[1] : ext[2]);
+          const float b0 = a == 0 ? bl[0] : (a == 1 ? bl[1] : bl[2]);
+          const float w = e * (1.0f / 256.0f);
+          float nlo = b0, nhi = b0 + e;
+          if (e > 0.f && l >= f && (float)(l - f + 1) < 128.0f) {   // the trimmed range is under half of the extent
+            const float width = (float)(l - f + 1) * w;
+            nlo = fmaxf(b0, b0 + (float)f * w - 0.25f * width);
+            nhi = fminf(b0 + e, b0 + (float)(l + 1) * w + 0.25f * width);
+          }
+          rb[2 * a] = nlo;
+          rb[2 * a + 1] = nhi;
+        }
+      }
+      __syncthreads();
+      bool any = false;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float nlo = rb[2 * a], nhi = rb[2 * a + 1];
+        if (nlo > bl[a] || nhi < bl[a] + ext[a]) {
+          any = true;
+          cut_lo[a] = nlo;
+          cut_hi[a] = nhi;
+          bl[a] = nlo;
+          ext[a] = nhi - nlo;
+        }
+      }
+      for (int i = t; i < 3 * 256; i += FPS_SORT_THREADS) hist[i] = 0;
+      if (!any) break;                          // (uniform: every thread read the same rb)
+    }
+    __syncthreads();
+  }
+  const bool reboxed = cut_lo[0] > -__builtin_inff() || cut_lo[1] > -__builtin_inff() || cut_lo[2] > -__builtin_inff() ||
+                       cut_hi[0] < __builtin_inff() || cut_hi[1] < __builtin_inff() || cut_hi[2] < __builtin_inff();
   // deal the bits (every thread computes the same sequence): seq = 2 bits per level, MSB level first
   int nb[3] = {0, 0, 0};
   uint32_t seq = 0;
@@ -666,6 +755,12 @@ __global__ __launch_bounds__(FPS_SORT_THREADS) void fps_cell_sort_kernel(
   __syncthreads();
   auto quant = [](float sc, float top) -> uint32_t { return (uint32_t)(sc > 0.f ? (sc < top ? sc : top) : 0.f); };   // NaN -> 0
   auto cell_of = [&](const float (&c)[3]) -> uint32_t {
+    if (reboxed) {   // outside a re-boxed axis: the outliers' own key (the last cell)
+      bool out = false;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) out = out || c[a] < cut_lo[a] || c[a] > cut_hi[a];
+      if (out) return (1u << FPS_SORT_BITS) - 1u;
+    }
     if (thin) {
       const uint32_t qa = quant((pick(c, ax_a) - pick(bl, ax_a)) * inv_ab, 63.f);
       const uint32_t qb = quant((pick(c, ax_b) - pick(bl, ax_b)) * inv_ab, 63.f);
@@ -1510,7 +1605,7 @@ __global__ __launch_bounds__(256) void fps_prefix_check_kernel(const float* __re
 
 static int launch_fps_cell_sort(const float* xyz, int64_t B, int64_t N, int G, int* perm, float* gbox,
                                 float4* aos, int aos_cap, hipStream_t stream) {
-  constexpr size_t lds = sizeof(uint32_t) * (FPS_SORT_WORDS + 3 * 256 + 64 * 64 / 2 + 7 * (FPS_SORT_THREADS / 64));
+  constexpr size_t lds = sizeof(uint32_t) * (FPS_SORT_WORDS + 3 * 256 + 64 * 64 / 2 + 7 * (FPS_SORT_THREADS / 64) + 8);
   static LdsAttrCache lds_cache;
   if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(&fps_cell_sort_kernel), lds, lds_cache)) return rc;
   hipLaunchKernelGGL(fps_cell_sort_kernel, dim3((unsigned)B), dim3(FPS_SORT_THREADS), lds, stream, xyz, (int)N, G,

@@ -201,7 +201,7 @@ static int launch_three_nn_scan(const float* q, const float* k, int64_t B, int64
 }
 
 // Cell edge for the operator-API grid search, chosen on the device (no host read):
-// `factor` x the mean distance from a key to its third-nearest other key, measured on 64
+// `factor` x the median distance from a key to its third-nearest other key, measured on 64
 // sample keys spread over the batch (one wave per sample scans its scene's keys, lanes
 // keep their four smallest squared distances, four wave-min rounds merge them).  The
 // search cost grows with (cell / key spacing)^2..3 and every query whose third neighbour
@@ -273,24 +273,30 @@ __global__ __launch_bounds__(64) void nn_auto_cell_kernel(const float* __restric
   last = __builtin_amdgcn_readfirstlane(last);
   if (!last) return;
   __threadfence();
-  if (lane == 0) {
-    float sum = 0.f;
-    int n = 0;
+  {
+    // the MEDIAN of the valid samples (lane q holds sample q; its rank by counting): a few keys that are far
+    // outliers -- FPS picks those first, so they ARE keys -- would drag a mean to an edge many times too large
+    const float d = __hip_atomic_load(d3s + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool ok = d > 0.f && d < __builtin_inff();
+    const int n = __popcll(__ballot(ok));
+    int rank = 0;
     for (int q = 0; q < NN_SAMPLES; ++q) {
-      const float d = __hip_atomic_load(d3s + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (d > 0.f && d < __builtin_inff()) {
-        sum += sqrtf(d);
-        ++n;
-      }
+      const float dq = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), q));
+      const bool okq = dq > 0.f && dq < __builtin_inff();
+      rank += (okq && (dq < d || (dq == d && q < lane))) ? 1 : 0;
     }
-    const float cell = n > 0 ? factor * sum / (float)n : 0.f;
-    if (!(cell > 0.f) || !(cell < 1e18f)) {
-      out[0] = 1.0f;
-      out[1] = -1.0f;
-    } else {
-      const float edge = cell * (1.0f - 1e-3f);
-      out[0] = 1.0f / cell;
-      out[1] = edge * edge;
+    const uint64_t mid = __ballot(ok && rank == n / 2);
+    float cell = 0.f;
+    if (mid) cell = factor * sqrtf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), (int)(__ffsll((unsigned long long)mid) - 1))));
+    if (lane == 0) {
+      if (!(cell > 0.f) || !(cell < 1e18f)) {
+        out[0] = 1.0f;
+        out[1] = -1.0f;
+      } else {
+        const float edge = cell * (1.0f - 1e-3f);
+        out[0] = 1.0f / cell;
+        out[1] = edge * edge;
+      }
     }
   }
 }

@@ -418,6 +418,34 @@ def test_fps_prepass_is_a_permutation_with_exact_tight_boxes(dev, variant, N):
         assert diag < (0.2 if variant != "uniform-box" else 0.4) * diag0, (b, diag, diag0)
 
 
+def test_fps_prepass_far_outliers_keep_the_spatial_order_and_fps_exact(F, oracle, dev):
+    """50 background points 50 m behind a table-top scene (round 4: they stretched the pre-pass's box until the
+    scene fell into a handful of cells -- FPS 25 ms instead of 5.4 per 16 scenes).  The box is the range that leaves
+    N / 128 points outside per side where that is under half of the extent; outside points share one key.  Still a
+    permutation with exact boxes, the regular groups as tight as without the outliers, the outliers in groups of
+    their own, and the sample itself bit-exact."""
+    N = 25600
+    clean = synth.make_batch([2], N)
+    pts = clean.copy()
+    pts[0, :, 100:150] += 50.0
+    pts[0, 2, 150:160] -= 30.0                  # ... and ten below
+    perm, box = _fps_prepass(pts, dev)
+    perm0, box0 = _fps_prepass(clean, dev)
+    assert np.array_equal(np.sort(perm[0]), np.arange(N))
+    want = _group_boxes(pts[0], perm[0])
+    assert np.array_equal(box[0], want, equal_nan=True)
+    diag = np.linalg.norm(want[:N // 64, 3:] - want[:N // 64, :3], axis=1)
+    diag0 = np.linalg.norm(box0[0][:N // 64, 3:] - box0[0][:N // 64, :3], axis=1)
+    assert np.median(diag) < 1.3 * np.median(diag0), (np.median(diag), np.median(diag0))
+    assert (diag > 1.0).sum() <= 3                     # the groups that hold the 60 far points (and a few rim points)
+    far = np.zeros(N, bool)
+    far[100:160] = True
+    groups_with_far = np.unique(np.nonzero(far[perm[0]])[0] // 64)
+    assert len(groups_with_far) <= 3
+    idx = F.farthest_point_sample(_t(pts, dev), 2048)
+    assert np.array_equal(idx.cpu().numpy(), oracle.fps(pts, 2048))
+
+
 def test_fps_prepass_degenerate_clouds(dev):
     """All points equal; a cloud on a line (two zero extents); a plane; non-finite coordinates:
     still a permutation with exact boxes (the keys only order, they never drop a point)."""
