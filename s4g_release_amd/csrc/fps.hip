@@ -1511,15 +1511,18 @@ static bool fps_use_pruned_l2(int64_t N, int64_t M) {
   return !(e && (e[0] == 'c' || e[0] == 'h' || e[0] == 'd'));
 }
 
-static bool fps_use_pruned(int64_t N) {
+// M < 0: "may the pruned kernel run for this N" (workspace sizing, which does not know M)
+static bool fps_use_pruned(int64_t N, int64_t M) {
   // S4G_FPS_MODE=dense|pruned (read per call).  Default: pruned where a lane holds more
   // than 20 points (N > 10 240) -- below that the full scan is cheaper than the
-  // bookkeeping (SA2 size: 0.94 ms dense vs 1.28 ms pruned).
+  // bookkeeping (SA2 size, 5 120 -> 1 024: 0.94 ms dense vs 1.28 ms pruned) -- unless the chain is long:
+  // from 2 048 picks on the pruned kernel wins from 10 points per lane (round 4, 16 scenes in step,
+  // M = 5 120: N = 6 000 4.2 vs 7.3 ms, 8 192 4.3 vs 7.4, 10 240 4.5 vs 7.2)
   const char* e = getenv("S4G_FPS_MODE");
   if (e && e[0] == 'd') return false;
   if (N > (int64_t)512 * 50) return false;
   if (e && e[0] == 'p') return N > 512 * 5;
-  return N > 512 * 20;
+  return N > 512 * 20 || (N > 512 * 10 && (M < 0 || M >= 2048));
 }
 
 static int ref_block_lg(int64_t n) {
@@ -1625,7 +1628,7 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
   // the full-scan kernel (which leaves its min-distances in the workspace), the rest pruned
   FpsSortWs w = {};
   bool pruned = false;
-  if (fps_use_pruned(N) && M > FPS_DENSE_STEPS && B < (1 << 16)) {
+  if (fps_use_pruned(N, M) && M > FPS_DENSE_STEPS && B < (1 << 16)) {
     w = fps_sort_ws(ws, B, N);
     pruned = ws && ws_bytes >= w.total;
   }
@@ -1734,7 +1737,7 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
 
 size_t fps_workspace_bytes(int64_t B, int64_t N) {
   if (N <= 0 || B <= 0) return 0;
-  if (N <= (int64_t)512 * 50) return fps_use_pruned(N) ? fps_sort_ws(nullptr, B, N).total : 0;
+  if (N <= (int64_t)512 * 50) return fps_use_pruned(N, -1) ? fps_sort_ws(nullptr, B, N).total : 0;
   if (N <= (int64_t)512 * 100) {   // sort buffers + sorted records of the pruned kernel / the cluster kernel's exchange slots
     const size_t c = fps_cluster_ws_bytes(B);
     const size_t l2 = fps_sort_ws(nullptr, B, N).total;
