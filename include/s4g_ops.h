@@ -57,7 +57,7 @@ extern "C" {
  *  read inside libs4g_hip.so (per call unless noted):
  *   S4G_FPS_MODE=dense|pruned      FPS kernel for N <= 25 600: full scan | group-pruned (default: pruned
  *                                  above 10 240 points, and above 5 120 when M >= 2 048).  =dense also turns the L2-resident pruned kernel
- *                                  off for 25 600 < N <= 51 200 (the streaming kernel runs instead)
+ *                                  off for 25 600 < N <= 65 535 (the streaming kernel runs instead)
  *   S4G_FPS_DENSE_STEPS=k          first k picks by the full-scan kernel in front of the pruned one (0)
  *   S4G_BQ_MODE=scan|grid          ball query path (default: grid from 8 192 points)
  *   S4G_GRID_BUILD=loop            streaming grid build for every size (read once)

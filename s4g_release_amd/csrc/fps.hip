@@ -1473,6 +1473,8 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
 }
 
 constexpr int FPS_L2_CAP = 512 * 100;   // points per scene of fps_pruned_l2_kernel<512, 100>
+constexpr int FPS_L2_CAP_BIG = 65535;  // ... of <512, 128> (round 4: 51 200 < N <= 65 535; the pre-pass's 16-bit positions end there)
+static int fps_l2_slots(int64_t N) { return N <= FPS_L2_CAP ? 100 : 128; }
 
 struct FpsSortWs {
   float* gbox;      // [B][G][6] boxes of the 64-point groups
@@ -1494,11 +1496,12 @@ static FpsSortWs fps_sort_ws(void* base, int64_t B, int64_t N) {
   };
   // fps_pruned_l2_kernel's box pass always writes 8 * 100 groups per scene (fewer real groups for
   // 25 600 < N < 34 816): size for whichever is larger
-  const int64_t gbox_groups = (N + 63) / 64 + 256 > 800 ? (N + 63) / 64 + 256 : 800;
+  const int64_t l2_groups = 8 * (int64_t)fps_l2_slots(N);
+  const int64_t gbox_groups = (N + 63) / 64 + 256 > l2_groups ? (N + 63) / 64 + 256 : l2_groups;
   w.gbox = (float*)take(sizeof(float) * 6 * B * gbox_groups);
   w.md = (float*)take(sizeof(float) * n);
   w.val_out = (int*)take(sizeof(int) * n);
-  w.aos = N > (int64_t)512 * 50 ? (float4*)take(sizeof(float4) * (size_t)B * FPS_L2_CAP) : nullptr;
+  w.aos = N > (int64_t)512 * 50 ? (float4*)take(sizeof(float4) * (size_t)B * 512 * fps_l2_slots(N)) : nullptr;
   w.total = off;
   return w;
 }
@@ -1506,7 +1509,7 @@ static FpsSortWs fps_sort_ws(void* base, int64_t B, int64_t N) {
 // 25 600 < N <= 51 200: the one-CU pruned kernel with coordinates in L2 (default),
 // S4G_FPS_MODE=cluster the two-CU full scan (opt-in, B <= 128), =hybrid the one-CU full scan
 static bool fps_use_pruned_l2(int64_t N, int64_t M) {
-  if (N <= (int64_t)512 * 50 || N > FPS_L2_CAP || M < 64) return false;
+  if (N <= (int64_t)512 * 50 || N > FPS_L2_CAP_BIG || M < 64) return false;
   const char* e = getenv("S4G_FPS_MODE");
   return !(e && (e[0] == 'c' || e[0] == 'h' || e[0] == 'd'));
 }
@@ -1697,10 +1700,14 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
   if (fps_use_pruned_l2(N, M) && B < (1 << 16)) {
     const FpsSortWs w2 = fps_sort_ws(ws, B, N);
     if (ws && ws_bytes >= w2.total) {
-      constexpr int G = 8 * 100;
-      if (int rc = launch_fps_cell_sort(xyz, B, N, G, w2.val_out, w2.gbox, w2.aos, FPS_L2_CAP, stream)) return rc;
-      hipLaunchKernelGGL((fps_pruned_l2_kernel<512, 100, FMAD, IdxT, 2>), grid, dim3(512), 0, stream, xyz,
-                         w2.aos, w2.gbox, (int)N, (int)M, idx, ctr, lg, ex.dist);
+      const int slots = fps_l2_slots(N);
+      if (int rc = launch_fps_cell_sort(xyz, B, N, 8 * slots, w2.val_out, w2.gbox, w2.aos, 512 * slots, stream)) return rc;
+      if (slots == 100)
+        hipLaunchKernelGGL((fps_pruned_l2_kernel<512, 100, FMAD, IdxT, 2>), grid, dim3(512), 0, stream, xyz,
+                           w2.aos, w2.gbox, (int)N, (int)M, idx, ctr, lg, ex.dist);
+      else
+        hipLaunchKernelGGL((fps_pruned_l2_kernel<512, 128, FMAD, IdxT, 2>), grid, dim3(512), 0, stream, xyz,
+                           w2.aos, w2.gbox, (int)N, (int)M, idx, ctr, lg, ex.dist);
       S4G_LAUNCH_CHECK();
       return S4G_OK;
     }
@@ -1738,7 +1745,7 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
 size_t fps_workspace_bytes(int64_t B, int64_t N) {
   if (N <= 0 || B <= 0) return 0;
   if (N <= (int64_t)512 * 50) return fps_use_pruned(N, -1) ? fps_sort_ws(nullptr, B, N).total : 0;
-  if (N <= (int64_t)512 * 100) {   // sort buffers + sorted records of the pruned kernel / the cluster kernel's exchange slots
+  if (N <= FPS_L2_CAP_BIG) {   // sort buffers + sorted records of the pruned kernel / the cluster kernel's exchange slots
     const size_t c = fps_cluster_ws_bytes(B);
     const size_t l2 = fps_sort_ws(nullptr, B, N).total;
     return l2 > c ? l2 : c;

@@ -99,9 +99,29 @@ def test_fps_cluster_full_size_batch_ties_and_fmad(F, oracle, dev, monkeypatch, 
 
 
 def test_fps_streaming_fallback_very_large_cloud(F, oracle, dev):
-    pts = synth.make_batch([2], 60000)
+    """N > 65 535: the streaming kernel (min-distances in the workspace); M < 64 takes it at any size."""
+    pts = synth.make_batch([2], 70000)
     got = F.farthest_point_sample(_t(pts, dev), 100).cpu().numpy()
     assert np.array_equal(got, oracle.fps(pts, 100))
+    pts = synth.make_batch([2], 60000)
+    got = F.farthest_point_sample(_t(pts, dev), 40).cpu().numpy()
+    assert np.array_equal(got, oracle.fps(pts, 40))
+
+
+@pytest.mark.parametrize("N,M,variant", [(51201, 900, "tabletop-v1"), (60000, 1500, "dup-heavy"),
+                                         (65535, 700, "lattice"), (65535, 2000, "tabletop-v1")])
+def test_fps_l2_pruned_kernel_128_slots(F, oracle, dev, N, M, variant):
+    """51 200 < N <= 65 535 (round 4): the L2-resident pruned kernel with 128 min-distances per lane instead of
+    the streaming fallback (16 scenes of 65 535 points -> 5 120: 6.6 ms instead of ~75); both distance contracts."""
+    pts = synth.make_batch([3, 9], N, variant=variant)
+    got = F.farthest_point_sample(_t(pts, dev), M).cpu().numpy()
+    assert np.array_equal(got, oracle.fps(pts, M))
+    try:
+        F.set_distance_mode("fmad")
+        got = F.farthest_point_sample(_t(pts[:1], dev), 300).cpu().numpy()
+    finally:
+        F.set_distance_mode("strict")
+    assert np.array_equal(got, oracle.fps(pts[:1], 300, fmad=1))
 
 
 def test_fps_fmad_mode_pruned_size(F, oracle, dev):
