@@ -1218,11 +1218,20 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
           if constexpr (SPEC) {
             // the wave's runner-up distance: the best of this group's other points and of the
             // other groups' maxima (a second holder of the maximum makes it the maximum itself)
+            // (round 4) Several holders of the maximum in the group that are EXACT COPIES of the winner -- clouds
+            // subsampled with replacement, as the reference's own harness does (grasp_proposal_test.py:29) -- fall
+            // to zero with it: they do not bound the next pick, the runner-up is the best point that is not a copy.
+            bool dup = lane == wl;
             if (__popcll(eq) > 1) {
-              nbest = 2;
-            } else if (nbest == 1) {
+              const float wx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vx), wl));
+              const float wy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vy), wl));
+              const float wz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vz), wl));
+              dup = hit && vx == wx && vy == wy && vz == wz;
+              if (__ballot(hit && !dup)) nbest = 2;             // a different point at the same distance
+            }
+            if (nbest == 1) {
               // max(this group's other points, the other groups' maxima): one wave reduction for both
-              uint32_t others = (s < N && lane != wl) ? __float_as_uint(vm) : 0u;
+              uint32_t others = (s < N && !dup) ? __float_as_uint(vm) : 0u;
 #pragma unroll
               for (int r2 = 0; r2 < GPL; ++r2)
                 others = max(others, (r2 == r && lane == gl) ? 0u : gbits[r2]);
@@ -1444,10 +1453,16 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
             kmin = wave_min_u32(k);
             wl = __ffsll((unsigned long long)__ballot(k == kmin)) - 1;
           }
+          bool dup = lane == wl;                               // exact copies of the winner: see fps_pruned_kernel
           if (__popcll(eq) > 1) {
-            nbest = 2;
-          } else if (nbest == 1) {
-            uint32_t others = (s < N && lane != wl) ? __float_as_uint(vm) : 0u;
+            const float wx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.x), wl));
+            const float wy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.y), wl));
+            const float wz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.z), wl));
+            dup = hit && me.x == wx && me.y == wy && me.z == wz;
+            if (__ballot(hit && !dup)) nbest = 2;
+          }
+          if (nbest == 1) {
+            uint32_t others = (s < N && !dup) ? __float_as_uint(vm) : 0u;
 #pragma unroll
             for (int r2 = 0; r2 < GPL; ++r2) others = max(others, (r2 == r && lane == gl) ? 0u : gbits[r2]);
             wd2 = wave_max_u32(others);

@@ -98,6 +98,25 @@ def test_fps_cluster_full_size_batch_ties_and_fmad(F, oracle, dev, monkeypatch, 
     assert np.array_equal(got, oracle.fps(pts[:1], 600, fmad=1))
 
 
+def test_fps_clouds_subsampled_with_replacement_all_picks(F, oracle, dev):
+    """The reference's own harness draws its 25 600 points WITH replacement (grasp_proposal_test.py:26-29), so exact
+    copies are the normal input.  Copies of the winner inside its group fall to zero with it: they no longer veto the
+    exchange's further picks (round 4: FPS of such clouds 7.5 -> 5.6 ms per 16 scenes), and every one of the 5 119
+    picks still is the oracle's, including which copy's index is reported."""
+    rng = np.random.default_rng(29)
+    src = synth.make_batch([5], 48902)[0]
+    pts = np.stack([src[:, rng.integers(0, 48902, size=25600)] for _ in range(2)]).astype(np.float32)
+    assert len(np.unique(pts[0].T, axis=0)) < 0.85 * 25600          # ~21 % of the draws repeat an earlier one
+    got = F.farthest_point_sample(_t(pts, dev), 5120).cpu().numpy()
+    assert np.array_equal(got, oracle.fps(pts, 5120))
+    dup = synth.make_batch([1], 25600, variant="dup-heavy")
+    got = F.farthest_point_sample(_t(dup, dev), 5120).cpu().numpy()
+    assert np.array_equal(got, oracle.fps(dup, 5120))
+    big = np.stack([src[:, rng.integers(0, 48902, size=51200)]]).astype(np.float32)   # the L2-resident kernel
+    got = F.farthest_point_sample(_t(big, dev), 3000).cpu().numpy()
+    assert np.array_equal(got, oracle.fps(big, 3000))
+
+
 def test_fps_streaming_fallback_very_large_cloud(F, oracle, dev):
     """N > 65 535: the streaming kernel (min-distances in the workspace); M < 64 takes it at any size."""
     pts = synth.make_batch([2], 70000)
