@@ -47,7 +47,8 @@ struct FpsSlot {
   uint32_t tie;
   float x, y, z;
   uint32_t d2;      // two-pick exchange: distance bits of the wave's runner-up (else 0)
-  uint32_t pad[2];
+  uint32_t key2;    // ... and, where the runner-up TIES with the candidate (d2 == d), its tie key; 0 = not known
+  uint32_t pad;
 };
 
 // Optional per-call extras of the register / pruned kernels: dist (B, M) receives every pick's
@@ -98,7 +99,7 @@ __device__ __forceinline__ void fps_block_exchange(FpsSlot* slots, int wave,
     s.x = sx;
     s.y = sy;
     s.z = sz;
-    s.d2 = s.pad[0] = s.pad[1] = 0;
+    s.d2 = s.key2 = s.pad = 0;
     slots[wave] = s;
   }
   __syncthreads();
@@ -142,7 +143,7 @@ __device__ __forceinline__ void fps_block_exchange(FpsSlot* slots, int wave,
 // Everything is wave-uniform and every wave decides alike.  Returns the number of picks (>= 1).
 template <int WAVES, bool FMAD, int MAXP, typename IdxT>
 __device__ __forceinline__ int fps_block_exchange_multi(FpsSlot* slots, int wave, int lane, uint32_t wmax,
-                                                        uint32_t wtie, uint32_t wd2, float sx, float sy,
+                                                        uint32_t wtie, uint32_t wd2, uint32_t wkey2, float sx, float sy,
                                                         float sz, int limit, int& cur, float& cx, float& cy,
                                                         float& cz, uint32_t& picked_waves,
                                                         IdxT* __restrict__ out_i, float* __restrict__ cout_i,
@@ -157,7 +158,8 @@ __device__ __forceinline__ int fps_block_exchange_multi(FpsSlot* slots, int wave
     s.y = sy;
     s.z = sz;
     s.d2 = wd2;
-    s.pad[0] = s.pad[1] = 0;
+    s.key2 = wkey2;
+    s.pad = 0;
     slots[wave] = s;
   }
   __syncthreads();
@@ -179,13 +181,9 @@ __device__ __forceinline__ int fps_block_exchange_multi(FpsSlot* slots, int wave
   uint32_t my_d = 0u;
   const bool upper = (lane & 8) != 0;   // lanes 8..15 of a row reduce the runner-ups while lanes 0..7 reduce v
   uint32_t bmax = max8(v);
-#pragma unroll
-  for (int k = 0; k < MAXP; ++k) {
-    if (k >= limit) break;
-    if (k > 0) {
-      const uint32_t bmax_s = __builtin_amdgcn_readfirstlane(bmax);
-      if (bmax_s == 0u || bmax_s <= bnd) break;
-    }
+  // one pick: the best candidate by (distance, key), then -- unless it was the last one this exchange may take --
+  // the other candidates' values after it and the two maxima of the next round
+  auto take = [&](int k) {
     uint32_t win = (uint32_t)__ballot(v == bmax) & 0xFFu;
     if (win & (win - 1u)) {   // equal distances: the smaller key (sampling_kernel.cu's tie rule)
       uint32_t cand = (v == bmax) ? s.tie : 0xFFFFFFFFu;
@@ -209,6 +207,44 @@ __device__ __forceinline__ int fps_block_exchange_multi(FpsSlot* slots, int wave
       const uint32_t red = max8(upper ? (hit ? s.d2 : 0u) : v);
       bnd = max(bnd, (uint32_t)__builtin_amdgcn_readlane(red, 8));
       bmax = red;   // (valid in lanes 0..7 of every row: the only lanes the ballots and lane k look at)
+    }
+  };
+  bool at_bound = false;     // the sequence ended on a candidate EQUAL to the disturbed waves' runner-up distance
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    if (k >= limit) break;
+    if (k > 0) {
+      const uint32_t bmax_s = __builtin_amdgcn_readfirstlane(bmax);
+      if (bmax_s == 0u || bmax_s <= bnd) {
+        at_bound = bmax_s != 0u && bmax_s == bnd;
+        break;
+      }
+    }
+    take(k);
+  }
+  if (__builtin_expect(at_bound, 0)) {
+    // (round 4) Lattice clouds: a whole shell of points holds the maximum, so the best remaining candidate TIES
+    // with a disturbed wave's runner-up.  The sequential algorithm takes the smallest key among all holders; a
+    // disturbed wave's other holders have keys >= the key2 it reported, so the candidate is the next pick iff
+    // its key is below every such key2 (0 = not reported: stop, as before round 4).  Rolled and out of the
+    // unrolled loop above: the tie-free exchange is the code of round 3.
+#pragma unroll 1
+    for (int k = np; k < MAXP && k < limit; ++k) {
+      const uint32_t bmax_s = __builtin_amdgcn_readfirstlane(bmax);
+      if (bmax_s == 0u || bmax_s < bnd) break;
+      if (bmax_s == bnd) {
+        uint32_t wkey = (v == bmax) ? s.tie : 0xFFFFFFFFu;
+        wkey = min(wkey, dpp_u32<0xB1>(wkey));
+        wkey = min(wkey, dpp_u32<0x4E>(wkey));
+        wkey = min(wkey, dpp_u32<0x141>(wkey));
+        const bool was_hit = v != s.d;            // picked (0) or lowered by a pick of this exchange
+        uint32_t kb = (was_hit && s.d2 == bnd) ? slots[ej].key2 : 0xFFFFFFFFu;
+        kb = min(kb, dpp_u32<0xB1>(kb));
+        kb = min(kb, dpp_u32<0x4E>(kb));
+        kb = min(kb, dpp_u32<0x141>(kb));
+        if (!((uint32_t)__builtin_amdgcn_readlane(wkey, 0) < (uint32_t)__builtin_amdgcn_readlane(kb, 0))) break;
+      }
+      take(k);
     }
   }
   // the callers' running centroid = the last pick (and the first one for the MAXP == 2 kernels)
@@ -1058,7 +1094,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
   if constexpr (SPEC) {                // the hand-over centroid poses as entry 0 of "the previous exchange"
     if (t == 0) {
       FpsSlot s0;
-      s0.d = s0.tie = s0.d2 = s0.pad[0] = s0.pad[1] = 0u;
+      s0.d = s0.tie = s0.d2 = s0.key2 = s0.pad = 0u;
       s0.x = cx;
       s0.y = cy;
       s0.z = cz;
@@ -1068,7 +1104,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
   }
   S4G_FPS_ACC_DECL();
   for (int i = i0; i < M;) {
-    uint32_t wmax, wtie, wd2 = 0u;
+    uint32_t wmax, wtie, wd2 = 0u, wkey2 = 0u;   // wkey2: the runner-up's tie key where it ties with the candidate
     float sx = cx, sy = cy, sz = cz;
     [[maybe_unused]] const unsigned long long st0 = S4G_FPS_T();
     // 1. groups the new centroid(s) can still change
@@ -1143,13 +1179,13 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
     if (wmax == 0u) {
       wtie = wave_min_u32(rkey | (uint32_t)cur);   // every point of this wave is at distance 0
     } else {
-      uint32_t best_key = 0xFFFFFFFFu;
+      uint32_t best_key = 0xFFFFFFFFu, second_key = 0xFFFFFFFFu;   // smallest / second-smallest key among the holders
       int nbest = 0;                               // groups / lanes that hold the maximum
       // Tie-heavy clouds (coordinates on a lattice: many groups of a wave hold the SAME maximum): the
       // group-by-group walk below costs ~80 instructions per tying group -- 42 ms instead of 4 for a batch
       // of lattice scenes of 25 600 points (round 4's `mixed_batch` leg found it).  From FPS_TIE_PAR tying
-      // groups on, every lane looks through its OWN tying slots instead: 21 ms (ties also rule out a second
-      // pick per exchange, which alone is 2.8 x); the tie-free path is unchanged (4.10 -> 4.14 ms).
+      // groups on, every lane looks through its OWN tying slots instead: 21 ms; with the runner-up's key published
+      // to the exchange (wkey2: ties no longer end an exchange after one pick) 12.4 ms.
       bool tie_par = false;
       if constexpr (GPL == 1) {
         const uint64_t gtie = __ballot(gbits[0] == wmax);     // bit = slot (group) of this wave that holds the maximum
@@ -1161,7 +1197,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
 #pragma unroll
           for (int pp = 0; pp < PPT; ++pp)
             if ((gtie >> pp) & 1ull) mdl[pp * THREADS] = md[pp];      // (wave-uniform: only the tying slots)
-          uint32_t kl = 0xFFFFFFFFu;
+          uint32_t kl = 0xFFFFFFFFu, k2l = 0xFFFFFFFFu;      // this lane's smallest and second-smallest key
           int pl = 0;
           uint64_t gleft = gtie;
 #pragma unroll 1
@@ -1172,12 +1208,16 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
             const uint32_t kk = tie_key(orig[s < N ? s : 0]);
             const bool hit = s < N && __float_as_uint(mdl[pp * THREADS]) == wmax;
             if (hit && kk < kl) {
+              k2l = kl;
               kl = kk;
               pl = pp;
+            } else if (hit && kk < k2l) {
+              k2l = kk;
             }
           }
           const uint32_t kmin = wave_min_u32(kl);
           const int wl = __ffsll((unsigned long long)__ballot(kl == kmin)) - 1;
+          wkey2 = wave_min_u32(lane == wl ? k2l : kl);         // the wave's second holder by key
           const int pw = __builtin_amdgcn_readlane(pl, wl);
           float vx, vy, vz, vm;
           fps_pick_slot<PPT, 0, PPT>(x, y, z, md, pw, vx, vy, vz, vm);
@@ -1192,6 +1232,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
       for (int r = 0; r < GPL; ++r) {
         uint64_t gmask = tie_par ? 0ull : __ballot(gbits[r] == wmax);
         if constexpr (SPEC) nbest += __popcll(gmask);
+        const int ngroups = __popcll(gmask);            // (copies of a group's winner only die if it is the wave's winner)
         while (gmask) {                          // one group unless maxima tie across groups
           const int gl = __ffsll((unsigned long long)gmask) - 1;
           // (readfirstlane: the slot number IS wave-uniform, but only a value the compiler knows to be
@@ -1222,12 +1263,25 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
             // subsampled with replacement, as the reference's own harness does (grasp_proposal_test.py:29) -- fall
             // to zero with it: they do not bound the next pick, the runner-up is the best point that is not a copy.
             bool dup = lane == wl;
-            if (__popcll(eq) > 1) {
-              const float wx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vx), wl));
-              const float wy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vy), wl));
-              const float wz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vz), wl));
-              dup = hit && vx == wx && vy == wy && vz == wz;
-              if (__ballot(hit && !dup)) nbest = 2;             // a different point at the same distance
+            uint32_t k2g = 0xFFFFFFFFu;                         // this group's second holder by key
+            if (__builtin_expect(__popcll(eq) > 1, 0)) {
+              if (ngroups == 1) {
+                const float wx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vx), wl));
+                const float wy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vy), wl));
+                const float wz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vz), wl));
+                dup = hit && vx == wx && vy == wy && vz == wz;
+              }
+              if (__ballot(hit && !dup)) {                      // a different point at the same distance
+                nbest = 2;
+                k2g = wave_min_u32((hit && !dup) ? k : 0xFFFFFFFFu);
+              }
+            }
+            if (__builtin_expect(nbest > 1, 0)) {   // (only then is the second key ever read: keep it off the tie-free path)
+              if (kmin < best_key) {
+                second_key = min(min(second_key, best_key), k2g);
+              } else {
+                second_key = min(second_key, kmin);
+              }
             }
             if (nbest == 1) {
               // max(this group's other points, the other groups' maxima): one wave reduction for both
@@ -1247,7 +1301,10 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
         }
       }
       if constexpr (SPEC) {
-        if (nbest > 1) wd2 = wmax;
+        if (__builtin_expect(nbest > 1, 0)) {
+          wd2 = wmax;
+          if (!tie_par) wkey2 = second_key == 0xFFFFFFFFu ? 0u : second_key;
+        }
       }
       wtie = best_key;
     }
@@ -1258,7 +1315,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
       // buffer parity per EXCHANGE, not per step: a multiple pick advances i by more than one, and
       // slots[i & 1] could then be rewritten by a fast wave while a slow one still reads the previous
       // exchange
-      npend = fps_block_exchange_multi<WAVES, FMAD, MAXP, IdxT>(slots[xpar], wave, lane, wmax, wtie, wd2, sx, sy,
+      npend = fps_block_exchange_multi<WAVES, FMAD, MAXP, IdxT>(slots[xpar], wave, lane, wmax, wtie, wd2, wkey2, sx, sy,
                                                                 sz, M - i, cur, cx, cy, cz, pwaves, out + i,
                                                                 cout ? cout + i : nullptr, M, f0x, f0y, f0z,
                                                                 dout ? dout + i : nullptr);
@@ -1478,7 +1535,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
       if (nbest > 1) wd2 = wmax;
       wtie = best_key;
     }
-    npend = fps_block_exchange_multi<WAVES, FMAD, MAXP, IdxT>(slots[xpar], wave, lane, wmax, wtie, wd2, sx, sy, sz,
+    npend = fps_block_exchange_multi<WAVES, FMAD, MAXP, IdxT>(slots[xpar], wave, lane, wmax, wtie, wd2, 0u, sx, sy, sz,
                                                               M - i, cur, cx, cy, cz, pwaves, out + i,
                                                               cout ? cout + i : nullptr, M, fx, fy, fz,
                                                               dout ? dout + i : nullptr);
