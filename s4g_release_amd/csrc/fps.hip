@@ -1414,7 +1414,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
   uint32_t pwaves = 0u;
   float fx = cx, fy = cy, fz = cz;     // first pick of the last exchange; (cx, cy, cz) = its last one
   for (int i = 1; i < M;) {
-    uint32_t wmax, wtie, wd2 = 0u;
+    uint32_t wmax, wtie, wd2 = 0u, wkey2 = 0u;
     float sx = cx, sy = cy, sz = cz;
     uint32_t gbits[GPL];
 #pragma unroll 1
@@ -1482,8 +1482,11 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
     if (wmax == 0u) {
       wtie = wave_min_u32(rkey | (uint32_t)cur);   // every point of this wave is at distance 0
     } else {
-      uint32_t best_key = 0xFFFFFFFFu;
+      uint32_t best_key = 0xFFFFFFFFu, second_key = 0xFFFFFFFFu;   // (second key: see fps_pruned_kernel)
       int nbest = 0;
+      int ngroups = 0;
+#pragma unroll
+      for (int r = 0; r < GPL; ++r) ngroups += __popcll(__ballot(gbits[r] == wmax));
 #pragma unroll
       for (int r = 0; r < GPL; ++r) {
         uint64_t gmask = __ballot(gbits[r] == wmax);
@@ -1511,12 +1514,25 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
             wl = __ffsll((unsigned long long)__ballot(k == kmin)) - 1;
           }
           bool dup = lane == wl;                               // exact copies of the winner: see fps_pruned_kernel
-          if (__popcll(eq) > 1) {
-            const float wx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.x), wl));
-            const float wy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.y), wl));
-            const float wz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.z), wl));
-            dup = hit && me.x == wx && me.y == wy && me.z == wz;
-            if (__ballot(hit && !dup)) nbest = 2;
+          uint32_t k2g = 0xFFFFFFFFu;
+          if (__builtin_expect(__popcll(eq) > 1, 0)) {
+            if (ngroups == 1) {
+              const float wx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.x), wl));
+              const float wy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.y), wl));
+              const float wz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.z), wl));
+              dup = hit && me.x == wx && me.y == wy && me.z == wz;
+            }
+            if (__ballot(hit && !dup)) {
+              nbest = 2;
+              k2g = wave_min_u32((hit && !dup) ? k : 0xFFFFFFFFu);
+            }
+          }
+          if (__builtin_expect(ngroups > 1 || nbest > 1, 0)) {
+            if (kmin < best_key) {
+              second_key = min(min(second_key, best_key), k2g);
+            } else {
+              second_key = min(second_key, kmin);
+            }
           }
           if (nbest == 1) {
             uint32_t others = (s < N && !dup) ? __float_as_uint(vm) : 0u;
@@ -1532,10 +1548,13 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_l2_kernel(const float* __r
           }
         }
       }
-      if (nbest > 1) wd2 = wmax;
+      if (__builtin_expect(nbest > 1, 0)) {
+        wd2 = wmax;
+        wkey2 = second_key == 0xFFFFFFFFu ? 0u : second_key;
+      }
       wtie = best_key;
     }
-    npend = fps_block_exchange_multi<WAVES, FMAD, MAXP, IdxT>(slots[xpar], wave, lane, wmax, wtie, wd2, 0u, sx, sy, sz,
+    npend = fps_block_exchange_multi<WAVES, FMAD, MAXP, IdxT>(slots[xpar], wave, lane, wmax, wtie, wd2, wkey2, sx, sy, sz,
                                                               M - i, cur, cx, cy, cz, pwaves, out + i,
                                                               cout ? cout + i : nullptr, M, fx, fy, fz,
                                                               dout ? dout + i : nullptr);
