@@ -1263,24 +1263,26 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
             // subsampled with replacement, as the reference's own harness does (grasp_proposal_test.py:29) -- fall
             // to zero with it: they do not bound the next pick, the runner-up is the best point that is not a copy.
             bool dup = lane == wl;
-            uint32_t k2g = 0xFFFFFFFFu;                         // this group's second holder by key
-            if (__builtin_expect(__popcll(eq) > 1, 0)) {
-              if (ngroups == 1) {
-                const float wx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vx), wl));
-                const float wy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vy), wl));
-                const float wz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vz), wl));
-                dup = hit && vx == wx && vy == wy && vz == wz;
+            if (__builtin_expect(__popcll(eq) > 1 || ngroups > 1, 0)) {   // ties: everything below stays off the tie-free path
+              uint32_t k2g = 0xFFFFFFFFu;                       // this group's second holder by key
+              if (__popcll(eq) > 1) {
+                if (ngroups == 1) {
+                  const float wx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vx), wl));
+                  const float wy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vy), wl));
+                  const float wz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vz), wl));
+                  dup = hit && vx == wx && vy == wy && vz == wz;
+                }
+                if (__ballot(hit && !dup)) {                    // a different point at the same distance
+                  nbest = 2;
+                  k2g = wave_min_u32((hit && !dup) ? k : 0xFFFFFFFFu);
+                }
               }
-              if (__ballot(hit && !dup)) {                      // a different point at the same distance
-                nbest = 2;
-                k2g = wave_min_u32((hit && !dup) ? k : 0xFFFFFFFFu);
-              }
-            }
-            if (__builtin_expect(nbest > 1, 0)) {   // (only then is the second key ever read: keep it off the tie-free path)
-              if (kmin < best_key) {
-                second_key = min(min(second_key, best_key), k2g);
-              } else {
-                second_key = min(second_key, kmin);
+              if (nbest > 1) {
+                if (kmin < best_key) {
+                  second_key = min(min(second_key, best_key), k2g);
+                } else {
+                  second_key = min(second_key, kmin);
+                }
               }
             }
             if (nbest == 1) {

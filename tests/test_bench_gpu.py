@@ -46,7 +46,7 @@ def test_bench_prints_one_contract_line():
     assert "besides the one being collected" in d["config"]["workload"] and d["config"]["in_flight"] == 2
     # BASELINE.json configs[4] rides on the same line: bf16, 32 x 51 200 points, its own roofline
     c4 = d["configs4"]
-    assert c4["dtype"] == "bf16" and c4["unit"] == "scenes/sec" and c4["value"] > 0 and c4["steps"] == 10
+    assert c4["dtype"] == "bf16" and c4["unit"] == "scenes/sec" and c4["value"] > 0 and c4["steps"] == 30
     assert "51 200" in c4["workload"] and c4["roofline"]["bound"] == "mfma" and 0 < c4["roofline"]["frac"] < 1
     assert c4["roofline"]["mfma_products_per_mac"] == 1
     assert d["collective"]["op"] is None
