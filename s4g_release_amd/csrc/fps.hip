@@ -1190,7 +1190,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float* __rest
       if constexpr (GPL == 1) {
         const uint64_t gtie = __ballot(gbits[0] == wmax);     // bit = slot (group) of this wave that holds the maximum
         tie_par = __popcll(gtie) > FPS_TIE_PAR;
-        if (tie_par) {
+        if (__builtin_expect(tie_par, 0)) {   // (unlikely: laid out behind the loop -- the step's code is as large as the instruction cache)
           // (through LDS: this thread's min-distances into its own column, then a ROLLED loop over them --
           // unrolled over the registers the block costs the common path 13 spilled registers and 4 %)
           float* __restrict__ mdl = reinterpret_cast<float*>(orig + THREADS * PPT) + t;
