@@ -788,12 +788,14 @@ def test_fused_model_full_golden(dev, precision):
         assert err < TOL, (k, err)
 
 
+@pytest.mark.parametrize("fixture", ["pn2_real.npz", "pn2_real_replace.npz"])
 @pytest.mark.parametrize("precision", ["f16x2", "bf16x3"])
-def test_fused_model_real_scene_golden(dev, precision):
+def test_fused_model_real_scene_golden(dev, precision, fixture):
     """The reference's own sample scene (inference/2638_view_0.p, seeded 25 600-point
-    subsample stored in the fixture) through the reference's Python network:
+    subsample stored in the fixture; `_replace`: drawn WITH replacement as the harness draws it, a fifth
+    of the points exact copies) through the reference's Python network:
     every index tensor bit-exact, outputs within 1e-4."""
-    g = GU.load("pn2_real.npz")
+    g = GU.load(fixture)
     net = GU.build_full_model(int(g["seed"]))
     assert GU.state_dict_sha256(net.state_dict()) == str(g["state_dict_sha256"])
     pred = _check_model(dev, g, net, g["points"], full=True, precision=precision)

@@ -3,6 +3,7 @@ network (tools/gen_golden.py): the oracle forward reproduces them, and the
 product model exposes the reference's state_dict layout and regenerates the
 golden weights from the seed."""
 import numpy as np
+import pytest
 import torch
 
 from tests import golden_util as GU
@@ -70,13 +71,17 @@ def test_full_config_input_regenerates():
     assert GU.sha(synth.make_batch([int(g["scene_id"])], 25600)) == str(g["points_sha256"])
 
 
-def test_real_scene_fixture_geometry_with_oracle():
-    """Oracle operators on the reference's sample scene (fixture pn2_real.npz): the
-    SA1 sampling and grouping indices the reference's modules requested."""
+@pytest.mark.parametrize("fixture", ["pn2_real.npz", "pn2_real_replace.npz"])
+def test_real_scene_fixture_geometry_with_oracle(fixture):
+    """Oracle operators on the reference's sample scene (fixtures pn2_real.npz: a seeded subsample;
+    pn2_real_replace.npz: drawn WITH replacement like the harness does, 19 986 distinct points among the
+    25 600): the SA1 sampling and grouping indices the reference's modules requested."""
     from oracle import oracle as O
-    g = GU.load("pn2_real.npz")
+    g = GU.load(fixture)
     pts = g["points"]
     assert pts.shape == (1, 3, 25600) and int(g["source_points"]) == 48902
+    if "replace" in fixture:
+        assert len(np.unique(pts[0].T, axis=0)) <= int(g["distinct_points"]) == 19986
     fps = O.fps(pts, 5120)
     assert np.array_equal(fps[:, :256], g["fps0_head"]) and GU.sha(fps) == str(g["fps0_sha256"])
     ctr = O.gather_points(pts, fps)

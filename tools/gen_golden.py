@@ -21,6 +21,9 @@ Outputs:
                                a SEEDED 25 600-point subsample is stored as data (the
                                demo's np.random.choice is unseeded), shipped config,
                                weights by seed (no checkpoint ships with the reference)
+  tests/golden/pn2_real_replace.npz   the same scene drawn WITH replacement (what the harness
+                               feeds: exact copies among the 25 600 points)
+S4G_GOLDEN_OUT=<dir> writes elsewhere (to add one fixture without rewriting the others).
 """
 import hashlib
 import os
@@ -99,7 +102,7 @@ def main():
     sys.path.insert(0, REF)
     from grasp_proposal.network_models.models.PointNet2_tcls import PointNet2 as RefPointNet2
     from grasp_proposal.network_models.models.pointnet2_utils import functions as ref_F
-    out_dir = os.path.join(ROOT, "tests", "golden")
+    out_dir = os.environ.get("S4G_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden"))
     os.makedirs(out_dir, exist_ok=True)
     torch.set_num_threads(8)
 
@@ -213,6 +216,32 @@ def main():
         blob["nnd%d_sha256" % li] = np.array(sha(_np(d)))
     np.savez_compressed(os.path.join(out_dir, "pn2_real.npz"), **blob)
     print("pn2_real.npz: %d of %d points of 2638_view_0.p" % (pts.shape[2], cloud.shape[1]))
+
+    # ---- ... and drawn WITH replacement, which is what the harness itself does
+    # (grasp_proposal_test.py:26-29: np.random.choice(..., replace=True) when the cloud is smaller than
+    # NUM_INPUT, and the demo's own unseeded choice): ~21 % of the 25 600 points are exact copies
+    pick = np.random.default_rng(26382).choice(cloud.shape[1], 25600, replace=True)
+    pts = np.ascontiguousarray(cloud[:, pick][None])
+    captured.clear()
+    with torch.no_grad():
+        pred = net({"scene_points": torch.from_numpy(pts)})
+    blob = {"seed": np.int64(seed), "points": pts, "source_points": np.int64(cloud.shape[1]),
+            "subsample_seed": np.int64(26382), "distinct_points": np.int64(len(np.unique(pick))),
+            "state_dict_sha256": np.array(state_dict_sha256(sd)), "positions": pos}
+    for k, v in pred.items():
+        blob["out/" + k] = _np(v)[:, :, pos]
+        blob["outsum/" + k] = np.float64(_np(v).astype(np.float64).sum())
+    for li, r in enumerate(captured["farthest_point_sample"]):
+        blob["fps%d_sha256" % li] = np.array(sha(_np(r)))
+        blob["fps%d_head" % li] = _np(r)[:, :256]
+    for li, (i, c) in enumerate(captured["ball_query"]):
+        blob["ball%d_sha256" % li] = np.array(sha(_np(i)))
+        blob["cnt%d_sha256" % li] = np.array(sha(_np(c)))
+    for li, (i, d) in enumerate(captured["point_search"]):
+        blob["nn%d_sha256" % li] = np.array(sha(_np(i)))
+        blob["nnd%d_sha256" % li] = np.array(sha(_np(d)))
+    np.savez_compressed(os.path.join(out_dir, "pn2_real_replace.npz"), **blob)
+    print("pn2_real_replace.npz: %d draws, %d distinct points" % (pts.shape[2], blob["distinct_points"]))
 
 
 if __name__ == "__main__":
