@@ -412,8 +412,27 @@ __global__ __launch_bounds__(64 * BQ_WAVES_PER_BLOCK) void bq_grid_query_kernel(
     IdxT* __restrict__ out_row = idx + ((size_t)b * M + m) * K;
     IdxT* __restrict__ out_cnt = cnt_out + (size_t)b * M + m;
     bool in_lds = false;
-    if (!exact) {
-      // out of the grid's exactness range: index-order scan, straight to global
+    // (round 4) A ball whose 27 cells hold a large share of the cloud -- a radius far above the point spacing --
+    // is answered faster by the index-order scan, which stops at the K-th hit: with C candidates and h ~ 0.3 C
+    // hits the scan reads ~ K N / h points, fewer than C once C^2 > ~200 N (16 x 25 600 points, 5 120 centres, r = 0.2:
+    // 2.85 -> 0.08 ms; r = 0.05: 0.30 -> 0.21; the shipped r = 0.02: 0.090 -> 0.091).
+    // Same result by construction ("first K in index order" either way).  The sum is only formed when a row
+    // is long, so the usual ball (rows of ~30 records) pays one compare.
+    bool dense = false;
+    {
+      const int len = (end0 - beg0) + (end1 - beg1);      // lanes 0..8: this row's records
+      if (__any(len > 128)) {
+        int tot = len;
+        tot += __shfl_xor(tot, 1);
+        tot += __shfl_xor(tot, 2);
+        tot += __shfl_xor(tot, 4);
+        tot += __shfl_xor(tot, 8);
+        tot = __shfl(tot, 0);                              // lanes 0..15 hold the nine rows (the others are 0)
+        dense = (float)tot * (float)tot > 200.0f * (float)N && tot > 8 * K;
+      }
+    }
+    if (!exact || dense) {
+      // out of the grid's exactness range (or a dense ball): index-order scan, straight to global
       bq_scan_centroid<FMAD, IdxT>(px, py, pz, N, cx, cy, cz, r2, K, lane, out_row, out_cnt);
       if constexpr (GROUP) __threadfence_block();  // the row is re-read below by other lanes
     } else {

@@ -176,7 +176,10 @@ def test_fps_argument_errors(F, dev):
 # ------------------------------------------------------------------ ball query
 @pytest.mark.parametrize("variant", ["tabletop-v1", "dup-heavy", "uniform-box"])
 @pytest.mark.parametrize("N,M,r,K", [(25600, 5120, 0.02, 64), (5120, 1024, 0.08, 64),
-                                     (1024, 256, 0.32, 64), (777, 33, 0.05, 7)])
+                                     (1024, 256, 0.32, 64), (777, 33, 0.05, 7),
+                                     # radii far above the point spacing: balls whose 27 cells hold a large share of
+                                     # the cloud take the index-order scan inside the grid kernel (round 4)
+                                     (25600, 2048, 0.2, 64), (25600, 1024, 0.06, 128), (12000, 700, 1.5, 16)])
 def test_ball_query_matches_oracle(F, oracle, dev, variant, N, M, r, K):
     pts = synth.make_batch([0, 5], N, variant=variant)
     ctr = oracle.gather_points(pts, oracle.fps(pts, M))
