@@ -67,3 +67,23 @@ def test_product_package_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_measurement_build_with_the_kernel_variants_compiles(tmp_path):
+    """`-DS4G_VARIANTS` (csrc/variants/*.inc: the measured-slower kernels kept for A/B runs) must keep compiling
+    against the shipped sources -- a change of a shared struct once broke it unnoticed -- and must say what it is."""
+    import ctypes
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = tmp_path / "libs4g_hip_variants.so"
+    out = subprocess.run(["make", "-C", os.path.join(root, "s4g_release_amd", "csrc"), "-j8", "OBJDIR=%s" % tmp_path,
+                          "LIB=%s" % lib, "HIPFLAGS_EXTRA=-DS4G_VARIANTS"], capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    import torch  # noqa: F401  (its HIP runtime first, as _cabi.lib does)
+    h = ctypes.CDLL(str(lib))
+    assert h.s4g_build_variants() == 1 and h.s4g_abi_version() == 8
+    shutil.rmtree(tmp_path, ignore_errors=True)
