@@ -471,6 +471,37 @@ def main():
               "d2h_ms_per_step": round(d2h, 4), "d2h_bytes": int(sum(o.numel() for o in outs_host) * 4),
               "note": "pinned host buffers, one step's clouds in / four head tensors out; not part of `value`"}
 
+        # ---- the contraction launches WITHOUT the next batches' geometry beside them: the same pipelined loop with
+        # the coordinate-only operators answered from a cache (tools/geo_cost.py's trick; the tensors are the same, the
+        # operators do not run) -- what the MFMA kernels reach when no FPS workgroup holds 16 CUs' register files
+        if impl == "fused" and roofline_dense is not None:
+            geo_ops = ("_fps_gather", "_fps_prefix_check", "_ball_query", "_group_rel_xyz_unique", "_group_rel_xyz",
+                       "_three_nn")
+            geo_orig = {n: getattr(runner, n) for n in geo_ops}
+            geo_cache = {}
+
+            def _cached(name):
+                def f(*a, **kw):
+                    key = (name,) + tuple(tuple(t.shape) if isinstance(t, torch.Tensor) else t for t in a) + \
+                        tuple(sorted((k, v is not None) for k, v in kw.items()))
+                    if key not in geo_cache:
+                        geo_cache[key] = geo_orig[name](*a, **kw)
+                    return geo_cache[key]
+                return f
+            try:
+                for n in geo_ops:
+                    setattr(runner, n, _cached(n))
+                ng_el, _, ng_sum, ng_tp = timed_region(12, 3, collective=False, gathered=False)
+            finally:
+                for n in geo_ops:
+                    setattr(runner, n, geo_orig[n])
+            ng_roof, _ = dense_roofline(ng_sum, ng_tp, precision)
+            roofline_dense["without_geometry"] = {
+                "frac": ng_roof["frac"], "achieved": ng_roof["achieved"], "ms_per_step": ng_roof["ms_per_step"],
+                "step_ms": round(1e3 * ng_el / 12, 3), "steps": 12,
+                "note": "same loop, the next batches' FPS / ball queries / 3-NN answered from a cache: the contraction "
+                        "launches with the whole chip to themselves (tools/geo_cost.py, profiles/r04_geometry_cost.md)"}
+
         # ---- north-star roofline: the operator pair ball_query + group_points(xyz) at SA1
         # size on this step's batch, through the public operator API (int64 indices),
         # HIP events around each launch on the launch stream.
