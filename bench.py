@@ -491,14 +491,14 @@ def main():
             try:
                 for n in geo_ops:
                     setattr(runner, n, _cached(n))
-                ng_el, _, ng_sum, ng_tp = timed_region(12, 3, collective=False, gathered=False)
+                ng_el, _, ng_sum, ng_tp = timed_region(32, 6, collective=False, gathered=False)
             finally:
                 for n in geo_ops:
                     setattr(runner, n, geo_orig[n])
             ng_roof, _ = dense_roofline(ng_sum, ng_tp, precision)
             roofline_dense["without_geometry"] = {
                 "frac": ng_roof["frac"], "achieved": ng_roof["achieved"], "ms_per_step": ng_roof["ms_per_step"],
-                "step_ms": round(1e3 * ng_el / 12, 3), "steps": 12,
+                "step_ms": round(1e3 * ng_el / 32, 3), "steps": 32,
                 "note": "same loop, the next batches' FPS / ball queries / 3-NN answered from a cache: the contraction "
                         "launches with the whole chip to themselves (tools/geo_cost.py, profiles/r04_geometry_cost.md)"}
 

@@ -30,7 +30,7 @@ def test_bench_prints_one_contract_line():
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     ng = r["without_geometry"]       # the same launches with the next batches' geometry answered from a cache
-    assert ng["frac"] > 0.9 * r["frac"] and ng["ms_per_step"] > 0 and ng["steps"] == 12
+    assert ng["frac"] > 0.9 * r["frac"] and ng["ms_per_step"] > 0 and ng["steps"] == 32
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
