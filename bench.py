@@ -39,6 +39,12 @@ Extra objects on the line:
   distributed   world, communicator size, every rank's scene range and device (self-verifying)
   cpu_baseline  the CPU oracle forward (oracle/pn2_forward.py) on ONE scene,
                 rank 0 at N == 1 only -- a reported baseline, not the target
+
+TEST MODE (tests/test_bench_world.py only): S4G_BENCH_BACKEND=gloo runs this file's whole control flow --
+self-launch, process group, shard table, gather check, fenced timed region, max over ranks, ranks != 0
+leaving, rank 0's line -- on CPU with `tests/bench_stub.StubRunner` in place of the network (it computes
+nothing of the network: a fill pattern with the fast path's submit() / result() shape).  The line then
+carries `"test_mode"` and its `value` is not a measurement.  Without that variable a GPU is required.
 """
 import argparse
 import hashlib
@@ -176,6 +182,57 @@ def load_traffic(key):
     return tr["traffic_bytes"], tr["source"], None
 
 
+class _HipRank:
+    """Device plumbing of one rank: a HIP device, RCCL, HIP events."""
+    backend, test_mode = "nccl", None
+
+    def __init__(self, torch, local_rank):
+        assert torch.cuda.is_available(), "bench.py needs a GPU"
+        self.torch = torch
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        self.name = torch.cuda.get_device_name(self.dev) + " cuda:%d" % local_rank
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def event(self):
+        ev = self.torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def init_kw(self):
+        return {"backend": "nccl", "device_id": self.dev}
+
+
+class _HostEvent:
+    def __init__(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return 1e3 * (other.t - self.t)
+
+
+class _HostRank:
+    """S4G_BENCH_BACKEND=gloo (tests only): the same control flow on CPU tensors, host clock for events."""
+    backend = "gloo"
+    test_mode = ("S4G_BENCH_BACKEND=gloo: tests/bench_stub.StubRunner on CPU instead of the network -- "
+                 "control-flow test of bench.py, `value` is NOT a measurement")
+
+    def __init__(self, torch, local_rank):
+        self.dev = torch.device("cpu")
+        self.name = "host-stub:%d" % local_rank
+
+    def sync(self):
+        pass
+
+    def event(self):
+        return _HostEvent()
+
+    def init_kw(self):
+        return {"backend": "gloo"}
+
+
 def percentile(xs, q):
     xs = sorted(xs)
     if not xs:
@@ -254,39 +311,44 @@ def main():
         except ValueError as e:
             print("bench.py: --global-batch: %s" % e, file=sys.stderr)
             sys.exit(2)
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    _cabi.lib()   # no HIP library -> fail loudly, never a fallback
+    stub = os.environ.get("S4G_BENCH_BACKEND") == "gloo"      # tests only: see the docstring
+    hw = (_HostRank if stub else _HipRank)(torch, local_rank)
+    dev = hw.dev
+    if not stub:
+        _cabi.lib()   # no HIP library -> fail loudly, never a fallback
     # S4G_BENCH_FORCE_DIST=1: take the RCCL path (init, all-gather, barrier, max-reduce)
     # even with one rank, so the multi-GPU code can be exercised on a 1-GPU box
     use_dist = world > 1 or (os.environ.get("S4G_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        dist.init_process_group(**hw.init_kw())
 
     cfg = S4GConfig()
-    torch.manual_seed(20260101)
-    net = build_pointnet2_cls(cfg)
-    randomize_bn_(net, 20260102)
-    net = net.to(dev).eval()
-
     impl = args.impl
     fused_cls = None
-    if impl in ("auto", "fused"):
-        try:
-            from s4g_release_amd.fused import FusedPointNet2 as fused_cls
-        except ImportError:
-            if impl == "fused":
-                raise
-    if fused_cls is not None:
-        runner = fused_cls(net, precision=args.precision)
-        impl = "fused"
+    if stub:
+        from tests.bench_stub import StubRunner
+        net, runner, impl = None, StubRunner(), "stub"
+        args.no_extras = args.no_cpu_baseline = True
     else:
-        runner = net
-        impl = "modules"
+        torch.manual_seed(20260101)
+        net = build_pointnet2_cls(cfg)
+        randomize_bn_(net, 20260102)
+        net = net.to(dev).eval()
+        if impl in ("auto", "fused"):
+            try:
+                from s4g_release_amd.fused import FusedPointNet2 as fused_cls
+            except ImportError:
+                if impl == "fused":
+                    raise
+        if fused_cls is not None:
+            runner = fused_cls(net, precision=args.precision)
+            impl = "fused"
+        else:
+            runner = net
+            impl = "modules"
     precision = getattr(runner, "precision", "library")
-    if impl != "fused":
+    if impl not in ("fused", "stub"):
         args.timer_every = 1      # only the fast path announces its passes to the timers
 
     B = args.batch
@@ -296,7 +358,7 @@ def main():
     batch = {"scene_points": pts}
     heads = ("score", "frame_R", "frame_t", "movable_logits")
 
-    pipelined = impl == "fused" and not args.no_pipeline
+    pipelined = impl in ("fused", "stub") and not args.no_pipeline
 
     # the per-batch collective: packed head outputs (21 channels per point) or, with --gather poses,
     # the K best decoded grasp frames per scene, on its own stream
@@ -326,9 +388,7 @@ def main():
 
         def mark():
             if marks is not None:
-                ev = torch.cuda.Event(enable_timing=True)
-                ev.record()
-                marks.append(ev)
+                marks.append(hw.event())
         if n <= 0:
             return
         with torch.no_grad():
@@ -350,11 +410,11 @@ def main():
     def _fence(collective=True):
         """collective=False: the rank-0-only probes after the headline region -- the other ranks have left,
         a barrier there would wait for peers that never come."""
-        torch.cuda.synchronize()
+        hw.sync()
         if use_dist and collective:
             assert not solo[0], "collective fence inside a rank-0-only leg"
             dist.barrier()
-            torch.cuda.synchronize()
+            hw.sync()
 
     def timed_region(steps, warmup, collective=True, timers=True, **kw):
         """`warmup` untimed + EXACTLY `steps` timed passes between fences -> (seconds, step_ms, summary,
@@ -366,8 +426,7 @@ def main():
         F.OpTimer.reset(enabled=timers, every=args.timer_every)
         fence()
         marks = []
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev0.record()
+        ev0 = hw.event()
         t0 = time.perf_counter()
         run_steps(steps, marks=marks, **kw)
         fence()
@@ -385,7 +444,14 @@ def main():
 
     # who runs what (one all_gather_object, outside the timed region): world, communicator size as the
     # collective library reports it, every rank's scene range and device -- checked to tile the global batch
-    shards = sdist.shard_report(scene_ids, world * B, torch.cuda.get_device_name(dev) + " cuda:%d" % local_rank)
+    shards = sdist.shard_report(scene_ids, world * B, hw.name)
+    if gather is not None:
+        # one gathered batch checked on EVERY rank before anything is timed: block r of the gathered tensor must
+        # carry rank r's checksum (exchanged through all_gather_object) and this rank's block must equal what it
+        # computed, bit for bit -- the first real N > 1 run verifies its data path, not only its shard table
+        with torch.no_grad():
+            shards["gather_check"] = sdist.gather_check(gather, runner(batch), pts)
+        hw.sync()
 
     elapsed, step_ms, summary, timed_passes = timed_region(args.steps, args.warmup)
     if use_dist:
@@ -607,7 +673,10 @@ def main():
             del mix_batch
 
     tb, src, why = load_traffic("contractions[step,B=%d,N=%d,precision=%s]" % (B, N, precision))
-    if roofline_dense is None:
+    if stub:
+        roofline_dense = {"kernel": None, "bound": "mfma", "achieved": None, "peak": BF16_MFMA_PEAK_TF,
+                          "unit": "TFLOP/s", "frac": None, "note": "test mode: no kernel ran"}
+    elif roofline_dense is None:
         dense_tf = GFLOP_PER_SCENE * value / world / 1e3
         roofline_dense = {"kernel": "whole forward (library GEMMs), dense flops / wall time",
                           "bound": "mfma", "achieved": round(dense_tf, 2),
@@ -676,7 +745,8 @@ def main():
     if gather is None:
         collective = {"op": None, "note": "single process: no collective"}
     else:
-        collective = {"op": "all_gather_into_tensor (RCCL)", "payload": args.gather,
+        collective = {"op": "all_gather_into_tensor (%s)" % ("RCCL" if hw.backend == "nccl" else hw.backend),
+                      "payload": args.gather,
                       "payload_bytes_per_rank_per_step": int(gather.payload_bytes),
                       "stream": gather.last_stream,
                       "note": "issued on a side stream behind an event of the collecting stream; the next batch's "
@@ -684,12 +754,13 @@ def main():
     payload = ("all-gather of 21 ch/point" if args.gather == "heads" else
                "all-gather of the %d best decoded grasp frames per scene" % args.num_poses)
     line = {
+        **({"test_mode": hw.test_mode} if hw.test_mode else {}),
         "metric": "scenes/sec (25.6k-pt clouds) end-to-end grasp inference",
         "value": round(value, 3), "unit": "scenes/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
         "dtype": {"bf16": "bf16", "f16x2": "f32 (f16x2 split)", "bf16x3": "f32 (bf16x3 split)"}.get(precision, "f32"),
-        "data": "synthetic",
+        "data": "synthetic" if not stub else "synthetic clouds, stub outputs (test mode)",
         "config": {"workload": "S4G PN2_CLS forward (3 SA + 3 FP + 4 heads), %d scenes/GPU/step, "
                                "%d-pt %s clouds, %s, impl=%s%s" % (B, args.points, args.variant, arith,
                                                                    impl, pipe_label),

@@ -46,8 +46,10 @@ extern "C" {
  * 7: s4g_fps_gather_ex_i32, s4g_fps_prefix_check_f32, s4g_fps_prepass_f32 (no layout change).
  * 8: s4g_group_rel_xyz_unique_i32 and the seg4 / seg_rows fields of s4g_gemm_desc_t (the first SA level
  *    contracts a centroid's distinct rows only); out2 / ldc2 / split_n / out_amax2 (two layers that read the
- *    same tensor as one launch); the operators in double (*_f64); s4g_build_variants. */
-#define S4G_ABI_VERSION 8
+ *    same tensor as one launch); the operators in double (*_f64); s4g_build_variants.
+ * 9: s4g_heads_desc_t.out_batch_stride (the four heads written as channel slices of one packed
+ *    (B, 21, N) tensor: the all-gather payload of the multi-GPU path without a packing copy). */
+#define S4G_ABI_VERSION 9
 
 /* ---------------------------------------------------------------------------
  * Environment knobs (round 4: the complete list; everything else that used to be read from the
@@ -432,6 +434,11 @@ typedef struct s4g_heads_desc {
   const float *pre_lbias;    /* C */
   const float *pre_a_amax2;  /* per-scene maxima of pre_dense or NULL */
   int32_t pre_N2;
+  /* ABI >= 9, optional: floats between two consecutive scenes' blocks of EVERY out[h].  0 = each out[h] is
+   * its own contiguous (B, channels[h], N) tensor.  Non-zero (>= channels[h] N): the four heads are channel
+   * slices of ONE packed (B, C_total, N) tensor -- out[h] = packed + first_channel_h * N, out_batch_stride =
+   * C_total * N -- which is what the multi-GPU path all-gathers (dist.py), so no copy packs the outputs. */
+  int64_t out_batch_stride;
 } s4g_heads_desc_t;
 
 int s4g_heads_chain_f32(const s4g_heads_desc_t *desc, s4g_stream_t stream);

@@ -47,6 +47,7 @@ struct HeadsParams {
   const float* wsc[5];     // per-channel inverse weight scales (PL == 2)
   float* out[4];
   int ch[4];
+  long long obs[4];        // floats between two scenes' blocks of out[h] (ch[h] * N, or the packed tensor's C_total * N)
   int sigmoid_head;
   const float* a_amax;     // per-scene maxima of X (PL == 2); PRE: of the sparse features
   float a_floor;
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
       const int row = p0 + wv * 32 + li;
       const int b = row / p.N, pt = row - b * p.N;
       const int nch = p.ch[g];
-      float* __restrict__ base = p.out[g] + (size_t)b * nch * p.N + pt;
+      float* __restrict__ base = p.out[g] + (size_t)b * (size_t)p.obs[g] + pt;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 sc4 = *reinterpret_cast<const float4*>(epi_s + 8 * j + 4 * lh);
@@ -444,6 +445,8 @@ extern "C" int s4g_heads_chain_f32(const s4g_heads_desc_t* d, s4g_stream_t strea
     if (!d->out[h] || d->channels[h] <= 0 || d->channels[h] > 32) return S4G_EINVAL;
     p.out[h] = d->out[h];
     p.ch[h] = d->channels[h];
+    if (d->out_batch_stride != 0 && d->out_batch_stride < (int64_t)d->channels[h] * d->N) return S4G_EINVAL;
+    p.obs[h] = d->out_batch_stride != 0 ? (long long)d->out_batch_stride : (long long)d->channels[h] * d->N;
   }
   p.sigmoid_head = d->sigmoid_head;
   p.a_amax = d->a_amax;

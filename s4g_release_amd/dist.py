@@ -42,8 +42,15 @@ def shard_range(total, rank, world):
 
 
 def pack_outputs(pred):
-    """dict of (B, C_h, N) -> one contiguous (B, sum C_h, N) tensor + channel splits."""
+    """dict of (B, C_h, N) -> one contiguous (B, sum C_h, N) tensor + channel splits.  The fast path's
+    `fused.PackedPred` already IS that tensor (the heads launch wrote the four outputs as its channel
+    slices): it is returned as it stands, no copy; any other dict is concatenated."""
     chans = [pred[k].shape[1] for k in HEADS]
+    packed = getattr(pred, "packed", None)
+    if (packed is not None and packed.is_contiguous() and packed.shape[1] == sum(chans) and
+            all(pred[k].data_ptr() == packed.data_ptr() + 4 * packed.shape[2] * c0
+                for k, c0 in zip(HEADS, [sum(chans[:i]) for i in range(len(chans))]))):
+        return packed, chans
     return torch.cat([pred[k] for k in HEADS], dim=1).contiguous(), chans
 
 
@@ -124,12 +131,22 @@ class OutputGather:
         self.last_stream = "caller"
         self.payload_bytes = 0
 
+    def local_payload(self, pred, scene_points=None):
+        """This rank's contribution as a list of tensors, in the order of `as_list(gathered)`."""
+        if self.mode == "poses":
+            return list(self.decode(pred, scene_points))
+        return [pred[k] for k in HEADS]
+
+    @staticmethod
+    def as_list(gathered):
+        return [gathered[k] for k in HEADS] if isinstance(gathered, dict) else list(gathered)
+
     def _collect(self, pred, scene_points):
         if self.mode == "poses":
             H, score, index = self.decode(pred, scene_points)
             self.payload_bytes = H.shape[0] * H.shape[1] * 18 * 4
             return all_gather_poses(H, score, index, self.group)
-        self.payload_bytes = sum(v.numel() * v.element_size() for v in pred.values())
+        self.payload_bytes = sum(pred[k].numel() * pred[k].element_size() for k in HEADS)
         return all_gather_outputs(pred, self.group)
 
     def __call__(self, pred, scene_points=None):
@@ -177,6 +194,9 @@ def shard_report(scene_ids, global_batch, device_name="", group=None):
         backend = dist.get_backend(group)
     else:
         comm, rows, backend = 1, [mine], None
+    if any(r is None for r in rows):
+        raise RuntimeError("shard_report: all_gather_object returned %d of %d rows"
+                           % (sum(r is not None for r in rows), comm))
     rows = sorted(rows, key=lambda r: r["rank"])
     if [r["rank"] for r in rows] != list(range(comm)):
         raise RuntimeError("shard_report: ranks %s of a communicator of %d" % ([r["rank"] for r in rows], comm))
@@ -187,5 +207,52 @@ def shard_report(scene_ids, global_batch, device_name="", group=None):
         edge = r["scenes"][1]
     if edge != global_batch:
         raise RuntimeError("shard_report: the ranks cover %d scenes of a global batch of %d" % (edge, global_batch))
-    return {"world": comm, "communicator_size": comm, "backend": backend, "global_batch": int(global_batch),
-            "per_rank": rows}
+    # `world`: the launcher's count (torchrun's WORLD_SIZE; 1 without a launcher); `communicator_size`: what
+    # the collective library's communicator reports; `rows_gathered`: the rows the collective actually
+    # returned.  Three sources, so their agreement (asserted by bench.py's tests) says something.
+    return {"world": int(os.environ.get("WORLD_SIZE", "1")) if group is None else comm,
+            "communicator_size": comm, "rows_gathered": len(rows), "backend": backend,
+            "global_batch": int(global_batch), "per_rank": rows}
+
+
+def _bits_checksum(tensors):
+    """Order-free exact checksum of a list of tensors: the int64 sum of their 32-bit patterns (int64 tensors:
+    of their values).  Equal data -> equal checksum whatever kernel or blocking summed it."""
+    total = 0
+    for t in tensors:
+        t = t.contiguous()
+        v = t if t.dtype == torch.int64 else t.view(torch.int32).to(torch.int64)
+        total += int(v.sum().item())
+    return total & 0xFFFFFFFFFFFFFFFF
+
+
+def gather_check(gather, pred, scene_points=None, group=None):
+    """Verify ONE gathered batch on every rank (bench.py runs it before the timed region; world-2 / -8 gloo tests
+    run it in the container): (1) this rank's block of the gathered tensors equals what the rank computed, bit for
+    bit; (2) block r carries the checksum rank r announced for its own payload (`all_gather_object`), for every r --
+    i.e. the collective put every rank's data where `unpack` expects it.  Raises RuntimeError on a mismatch,
+    returns a summary for the bench line."""
+    local = gather.local_payload(pred, scene_points)
+    out = gather.as_list(gather(pred, scene_points))
+    if dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    else:
+        world, rank = 1, 0
+    per = local[0].shape[0]
+    for lt, gt in zip(local, out):
+        if gt.shape[0] != world * per:
+            raise RuntimeError("gather_check: gathered %d rows for %d ranks x %d" % (gt.shape[0], world, per))
+        if not torch.equal(gt[rank * per:(rank + 1) * per], lt):
+            raise RuntimeError("gather_check: rank %d's own block changed in the all-gather" % rank)
+    mine = _bits_checksum(local)
+    sums = [mine]
+    if dist.is_initialized():
+        sums = [None] * world
+        dist.all_gather_object(sums, mine, group=group)
+    for r in range(world):
+        got = _bits_checksum([gt[r * per:(r + 1) * per] for gt in out])
+        if got != sums[r]:
+            raise RuntimeError("gather_check: block %d of the gathered batch does not carry rank %d's data "
+                               "(checksum %x, announced %x)" % (r, r, got, sums[r]))
+    return {"blocks_verified": world, "own_block_bit_identical": True, "scenes_per_block": int(per),
+            "payload": gather.mode, "checksum_rank0": "%016x" % sums[0]}

@@ -176,6 +176,9 @@ class FusedPointNet2:
         self.merge_shared = os.environ.get("S4G_MERGE_SHARED", "1") != "0"
         self.fp_chain_next = os.environ.get("S4G_FP_CHAIN_NEXT", "1") != "0"
         self.fps_prefix = os.environ.get("S4G_FPS_PREFIX", "1") != "0"
+        # the four head tensors as channel slices of ONE (B, 21, N) tensor (`PackedPred.packed`: the payload of
+        # the multi-GPU all-gather, dist.py, without a packing copy); S4G_PACKED_OUT=0: four tensors of their own
+        self.packed_out = os.environ.get("S4G_PACKED_OUT", "1") != "0"
         p = next(net.parameters())
         if not p.is_cuda:
             raise RuntimeError("FusedPointNet2 needs the model on a HIP device (no CPU fallback)")
@@ -419,6 +422,8 @@ class FusedPointNet2:
         for h, o in enumerate(outs):
             d.out[h] = o.data_ptr()
             d.channels[h] = self.head_channels[h]
+            if o.stride(0) != self.head_channels[h] * N0:    # channel slices of the packed (B, 21, N) tensor
+                d.out_batch_stride = o.stride(0)
         d.sigmoid_head = 3
         d.a_amax = None if x_amax is None else x_amax.data_ptr()
         d.a_amax_floor = 0.0 if pre is None else pre["a_amax_floor"]
@@ -825,9 +830,9 @@ class FusedPointNet2:
         x, x_amax = sparse_feat, sparse_amax
         names = ("score", "frame_R", "frame_t", "movable_logits")
         if self.heads_fused is not None and (heads_pre is not None or x.shape[1] == 256):
-            outs = [torch.empty((B, c, N0), dtype=torch.float32, device=dev) for c in self.head_channels]
+            packed, outs = self._head_outputs(B, N0, dev)
             self._heads(x, x_amax, outs, B, N0, pre=heads_pre)
-            return dict(zip(names, outs))
+            return PackedPred(zip(names, outs), packed=packed)
         l0 = self.head_layers[0]
         if not heads0_fused:
             h = torch.empty((P, l0.cout), dtype=torch.float32, device=dev)
@@ -857,17 +862,29 @@ class FusedPointNet2:
             x, x_amax = h, h_amax
             l += 3 if l3 is not None else (2 if l2 is not None else 1)
         names = ("score", "frame_R", "frame_t", "movable_logits")
-        outs = [torch.empty((B, c, N0), dtype=torch.float32, device=dev)
-                for c in self.head_channels]
+        packed, outs = self._head_outputs(B, N0, dev)
         starts = [0]
         for c in self.head_channels:
             starts.append(starts[-1] + c)
-        cf_ptr = (_fp * 4)(*[o.data_ptr() for o in outs])
-        cf_start = (_i32 * 5)(*starts)
+        if packed is not None:
+            # the channel-first epilogue addresses head h as base_h + (b ch_h + c) N: the packed tensor is ONE
+            # head of sum(ch) channels to it (the sigmoid boundary is a channel number either way)
+            cf_ptr = (_fp * 4)(*[packed.data_ptr()] * 4)
+            cf_start = (_i32 * 5)(0, *[starts[-1]] * 4)
+        else:
+            cf_ptr = (_fp * 4)(*[o.data_ptr() for o in outs])
+            cf_start = (_i32 * 5)(*starts)
         self._gemm("heads.logits", self.logit_layer, P, LOAD_PLAIN, EPI_CF, relu=False, A=x,
                    lda=x.shape[1], cf_ptr=cf_ptr, cf_start=cf_start,
                    cf_sigmoid_from=self.sigmoid_from, cf_N=N0, a_amax=x_amax)
-        return dict(zip(names, outs))
+        return PackedPred(zip(names, outs), packed=packed)
+
+    def _head_outputs(self, B, N0, dev):
+        """(packed (B, sum c_h, N) tensor or None, the four (B, c_h, N) head tensors -- its channel slices)."""
+        if not self.packed_out:
+            return None, [torch.empty((B, c, N0), dtype=torch.float32, device=dev) for c in self.head_channels]
+        packed = torch.empty((B, sum(self.head_channels), N0), dtype=torch.float32, device=dev)
+        return packed, list(packed.split(self.head_channels, dim=1))
 
     @torch.no_grad()
     def submit(self, data_batch):
@@ -941,6 +958,17 @@ class FusedPointNet2:
                     inter["sa%d_rows" % li] = rel[2]
             return pred, inter
         return pred
+
+
+class PackedPred(dict):
+    """The forward's output dict (`PointNet2_tcls.py:142-147`: score / frame_R / frame_t / movable_logits).  On the
+    fast path the four tensors are channel slices of `packed`, ONE (B, 21, N) tensor in the head order of
+    `dist.HEADS` that the heads launch wrote directly -- `dist.pack_outputs` hands it to the all-gather as it
+    is.  `packed` is None when the tensors are separate allocations (S4G_PACKED_OUT=0)."""
+
+    def __init__(self, items=(), packed=None):
+        super().__init__(items)
+        self.packed = packed
 
 
 class GraphedForward:

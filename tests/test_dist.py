@@ -204,3 +204,75 @@ def test_uneven_batch_is_rejected():
                 um.patch.object(dist, "get_world_size", return_value=4), \
                 um.patch.object(dist, "get_rank", return_value=0):
             sdist.sharded_forward(_fake_runner, torch.randn(6, 3, 5))
+
+
+def test_pack_outputs_hands_a_packed_pred_over_without_a_copy():
+    """The fast path's heads launch writes the four outputs as channel slices of one (B, 21, N) tensor
+    (`fused.PackedPred`): `pack_outputs` must return that tensor itself; any other dict is concatenated."""
+    from s4g_release_amd.fused import PackedPred
+    packed = torch.randn(3, 21, 11)
+    pred = PackedPred(zip(sdist.HEADS, packed.split([3, 9, 4, 5], dim=1)), packed=packed)
+    out, chans = sdist.pack_outputs(pred)
+    assert out.data_ptr() == packed.data_ptr() and chans == [3, 9, 4, 5]
+    plain = {k: v.clone() for k, v in pred.items()}
+    out2, _ = sdist.pack_outputs(plain)
+    assert out2.data_ptr() != packed.data_ptr() and torch.equal(out2, packed)
+    # a PackedPred whose slices were replaced is not trusted
+    pred["score"] = pred["score"].clone()
+    out3, _ = sdist.pack_outputs(pred)
+    assert out3.data_ptr() != packed.data_ptr() and torch.equal(out3, packed)
+
+
+def test_gather_check_passes_a_faithful_gather_and_refuses_a_corrupted_one():
+    pred = _fake_runner({"scene_points": torch.randn(4, 3, 9)})
+    g = sdist.OutputGather("heads")
+    rep = sdist.gather_check(g, pred)
+    assert rep["blocks_verified"] == 1 and rep["own_block_bit_identical"] and rep["scenes_per_block"] == 4
+
+    class Corrupt(sdist.OutputGather):
+        def __call__(self, pred, scene_points=None):
+            out = super().__call__(pred, scene_points)
+            out = {k: v.clone() for k, v in out.items()}
+            out["frame_t"][2, 1, 3] += 1.0
+            return out
+    with pytest.raises(RuntimeError, match="own block changed"):
+        sdist.gather_check(Corrupt("heads"), pred)
+
+
+def _gather_check_worker(rank, world, port, swap, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sdist.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(100 + rank)
+    pts = torch.randn(2, 3, 17, generator=g)
+    pred = _fake_runner({"scene_points": pts})
+
+    class Swapped(sdist.OutputGather):       # a collective that delivers the OTHER ranks' blocks rotated
+        def __call__(self, pred, scene_points=None):
+            out = super().__call__(pred, scene_points)
+            per = pred["score"].shape[0]
+            res = {}
+            for k, v in out.items():
+                blocks = list(v.split(per, dim=0))
+                me = dist.get_rank()
+                others = [i for i in range(len(blocks)) if i != me]
+                rot = others[1:] + others[:1]
+                new = list(blocks)
+                for dst, src in zip(others, rot):
+                    new[dst] = blocks[src]
+                res[k] = torch.cat(new, dim=0)
+            return res
+    try:
+        rep = sdist.gather_check((Swapped if swap else sdist.OutputGather)("heads"), pred)
+        res = ("ok", rep["blocks_verified"])
+    except RuntimeError as e:
+        res = ("refused", str(e)[:120])
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, res))
+
+
+def test_gather_check_world3_catches_blocks_delivered_in_the_wrong_place():
+    assert [r[1] for r in _run_world(_gather_check_worker, 3, False)] == [("ok", 3)] * 3
+    res = _run_world(_gather_check_worker, 3, True)
+    assert all(r[1][0] == "refused" and "does not carry rank" in r[1][1] for r in res), res
