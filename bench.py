@@ -518,7 +518,8 @@ def main():
         with torch.no_grad():
             pred = runner(batch)
         pin = pts_host.pin_memory()
-        outs_host = [torch.empty(pred[k].shape, dtype=pred[k].dtype).pin_memory() for k in heads]
+        d2h_src = [pred.packed] if getattr(pred, "packed", None) is not None else [pred[k] for k in heads]
+        outs_host = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in d2h_src]
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         h2d = d2h = 0.0
         for rep in range(4):
@@ -526,8 +527,8 @@ def main():
             e[0].record()
             pts.copy_(pin, non_blocking=True)
             e[1].record()
-            for k, o in zip(heads, outs_host):
-                o.copy_(pred[k], non_blocking=True)
+            for t, o in zip(d2h_src, outs_host):
+                o.copy_(t, non_blocking=True)
             e[2].record()
             torch.cuda.synchronize()
             if rep:
@@ -535,7 +536,7 @@ def main():
                 d2h += e[1].elapsed_time(e[2]) / 3
         io = {"h2d_ms_per_step": round(h2d, 4), "h2d_bytes": int(pts.numel() * 4),
               "d2h_ms_per_step": round(d2h, 4), "d2h_bytes": int(sum(o.numel() for o in outs_host) * 4),
-              "note": "pinned host buffers, one step's clouds in / four head tensors out; not part of `value`"}
+              "note": "pinned host buffers, one step's clouds in / the packed (B, 21, N) head outputs out; not part of `value`"}
 
         # ---- the contraction launches WITHOUT the next batches' geometry beside them: the same pipelined loop with
         # the coordinate-only operators answered from a cache (tools/geo_cost.py's trick; the tensors are the same, the

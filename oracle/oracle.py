@@ -24,8 +24,11 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libs4g_oracle.so")
+# S4G_ORACLE_LIB (tests/test_oracle_sanitizers.py only): another build of the same source, e.g. the
+# AddressSanitizer / UBSan library `make -C oracle asan` produces
+_LIB_PATH = os.environ.get("S4G_ORACLE_LIB") or os.path.join(_HERE, "libs4g_oracle.so")
 _lib = None
+_double = False      # see double_dispatch
 
 _f32p = ctypes.POINTER(ctypes.c_float)
 _f64p = ctypes.POINTER(ctypes.c_double)
@@ -36,6 +39,8 @@ _i64 = ctypes.c_int64
 def build(force=False):
     """Compile the C restatement with gcc (no GPU needed)."""
     src = os.path.join(_HERE, "s4g_oracle.c")
+    if os.environ.get("S4G_ORACLE_LIB"):
+        return _LIB_PATH            # the caller built it
     if (not force and os.path.exists(_LIB_PATH)
             and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
         return _LIB_PATH
@@ -80,10 +85,41 @@ def lib():
     return _lib
 
 
-def _f32(a):
-    """float32, or float64 where the caller passes float64 (the operators' second dispatch case)."""
-    a = np.asarray(a)
-    return np.ascontiguousarray(a, dtype=np.float64 if a.dtype == np.float64 else np.float32)
+class double_dispatch:
+    """Opt in to the operators' second dispatch case (`AT_DISPATCH_FLOATING_TYPES`: scalar_t = double):
+
+        with oracle.double_dispatch():
+            idx = oracle.fps(points_f64, 512)      # the -DS4G_ORACLE_F64 build, float64 in / out
+
+    Outside the block every floating array is coerced to float32 -- numpy's default float64 (`np.random.rand`,
+    `pts * 256 / 256`) must not silently select double-precision semantics in a checker.  Inside it, float64
+    arrays keep their type and a call that mixes float32 and float64 arrays raises TypeError."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _double
+        self.prev, _double = _double, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _double
+        _double = self.prev
+        return False
+
+
+def _f32(a, *more):
+    """float32 -- or, inside `double_dispatch()`, float64 where the caller passes float64.  With several arrays:
+    all coerced alike, mixed float32 / float64 refused."""
+    arrs = [np.asarray(x) for x in (a,) + more]
+    kinds = {x.dtype == np.float64 for x in arrs} if _double else {False}
+    if len(kinds) > 1:
+        raise TypeError("oracle: float32 and float64 arrays in one call (the reference's extension dispatches "
+                        "on ONE scalar type)")
+    dt = np.float64 if kinds == {True} else np.float32
+    out = [np.ascontiguousarray(x, dtype=dt) for x in arrs]
+    return out[0] if not more else out
 
 
 def _fn(name, a):
@@ -129,7 +165,7 @@ def fps_literal(points, num_centroids, fmad=0):
 
 
 def ball_query(points, centroids, radius, num_neighbours, fmad=0):
-    points, centroids = _f32(points), _f32(centroids)
+    points, centroids = _f32(points, centroids)
     B, _, N = points.shape
     M = centroids.shape[2]
     K = int(num_neighbours)
@@ -173,7 +209,7 @@ def gather_points(points, index):
 
 def three_nn(query_xyz, key_xyz, fmad=0):
     """Returns (index (B,N1,3) int64, SQUARED distance (B,N1,3) fp32)."""
-    q, k = _f32(query_xyz), _f32(key_xyz)
+    q, k = _f32(query_xyz, key_xyz)
     B, _, N1 = q.shape
     N2 = k.shape[2]
     idx = np.empty((B, N1, 3), dtype=np.int64)
@@ -193,7 +229,7 @@ def interp_weights(d2, eps=1e-10):
 
 
 def three_interpolate(feature, index, weight, fmad=0):
-    feature, index, weight = _f32(feature), _i64a(index), _f32(weight)
+    (feature, weight), index = _f32(feature, weight), _i64a(index)
     B, C, N2 = feature.shape
     N1 = index.shape[1]
     weight = weight.astype(feature.dtype, copy=False)
@@ -204,7 +240,7 @@ def three_interpolate(feature, index, weight, fmad=0):
 
 
 def three_interpolate_backward(grad_out, index, weight, num_inst):
-    grad_out, index, weight = _f32(grad_out), _i64a(index), _f32(weight)
+    (grad_out, weight), index = _f32(grad_out, weight), _i64a(index)
     B, C, N1 = grad_out.shape
     weight = weight.astype(grad_out.dtype, copy=False)
     gin = np.empty((B, C, num_inst), dtype=grad_out.dtype)

@@ -145,7 +145,9 @@ __global__ __launch_bounds__(GU_THREADS) void group_unique_scan_kernel(const int
   // 7/8 of the capacity on it keeps the plain layout -- centroid m at row m K, all K slots -- and says so with
   // rows[b] == M K; the contraction then takes its 64-row epilogue for that scene.  Decided per scene, from
   // the scene alone: results never depend on the rest of the batch.
-  if (total_s > (int)((int64_t)M * K / 8 * 7)) {
+  // ... and a compact layout whose tile-padded row count reaches M K would carry the plain layout's MARKER
+  // with compact row starts (possible below 2 048 rows, where 7/8 M K rounded up to a tile can be M K): plain too.
+  if (total_s > (int)((int64_t)M * K / 8 * 7) || (total_s + GU_TILE - 1) / GU_TILE * GU_TILE >= M * K) {
     for (int i = 0; i < per; ++i) {
       const int m = m0 + i;
       if (m < M) row_start[(size_t)b * M + m] = m * K;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(GU_THREADS) void group_unique_scan_kernel(const int
     return;
   }
   const int total = total_s;                                   // a multiple of 4
-  const int padded = (total + GU_TILE - 1) / GU_TILE * GU_TILE;   // < M K (a multiple of GU_TILE)
+  const int padded = (total + GU_TILE - 1) / GU_TILE * GU_TILE;   // < M K (checked above)
   if (t == 0) rows[b] = padded;
   const size_t base = (size_t)b * M * K;
   for (int r = total + t; r < padded; r += GU_THREADS) {

@@ -139,8 +139,15 @@ class _Layer:
 class FusedPointNet2:
     """Callable with the reference forward's signature: {"scene_points": (B,3,N)} -> dict."""
 
-    def __init__(self, net, precision=None):
-        """precision: "f16x2" (default; fp32 operands split into two scaled fp16
+    def __init__(self, net, precision=None, fold_only=False):
+        """net: `model.PointNet2` or the reference's own `PointNet2_tcls.PointNet2` instance (the attributes read
+        are the reference's: `sa_modules[i].{sampler, grouper.{radius, num_neighbours}, mlp, in_channels,
+        num_centroids}`, `fp_modules[i].{interpolator._eps, mlp}`, `mlp_seg / seg_logit / mlp_R / R_logit / mlp_t /
+        t_logit / mlp_movable / movable_logit[0]`, blocks with `.conv` / `.bn`: `PointNet2_tcls.py:56-95`;
+        tests/test_reference_dropin.py passes the reference's object).
+        fold_only: fold and pack the weights wherever the model lives and stop -- no device, no library; the
+        object cannot run a forward (tools / tests that compare packed weights on a host without a GPU).
+        precision: "f16x2" (default; fp32 operands split into two scaled fp16
         planes, three fp16 MFMA products, fp32 accumulate: the error of a plain fp32
         dot product), "bf16x3" (three bf16 planes, six products: ~2x tighter than
         fp32 round-off, half the speed), "fp32" (fp32-input MFMA, an exact fma
@@ -180,12 +187,14 @@ class FusedPointNet2:
         # the multi-GPU all-gather, dist.py, without a packing copy); S4G_PACKED_OUT=0: four tensors of their own
         self.packed_out = os.environ.get("S4G_PACKED_OUT", "1") != "0"
         p = next(net.parameters())
-        if not p.is_cuda:
+        self.fold_only = bool(fold_only)
+        if not p.is_cuda and not fold_only:
             raise RuntimeError("FusedPointNet2 needs the model on a HIP device (no CPU fallback)")
         if net.training:
             raise RuntimeError("FusedPointNet2 is inference-only: call net.eval() first")
         self.dev = p.device
-        _cabi.lib()
+        if not fold_only:
+            _cabi.lib()
         self.sa = []
         for sa in net.sa_modules:
             if sa.sampler is None or sa.grouper is None:
@@ -281,6 +290,38 @@ class FusedPointNet2:
                 wpad[h, :c] = lg.weight.detach().flatten(1)
                 bpad[h, :c] = lg.bias.detach()
             self.heads_fused = list(hl) + [_Layer(wpad, bpad, cl, groups=4)]
+
+    def packed_weights(self):
+        """{name: tensor} of every folded / split / fragment-ordered weight tensor the launches read -- what must
+        be equal for two networks to run the same forward (tests/test_reference_dropin.py)."""
+        out = {}
+
+        def put(prefix, layer):
+            for a in ("W", "bias", "W3", "Wh2", "w_inv_scale", "Wfrag", "Wfrag_bf16"):
+                t = getattr(layer, a)
+                if t is not None:
+                    out["%s.%s" % (prefix, a)] = t
+        for li, sa in enumerate(self.sa):
+            for l, layer in enumerate(sa["layers"]):
+                put("sa%d.%d" % (li, l), layer)
+            if sa["mlp1"] is not None:
+                out["sa%d.mlp1" % li] = sa["mlp1"]
+            if sa["pre"] is not None:
+                put("sa%d.pre" % li, sa["pre"]["la"])
+                out["sa%d.pre.w1" % li] = sa["pre"]["w1"]
+            out["sa%d.meta" % li] = torch.tensor([sa["M"], sa["K"], sa["cf"], sa["radius"], sa["mlp1_bound"],
+                                                  0.0 if sa["pre"] is None else sa["pre"]["bound"]],
+                                                 dtype=torch.float64)
+        for fi, fp in enumerate(self.fp):
+            for l, layer in enumerate(fp["layers"]):
+                put("fp%d.%d" % (fi, l), layer)
+            out["fp%d.meta" % fi] = torch.tensor([fp["eps"], fp["bias0_max"]], dtype=torch.float64)
+        for l, layer in enumerate(self.head_layers):
+            put("heads.%d" % l, layer)
+        put("heads.logits", self.logit_layer)
+        if self.heads_fused is not None:
+            put("heads.logits_padded", self.heads_fused[-1])
+        return out
 
     def _fusable(self, l1, l2, loader=LOAD_PLAIN, epi=EPI_STORE):
         """Two consecutive layers one launch can take: widths that chain (C -> C -> Cout2) and a
@@ -895,6 +936,8 @@ class FusedPointNet2:
         waits for it.  FPS is a latency chain on one CU per scene; submitting
         batch i+1 before collecting batch i lets that chain run underneath the
         previous batch's contractions instead of in front of its own."""
+        if self.fold_only:
+            raise RuntimeError("FusedPointNet2(fold_only=True) holds packed weights only: it cannot run a forward")
         xyz = _F._f32c(data_batch["scene_points"], "scene_points")
         if xyz.dim() != 3 or xyz.size(1) != 3:
             raise RuntimeError("scene_points must be (B, 3, N)")

@@ -84,6 +84,8 @@ def test_bench_under_torchrun_takes_the_rccl_path():
     assert c["stream"].startswith("side stream")
     sh = d["distributed"]     # the self-verifying shard table went through the communicator
     assert sh["backend"] == "nccl" and sh["communicator_size"] == 1 and sh["per_rank"][0]["scenes"] == [0, 16]
+    # one gathered batch was verified through RCCL before the timed region (own block bit-identical, checksums)
+    assert sh["gather_check"]["blocks_verified"] == 1 and sh["gather_check"]["own_block_bit_identical"]
     assert d["configs4"]["value"] > 0 and d["mixed_batch"]["value"] > 0     # rank-0-only legs: no collective inside
 
 

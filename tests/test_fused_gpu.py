@@ -1020,3 +1020,49 @@ def test_forward_recorded_as_a_hip_graph_replays_bit_identically(dev):
             assert torch.equal(ref[k], got[k]), k
     with pytest.raises(RuntimeError):
         g({"scene_points": a[:1]})
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "bf16", "fp32"])
+def test_heads_written_into_one_packed_tensor_bit_identical(dev, monkeypatch, precision):
+    """ABI 9 (`s4g_heads_desc_t.out_batch_stride`; the channel-first epilogue of the layer-by-layer heads takes the
+    packed tensor as one 21-channel head): the four outputs are channel slices of ONE (B, 21, N) tensor that
+    `dist.pack_outputs` hands to the all-gather without a copy -- every value bit-identical to four tensors of
+    their own (S4G_PACKED_OUT=0), at a batch of 3 (the batch stride matters) and a ragged last panel."""
+    from s4g_release_amd import dist as sdist, synth
+    from s4g_release_amd.fused import FusedPointNet2, PackedPred
+    from s4g_release_amd.model import S4GConfig, build_pointnet2_cls, randomize_bn_
+    torch.manual_seed(18)
+    net = randomize_bn_(build_pointnet2_cls(S4GConfig()), 19).to(dev).eval()
+    x = {"scene_points": torch.from_numpy(synth.make_batch([2, 3, 4], 25600 - 40)).to(dev)}
+    packed = FusedPointNet2(net, precision=precision)(x)
+    assert isinstance(packed, PackedPred) and packed.packed.shape == (3, 21, 25600 - 40)
+    out, chans = sdist.pack_outputs(packed)
+    assert out.data_ptr() == packed.packed.data_ptr() and chans == [3, 9, 4, 5]
+    c0 = 0
+    for k, c in zip(sdist.HEADS, chans):
+        assert packed[k].data_ptr() == packed.packed[:, c0:c0 + c].data_ptr() and packed[k].shape == (3, c, 25560)
+        c0 += c
+    monkeypatch.setenv("S4G_PACKED_OUT", "0")
+    plain = FusedPointNet2(net, precision=precision)(x)
+    assert plain.packed is None and all(v.is_contiguous() for v in plain.values())
+    torch.cuda.synchronize()
+    for k in sdist.HEADS:
+        assert torch.equal(plain[k], packed[k]), k
+    assert torch.equal(sdist.pack_outputs(plain)[0], packed.packed)
+
+
+def test_heads_desc_refuses_a_batch_stride_below_a_heads_own_block(dev):
+    import ctypes as C
+    from s4g_release_amd import _cabi
+    d = _cabi.HeadsDesc()
+    d.precision, d.P, d.N, d.ldx = 3, 128, 64, 256
+    d.C, d.H0, d.H1, d.H2, d.H3 = 256, 512, 256, 256, 128
+    buf = torch.zeros(1 << 16, device=dev)
+    d.X = buf.data_ptr()
+    for l in range(5):
+        d.W_frag[l] = d.bias[l] = d.w_inv_scale[l] = buf.data_ptr()
+    for h, c in enumerate((3, 9, 4, 5)):
+        d.out[h], d.channels[h] = buf.data_ptr(), c
+    d.a_amax_floor = 1.0
+    d.out_batch_stride = 8 * 64          # below frame_R's 9 channels x 64 points
+    assert _cabi.lib().s4g_heads_chain_f32(C.byref(d), None) == _cabi.S4G_EINVAL

@@ -9,6 +9,13 @@ from s4g_release_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _double_oracle(oracle):
+    """This module checks the operators' scalar_t = double case: the oracle's double build is opt-in."""
+    with oracle.double_dispatch():
+        yield
+
+
 def _t(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 

@@ -192,18 +192,25 @@ def test_oracle_double_build_is_the_same_restatement(oracle):
     """scalar_t = double (the same C source, -DS4G_ORACLE_F64): on inputs that are exactly representable in float
     and whose squared distances are too (a coarse lattice), both builds must give the same indices; the
     closed-form FPS and the literal 512-thread emulation agree in double as they do in float."""
-    rng = np.random.default_rng(3)
-    pts32 = (rng.integers(0, 8, size=(2, 3, 700)) * 0.125).astype(np.float32)
-    pts64 = pts32.astype(np.float64)
-    i32, i64 = oracle.fps(pts32, 200), oracle.fps(pts64, 200)
-    assert np.array_equal(i32, i64) and np.array_equal(oracle.fps_literal(pts64, 200), i64)
-    c32, c64 = oracle.gather_points(pts32, i32), oracle.gather_points(pts64, i64)
-    assert c64.dtype == np.float64 and np.array_equal(c32.astype(np.float64), c64)
-    b32, b64 = oracle.ball_query(pts32, c32, 0.3, 16), oracle.ball_query(pts64, c64, 0.3, 16)
-    assert np.array_equal(b32[0], b64[0]) and np.array_equal(b32[1], b64[1])
-    n32, n64 = oracle.three_nn(pts32, c32), oracle.three_nn(pts64, c64)
-    assert np.array_equal(n32[0], n64[0]) and n64[1].dtype == np.float64
-    assert np.array_equal(n32[1].astype(np.float64), n64[1])
-    # a generic cloud: double distances differ from float ones, the double FPS still equals its literal twin
-    q = rng.standard_normal((1, 3, 500))
-    assert np.array_equal(oracle.fps(q, 120), oracle.fps_literal(q, 120))
+    with oracle.double_dispatch():
+        rng = np.random.default_rng(3)
+        pts32 = (rng.integers(0, 8, size=(2, 3, 700)) * 0.125).astype(np.float32)
+        pts64 = pts32.astype(np.float64)
+        i32, i64 = oracle.fps(pts32, 200), oracle.fps(pts64, 200)
+        assert np.array_equal(i32, i64) and np.array_equal(oracle.fps_literal(pts64, 200), i64)
+        c32, c64 = oracle.gather_points(pts32, i32), oracle.gather_points(pts64, i64)
+        assert c64.dtype == np.float64 and np.array_equal(c32.astype(np.float64), c64)
+        b32, b64 = oracle.ball_query(pts32, c32, 0.3, 16), oracle.ball_query(pts64, c64, 0.3, 16)
+        assert np.array_equal(b32[0], b64[0]) and np.array_equal(b32[1], b64[1])
+        n32, n64 = oracle.three_nn(pts32, c32), oracle.three_nn(pts64, c64)
+        assert np.array_equal(n32[0], n64[0]) and n64[1].dtype == np.float64
+        assert np.array_equal(n32[1].astype(np.float64), n64[1])
+        # a generic cloud: double distances differ from float ones, the double FPS still equals its literal twin
+        q = rng.standard_normal((1, 3, 500))
+        assert np.array_equal(oracle.fps(q, 120), oracle.fps_literal(q, 120))
+        with pytest.raises(TypeError):            # one scalar type per call, as in the reference's dispatch
+            oracle.ball_query(pts64, c32, 0.3, 16)
+    # outside the opt-in block numpy's default float64 is coerced: a checker never silently runs in double
+    assert oracle.gather_points(pts64, i32).dtype == np.float32
+    assert np.array_equal(oracle.fps(pts64, 200), i32)
+    assert oracle.three_nn(pts64, c32)[1].dtype == np.float32

@@ -23,7 +23,9 @@ def _unique_reference(pts, ctr, gidx, cnt, K):
     rows = np.zeros((B,), np.int32)
     for b in range(B):
         total = sum((max(int(c), 1) + 3) // 4 * 4 for c in cnt[b])
-        dense = total > cap // 8 * 7        # a mostly-full scene keeps the plain layout: every slot, rows == M K
+        # a mostly-full scene keeps the plain layout: every slot, rows == M K -- and so does one whose tile-padded
+        # compact row count would REACH M K (rows == M K is the plain layout's marker; only below 2 048 rows)
+        dense = total > cap // 8 * 7 or (total + 255) // 256 * 256 >= cap
         r = 0
         for m in range(M):
             c4 = K if dense else (max(int(cnt[b, m]), 1) + 3) // 4 * 4
@@ -78,6 +80,72 @@ def test_group_rel_xyz_unique_layout(dev, variant, N, M, radius):
         assert np.isnan(got[hi:(b + 1) * M * K]).all()
     if variant == "uniform-box":
         assert cnt[0, 5] == 0 and r_start[0, 6] - r_start[0, 5] == 4     # the empty ball keeps four copies of point 0
+
+
+@pytest.mark.parametrize("M,counts", [(16, [64] * 12 + [32] * 4),      # 896 rows = 7/8 M K, padded = 1 024 = M K
+                                      (16, [64] * 11 + [32] * 4 + [60]),   # 892 rows
+                                      (4, [64, 64, 64, 17]),          # M K = 256: one tile, always plain
+                                      (4, [1, 1, 1, 1]),
+                                      (16, [20] * 16),                # 320 rows -> 512: compact stays legal
+                                      (32, [64] * 28 + [1] * 4)])     # 2 048 rows: 1 808 > 7/8: plain by the old rule
+def test_small_levels_never_mix_the_plain_marker_with_compact_rows(dev, M, counts):
+    """below 2 048 rows a compact scene's padded row count could equal M K -- the plain
+    layout's marker -- while its rows sat at compact offsets, so the contraction read centroid m at row m K and
+    found another centroid's rows.  Either layout must be self-consistent: rows == M K <=> row_start[m] == m K."""
+    from s4g_release_amd import _cabi
+    K, N, B = 64, 500, 2
+    rng = np.random.default_rng(M * 1000 + len(counts) + sum(counts))
+    pts = rng.standard_normal((B, 3, N)).astype(np.float32)
+    ctr = rng.standard_normal((B, 3, M)).astype(np.float32)
+    cnt = np.tile(np.asarray(counts, np.int64), (B, 1))
+    cnt[1] = cnt[1][::-1]
+    gidx = rng.integers(0, N, (B, M, K))
+    for b in range(B):
+        for m in range(M):
+            gidx[b, m, cnt[b, m]:] = gidx[b, m, 0]          # ball_query's padding
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+    d_pts, d_ctr, d_idx, d_cnt = t(pts, torch.float32), t(ctr, torch.float32), t(gidx, torch.int32), t(cnt, torch.int32)
+    rel = torch.full((B * M * K, 4), float("nan"), device=dev)
+    seg4 = torch.full((B * M * K // 4,), -2, dtype=torch.int32, device=dev)
+    row_start = torch.empty((B, M), dtype=torch.int32, device=dev)
+    rows = torch.empty((B,), dtype=torch.int32, device=dev)
+    rc = _cabi.lib().s4g_group_rel_xyz_unique_i32(d_pts.data_ptr(), d_ctr.data_ptr(), d_idx.data_ptr(), d_cnt.data_ptr(),
+                                                  B, N, M, K, rel.data_ptr(), seg4.data_ptr(), row_start.data_ptr(),
+                                                  rows.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _cabi.check(rc, "group_rel_xyz_unique")
+    torch.cuda.synchronize()
+    r_rel, r_seg, r_start, r_rows = _unique_reference(pts, ctr, gidx, cnt, K)
+    h_rows, h_start = rows.cpu().numpy(), row_start.cpu().numpy()
+    assert np.array_equal(h_rows, r_rows) and np.array_equal(h_start, r_start)
+    for b in range(B):
+        plain = h_rows[b] == M * K
+        assert plain == np.array_equal(h_start[b], np.arange(M) * K)
+        lo, hi = b * M * K, b * M * K + r_rows[b]
+        assert np.array_equal(rel.cpu().numpy()[lo:hi], r_rel[lo:hi])
+        assert np.array_equal(seg4.cpu().numpy()[lo // 4:hi // 4], r_seg[lo // 4:hi // 4])
+
+
+def test_model_with_a_tiny_first_level_matches_the_full_rows_model(dev, monkeypatch):
+    """The same hazard end to end: a first SA level of 16 centroids x 64 neighbours (M K = 1 024)."""
+    from s4g_release_amd import synth
+    from s4g_release_amd.fused import FusedPointNet2
+    from s4g_release_amd.model import PointNet2, randomize_bn_
+    torch.manual_seed(31)
+    net = PointNet2(score_classes=3, num_centroids=(16, 8, 4), radius=(0.16, 0.3, 0.6), num_neighbours=(64, 64, 64),
+                    sa_channels=((128, 128, 256), (256, 256, 512), (512, 512, 1024)),
+                    fp_channels=((1024, 1024), (512, 512), (256, 256, 256)), num_fp_neighbours=(3, 3, 3),
+                    seg_channels=(512, 256, 256, 128), num_removal_directions=5, dropout_prob=0.5)
+    net = randomize_bn_(net, 32).to(dev).eval()
+    pts = torch.from_numpy(synth.make_batch(list(range(12)), 2048)).to(dev)
+    a, ia = FusedPointNet2(net)({"scene_points": pts}, return_intermediates=True)
+    rows = ia.pop("sa0_rows", None)
+    monkeypatch.setenv("S4G_SA_UNIQUE", "0")
+    b, ib = FusedPointNet2(net)({"scene_points": pts}, return_intermediates=True)
+    for k in ia:
+        assert torch.equal(ia[k], ib[k]), k
+    for k in a:
+        err = (a[k] - b[k]).abs().max().item()
+        assert err < 2e-5 * max(1.0, b[k].abs().max().item()), (k, err, None if rows is None else rows.tolist())
 
 
 def test_unsupported_shapes_are_refused(dev):
