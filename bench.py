@@ -62,6 +62,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3      # fp32-in MFMA = fp32 vector peak
 BF16_MFMA_PEAK_TF = 2500.0     # dense bf16 / fp16 MFMA (no sparsity)
+# calibrated on this board (profiles/r05_mfma_ceiling.md, tools/micro/mfma_ceiling.hip): the product kernels' inner loop
+# (A fragments from LDS, W fragments through a register ring from L2, 2 row blocks per wave) on RANDOM fp16 operands
+# sustains 1 248 TFLOP/s at the clock the power governor allows (1.81 GHz, 1.29 kW); registers-only: 1 681; constant
+# operands: 2 436
+F16_MFMA_ATTAINABLE_TF = 1248.0
 GFLOP_PER_SCENE = 203.48       # SURVEY.md Appendix B (BN folded, 2*MAC), N = 25 600
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
 
@@ -284,6 +289,10 @@ def dense_roofline(summary, steps_timed, precision, world_note=""):
             "fp32_equivalent_vs_fp32_mfma_peak": round(dense_tf / FP32_MFMA_PEAK_TF, 4),
             "GFLOP_per_step_fp32_equivalent": round(gemm_flops / 1e9, 1), "ms_per_step": round(gemm_ms, 3),
             "timed_passes": steps_timed,
+            "attainable": {"TFLOPs": F16_MFMA_ATTAINABLE_TF, "of_peak": round(F16_MFMA_ATTAINABLE_TF / BF16_MFMA_PEAK_TF, 4),
+                           "source": "profiles/r05_mfma_ceiling.md: this loop (A from LDS, W from L2) on random fp16 "
+                                     "operands, hwmon 1.29 kW / 1.81 GHz; registers only 1 681 TF, constant operands 2 436"},
+            "frac_of_attainable": round(products * dense_tf / F16_MFMA_ATTAINABLE_TF, 4),
             "peak_note": "peak is the nominal 2.4 GHz figure; measured (profiles/r03_power_clock.md: hwmon power / "
                          "clock sensors while each kernel runs back to back) these kernels draw 1.24-1.40 kW of the "
                          "1.40 kW board cap and are clocked at 1.8-2.2 GHz"}, kernels

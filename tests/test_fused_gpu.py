@@ -768,8 +768,9 @@ def test_fused_model_small_golden(dev, precision):
     net = PointNet2(**GU.small_config(g))
     net.load_state_dict(GU.small_state_dict(g), strict=True)
     pred = _check_model(dev, g, net, g["points"], full=False, precision=precision)
+    assert pred.packed.is_contiguous()      # the four outputs are channel slices of one (B, 21, N) tensor (ABI 9)
     for k in ("score", "frame_R", "frame_t", "movable_logits"):
-        assert pred[k].is_contiguous()
+        assert all(pred[k][b].is_contiguous() for b in range(pred[k].shape[0]))     # what the reference's consumers index
         err = np.max(np.abs(pred[k].cpu().numpy() - g["out/" + k]))
         assert err < TOL, (k, err)
 
