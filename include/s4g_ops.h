@@ -68,6 +68,8 @@ extern "C" {
  *   S4G_INTERP_MODE=lane           three_interpolate: lane-per-point kernel instead of the LDS tile
  *   S4G_GEMM_SINGLE_CHAIN=0|1      plain single layers never / wherever supported on mlp_chain_kernel's first-layer
  *                                  form (default: where it measured faster: Cout >= 1024 or K >= 1024)
+ *   S4G_MLP1_MFMA=0                first SA level's 3 -> C layer on the vector ALU (the chain kernel's loader) instead of
+ *                                  one MFMA step inside the chain kernel (round 5; f16x2 form with rel_xyz4 records)
  *  measurement builds only (make HIPFLAGS_EXTRA=-DS4G_VARIANTS, s4g_build_variants() == 1):
  *   S4G_FPS_MODE=cluster|hybrid, S4G_BQ_MODE=cell (+ S4G_BQ_CELL_WGS), S4G_GEMM_RESIDENT=0|1
  *  read by the Python host side (s4g_release_amd/):

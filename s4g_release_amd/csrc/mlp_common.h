@@ -37,6 +37,21 @@ __device__ __forceinline__ void split_pair_h(float x0, float x1, float s, uint32
   l = ll;
 }
 
+// the same with a scale of its own per element (per-channel factors in an accumulator epilogue)
+__device__ __forceinline__ void split_pair_h2(float x0, float x1, float s0, float s1, uint32_t& h, uint32_t& l) {
+  uint32_t hh, ll;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hh) : "v"(x0), "v"(s0));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hh) : "v"(x1), "v"(s1));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ll) : "v"(x0), "v"(s0), "v"(hh));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ll) : "v"(x1), "v"(s1), "v"(hh));
+  h = hh;
+  l = ll;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// (a0 b0 + c0, a1 b1 + c1), each rounded once: one v_pk_fma_f32 (two fp32 FMAs per lane and issue slot)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 template <bool CLAMP>
 __device__ __forceinline__ void split2_h(const float4 v, float s, uint2& h, uint2& l) {
   if constexpr (CLAMP) {

@@ -65,7 +65,10 @@ constexpr int GM_LDS = 36;  // padded row stride (floats)
 constexpr int GM_THREADS = 256;
 
 enum { LOAD_PLAIN = 0, LOAD_GATHER = 1, LOAD_INTERP = 2, LOAD_GATHER_MLP1 = 3, LOAD_GATHER_ADD = 4,
-       LOAD_INTERP_ADD = 5 };
+       LOAD_INTERP_ADD = 5,
+       // internal (never in a descriptor): GATHER_MLP1 on pre-gathered rel_xyz4 records in the f16x2 chain kernel --
+       // the 3 -> C first layer runs on the matrix cores too (mlp_chain_kernel, "phase 0")
+       LOAD_REL_MLP1 = 6 };
 enum { EPI_STORE = 0, EPI_MAX = 1, EPI_CHANNEL_FIRST = 2 };
 
 struct GemmParams {
@@ -1095,7 +1098,9 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
   const int p0 = blockIdx.x * BM;
 
   constexpr bool ADD_BOUNDS = LOADER == LOAD_GATHER_ADD || LOADER == LOAD_INTERP_ADD;   // the loader SUMS its inputs
-  constexpr bool SEGMAX = LOADER == LOAD_GATHER_MLP1 && EPI2 == EPI_MAX;   // may run on distinct rows only (seg4)
+  constexpr bool MFMA0 = LOADER == LOAD_REL_MLP1;   // the xyz-only first layer as one 16-deep MFMA step (f16x2 form only)
+  static_assert(!MFMA0 || (PL == 2 && KC == 1), "phase 0 on the matrix cores: f16x2, one panel");
+  constexpr bool SEGMAX = (LOADER == LOAD_GATHER_MLP1 || MFMA0) && EPI2 == EPI_MAX;   // may run on distinct rows only (seg4)
   bool seg_scene = false;   // this tile's scene is in the distinct-row layout (a mostly-full scene keeps the plain one)
   if constexpr (SEGMAX) {
     // distinct-row form: a scene's rows end before its base + rps; the tiles behind them have nothing to do
@@ -1153,7 +1158,23 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
   // more than one panel deep: KC > 1)
   S4G_STAMP(0);
   ALoader<LOADER, RPT, RS> ld;
-  ld.init(p, p0, g, t);
+  // phase 0 on the matrix cores: this wave's rows' (xyz_j - ctr_m, 0) records and this lane's channel of the first
+  // layer, requested before anything waits (buffer loads: a row past P reads zeros)
+  float4 rv0[NRB];
+  float4 wv0 = f4zero();
+  if constexpr (MFMA0) {
+    const int rows_left = p.P - p0;
+    const __amdgpu_buffer_rsrc_t rrel = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float4*>(p.rel4 + p0), 0, (rows_left < BM ? rows_left : BM) * 16, 0x00020000);
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+      rv0[rb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                               rrel, ((t >> 6) / CW * WROWS + rb * 32 + (lane & 31)) * 16, 0, 0));
+    const int ch = (t >> 6) % CW * 64 + lane;
+    if (ch < p.Cin) wv0 = p.mlp1[ch];
+  } else {
+    ld.init(p, p0, g, t);
+  }
   S4G_STAMP(1);
   // activation scale of the loader's rows (per scene; a tile that straddles scenes joins their rows)
   float amax = PL == 2 ? p.a_amax_floor : 1.f;
@@ -1205,14 +1226,85 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
     }
   };
   // (64 loaded values per thread in flight at most: one round trip for the 2-block form, two for the 4-block one)
-  if (!(S4G_CHAIN_ABLATE & 16)) load_panel(0, std::integral_constant<int, (K / 32) / (NRB / 2)>{});
+  const uint16_t* a_lane = Ah + (wr * WROWS + li) * astr + 8 * lh;
+  float* epi_s = scr + wave * 128;
+  f32x16 acc[2][NRB];   // [32-channel block][32-row block], in every phase
+  if constexpr (MFMA0) {
+    // ---- phase 0: H0 = relu(W1 (rel, 1)) for this wave's WROWS rows x 64 channels as ONE 16-deep step of the
+    // f16x2 contraction (12 MFMAs) instead of 3 FMAs + ReLU + select per element on the vector ALU.
+    //   position operand: lane (li, lh) holds (rx, ry, rz, ONE) s_a at k = 8 lh .. 8 lh + 3 -- BOTH half-waves carry
+    //     the row's record, so the k = 0..3 and k = 8..11 slots are copies; ONE = the power of two above the wave's
+    //     largest |coordinate| (measured here: no bound is assumed), s_a ONE = 2^15
+    //   channel operand: lane = channel wc 64 + lane = block lh, column li: (wx, wy, wz, b / ONE) s_w at ITS
+    //     half's k slots and zeros in the other block's, so block cb's fragment is "mine where lh == cb, else 0" --
+    //     no lane exchange; s_w = the channel's own power-of-two scale (its largest entry in [2^14, 2^15))
+    // acc = s_a s_w (w . rel + b); the epilogue applies relu, then splits with f = sa / (s_a s_w) per channel.
+    float m = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(rv0[rb].x), fabsf(rv0[rb].y)), fabsf(rv0[rb].z)));
+    uint32_t ea = wave_max_u32(__float_as_uint(m)) >> 23;
+    ea = ea < 90u ? 90u : (ea > 240u ? 240u : ea);      // (ONE >= 2^-36: coordinates below that are zero to fp32 sums)
+    ea = __builtin_amdgcn_readfirstlane(ea);
+    const float s_a = __uint_as_float((268u - ea) << 23), inv_a = __uint_as_float((ea - 14u) << 23);
+    const float one = __uint_as_float((ea + 1u) << 23), inv_one = __uint_as_float((253u - ea) << 23);
+    const float bq = wv0.w * inv_one;
+    const float mw = fmaxf(fmaxf(fabsf(wv0.x), fabsf(wv0.y)), fmaxf(fabsf(wv0.z), fabsf(bq)));
+    uint32_t ew = __float_as_uint(mw) >> 23;
+    ew = ew < 15u ? 15u : (ew > 240u ? 240u : ew);
+    const float s_w = __uint_as_float((268u - ew) << 23);
+    epi_s[lane] = __uint_as_float((ew - 14u) << 23) * inv_a * sa;
+    uint32_t wh01, wl01, wh23, wl23;
+    split_pair_h(wv0.x, wv0.y, s_w, wh01, wl01);
+    split_pair_h(wv0.z, bq, s_w, wh23, wl23);
+    uint4 af0[NRB][2], bf0[2][2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      bf0[cb][0] = make_uint4(lh == cb ? wh01 : 0u, lh == cb ? wh23 : 0u, 0u, 0u);
+      bf0[cb][1] = make_uint4(lh == cb ? wl01 : 0u, lh == cb ? wl23 : 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      const float one_r = p0 + wr * WROWS + rb * 32 + li < p.P ? one : 0.f;
+      uint32_t h01, l01, h23, l23;
+      split_pair_h(rv0[rb].x, rv0[rb].y, s_a, h01, l01);
+      split_pair_h(rv0[rb].z, one_r, s_a, h23, l23);
+      af0[rb][0] = make_uint4(h01, h23, 0u, 0u);
+      af0[rb][1] = make_uint4(l01, l23, 0u, 0u);
+    }
+    f32x16 z16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z16[r] = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+        acc[cb][rb] = chain_mfma<PL>(bf0[cb][1], af0[rb][0], z16);
+        acc[cb][rb] = chain_mfma<PL>(bf0[cb][0], af0[rb][1], acc[cb][rb]);
+        acc[cb][rb] = chain_mfma<PL>(bf0[cb][0], af0[rb][0], acc[cb][rb]);
+      }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 f4 = *reinterpret_cast<const float4*>(epi_s + nb * 32 + 8 * j + 4 * lh);
+#pragma unroll
+        for (int pb = 0; pb < NRB; ++pb) {
+          uint16_t* dst = Ah + (wr * WROWS + pb * 32 + li) * astr + wc * 64 + nb * 32 + 8 * j + 4 * lh;
+          uint2 h, l;
+          split_pair_h2(fmaxf(acc[nb][pb][4 * j], 0.f), fmaxf(acc[nb][pb][4 * j + 1], 0.f), f4.x, f4.y, h.x, l.x);
+          split_pair_h2(fmaxf(acc[nb][pb][4 * j + 2], 0.f), fmaxf(acc[nb][pb][4 * j + 3], 0.f), f4.z, f4.w, h.y, l.y);
+          *reinterpret_cast<uint2*>(dst) = h;
+          *reinterpret_cast<uint2*>(dst + aplane) = l;
+        }
+      }
+  } else {
+    if (!(S4G_CHAIN_ABLATE & 16)) load_panel(0, std::integral_constant<int, (K / 32) / (NRB / 2)>{});
+  }
   S4G_STAMP(2);
   __syncthreads();
   S4G_STAMP(3);
 
-  const uint16_t* a_lane = Ah + (wr * WROWS + li) * astr + 8 * lh;
-  float* epi_s = scr + wave * 128;
-  f32x16 acc[2][NRB];   // [32-channel block][32-row block], in every phase
   auto zero_acc = [&]() {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1337,14 +1429,21 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
       const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
       const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-      for (int pb = 0; pb < NRB; ++pb)
+      for (int pb = 0; pb < NRB; ++pb) {
+        // two v_pk_fma_f32 per four values (each half rounded once, as __fmaf_rn), the tile maximum as max3s
+        const f32x2 x01 = pk_fma(f32x2{acc[nb][pb][4 * j], acc[nb][pb][4 * j + 1]}, f32x2{scv[0], scv[1]}, f32x2{bv[0], bv[1]});
+        const f32x2 x23 = pk_fma(f32x2{acc[nb][pb][4 * j + 2], acc[nb][pb][4 * j + 3]}, f32x2{scv[2], scv[3]}, f32x2{bv[2], bv[3]});
+        float x[4] = {x01.x, x01.y, x23.x, x23.y};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float x = __fmaf_rn(acc[nb][pb][4 * j + e], scv[e], bv[e]);
-          if (relu_ph) x = fmaxf(x, 0.f);
-          acc[nb][pb][4 * j + e] = x;
-          if constexpr (PL == 2) tmax = fmaxf(tmax, fabsf(x));
+          if (relu_ph) x[e] = fmaxf(x[e], 0.f);
+          acc[nb][pb][4 * j + e] = x[e];
         }
+        if constexpr (PL == 2) {
+          tmax = fmaxf(fmaxf(tmax, fabsf(x[0])), fabsf(x[1]));
+          tmax = fmaxf(fmaxf(tmax, fabsf(x[2])), fabsf(x[3]));
+        }
+      }
     }
   if constexpr (LOADER == LOAD_PLAIN && EPI2 == EPI_STORE) {
     if (!p.Wfrag2) {
@@ -1871,6 +1970,15 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
         (h2 && !d->w2_inv_scale) || !d->bias2 ||
         (store && (((d->ldc | d->c_coff | d->c_gcol) & 3) || ((uintptr_t)d->out & 15))))
       return S4G_EINVAL;
+    // the xyz-only first layer of an SA level on pre-gathered records: as one MFMA step inside the chain kernel
+    // (f16x2 form; S4G_MLP1_MFMA=0, read per launch: the vector-ALU loader, for tests and A/B runs)
+    if (h2 && d->loader == S4G_GEMM_LOAD_GATHER_MLP1 && d->rel_xyz4 && d->epilogue == S4G_GEMM_EPI_MAX &&
+        d->Kpad16 == d->Cout && d->Cin <= d->Cout && (c128 || c256)) {
+      const char* m0 = getenv("S4G_MLP1_MFMA");
+      if (!(m0 && m0[0] == '0'))
+        return c128 ? launch_mlp_chain<LOAD_REL_MLP1, EPI_MAX, 2, 1, 2>(p, d->groups, st)
+                    : launch_mlp_chain<LOAD_REL_MLP1, EPI_MAX, 1, 1, 2>(p, d->groups, st);
+    }
 #define S4G_FUSED2_CASE(L, E, R, KCH)                                                        \
   if (d->loader == L && (int)d->epilogue == (int)E && (c128 ? 2 : (c256 ? 1 : 8)) == R &&     \
       d->Kpad16 / d->Cout == KCH)                                                             \

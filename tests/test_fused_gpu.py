@@ -340,11 +340,15 @@ def test_model_with_and_without_pregathered_rows(dev, monkeypatch):
     net = net.to(dev).eval()
     pts = torch.from_numpy(synth.make_batch([5, 6], 25600)).to(dev)
     monkeypatch.setenv("S4G_SA_UNIQUE", "0")     # (the distinct-row form has its own tests: test_sa_unique_gpu.py)
+    mfma = FusedPointNet2(net)({"scene_points": pts})          # round 5: the 3 -> 128 layer on the matrix cores
+    monkeypatch.setenv("S4G_MLP1_MFMA", "0")     # the first layer on the vector ALU, as the index-following loader does
     a = FusedPointNet2(net)({"scene_points": pts})
     monkeypatch.setenv("S4G_REL_XYZ", "0")
     b = FusedPointNet2(net)({"scene_points": pts})
     for k in a:
         assert torch.equal(a[k], b[k]), k
+        err = (mfma[k] - a[k]).abs().max().item()              # the same layer as an f16x2 product: fp32-class, not bitwise
+        assert err < 2e-5 * max(1.0, a[k].abs().max().item()), (k, err)
 
 
 def _h2_second(W2):
@@ -486,6 +490,52 @@ def test_gemm_fused_layer_pair_mlp1_loader(dev):
     h = (A @ W.double().t() + b.double()).clamp_min(0)
     ref = (h @ W2.double().t() + b2.double()).clamp_min(0).view(B * M, K, Cout2).max(dim=1)[0]
     assert (out.double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,M,C,Cout2,scale,bias_scale", [(2, 23, 128, 256, 0.2, 1.0), (1, 23, 128, 256, 0.2, 1.0),
+                                                          (2, 9, 256, 512, 0.03, 1.0), (1, 8, 128, 128, 1e-6, 40.0),
+                                                          (1, 6, 128, 256, 300.0, 1e-3), (1, 4, 128, 256, 0.0, 1.0)])
+def test_chain_first_layer_on_the_matrix_cores(dev, monkeypatch, B, M, C, Cout2, scale, bias_scale):
+    """Round 5: with pre-gathered (xyz_j - ctr_m, 0) records the 3 -> C first layer of an SA level is ONE 16-deep MFMA
+    step inside the chain kernel (operands split into scaled fp16 planes like every other layer: the wave's measured
+    coordinate maximum and each channel's own weight scale) instead of 3 FMAs + ReLU per element in the loader.
+    Against float64 and against the vector-ALU loader (S4G_MLP1_MFMA=0); a ragged last tile (P % 128 != 0), tiny and
+    huge coordinates, large biases, all-zero records."""
+    g = torch.Generator(device="cpu").manual_seed(50 + M)
+    K = 64
+    P = B * M * K
+    rel4 = torch.zeros(P, 4)
+    rel4[:, :3] = (torch.rand(P, 3, generator=g) - 0.5) * 2 * scale
+    rel4[5, :3] = 0.0
+    rel4 = rel4.to(dev)
+    w1 = torch.randn(C, 4, generator=g)
+    w1[:, 3] *= bias_scale
+    w1[3] = 0.0                                # a dead channel
+    w1 = w1.to(dev)
+    W = (torch.randn(C, C, generator=g) / C ** 0.5).to(dev)
+    b = torch.randn(C, generator=g).to(dev)
+    W2 = (torch.randn(Cout2, C, generator=g) / C ** 0.5).to(dev)
+    b2 = torch.randn(Cout2, generator=g).to(dev)
+    k16, w3 = _w3(W)
+    bound = float((w1[:, :3].abs().sum(1) * max(scale, 1e-30) + w1[:, 3].abs()).max())
+    h2 = _h2(W, floor=bound)
+    frag2, inv2 = _h2_second(W2)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("S4G_MLP1_MFMA", mode)
+        out = torch.full((B * M, Cout2), float("nan"), device=dev)
+        _run(dict(loader=3, epilogue=1, groups=1, relu=1, P=P, Cin=C, Kpad=C, Cout=C, W=W, bias=b, rel_xyz4=rel4,
+                  N=999, M=M, K=K, mlp1_w=w1, out=out, ldc=Cout2, precision=3, Kpad16=k16, W_bf16x3=w3,
+                  W2_f16x2_frag=frag2, w2_inv_scale=inv2, bias2=b2, Cout2=Cout2, relu2=1, **h2), dev)
+        outs[mode] = out
+    A = (rel4[:, :3].double() @ w1[:, :3].double().t() + w1[:, 3].double()).clamp_min(0)
+    h = (A @ W.double().t() + b.double()).clamp_min(0)
+    ref = (h @ W2.double().t() + b2.double()).clamp_min(0).view(B * M, K, Cout2).max(dim=1)[0]
+    tol = 3e-5 * max(1.0, ref.abs().max().item())
+    e1 = (outs["1"].double() - ref).abs().max().item()
+    e0 = (outs["0"].double() - ref).abs().max().item()
+    assert torch.isfinite(outs["1"]).all() and e1 < tol and e0 < tol, (e1, e0, tol)
+    assert e1 < 4 * max(e0, 1e-7 * max(1.0, ref.abs().max().item())), (e1, e0)     # as accurate as the fp32 FMA chain
 
 
 def test_gemm_chain_supported_query_matches_dispatch(dev):
@@ -1066,4 +1116,4 @@ def test_heads_desc_refuses_a_batch_stride_below_a_heads_own_block(dev):
         d.out[h], d.channels[h] = buf.data_ptr(), c
     d.a_amax_floor = 1.0
     d.out_batch_stride = 8 * 64          # below frame_R's 9 channels x 64 points
-    assert _cabi.lib().s4g_heads_chain_f32(C.byref(d), None) == _cabi.S4G_EINVAL
+    assert _cabi.lib().s4g_heads_chain_f32(C.byref(d), None) == -1      # S4G_EINVAL
