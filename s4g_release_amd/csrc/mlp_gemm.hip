@@ -1046,7 +1046,7 @@ __device__ __forceinline__ void chain_keep_alive(const f32x16& v) { asm volatile
 __device__ unsigned long long g_chain_stamps[512 * 16];
 #define S4G_STAMP(i)                                                                       \
   do {                                                                                     \
-    const unsigned sb_ = blockIdx.x - gridDim.x / 2;   /* steady state: the middle of the grid */ \
+    const unsigned sb_ = gridDim.x >= 1024 ? blockIdx.x - gridDim.x / 2 : blockIdx.x;   /* steady state: the middle of the grid */ \
     if (threadIdx.x == 0 && sb_ < 512u && blockIdx.y == 0)                                 \
       g_chain_stamps[sb_ * 16 + (i)] = __builtin_amdgcn_s_memtime();                      \
   } while (0)
@@ -1095,12 +1095,13 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
-  const int p0 = blockIdx.x * BM;
 
   constexpr bool ADD_BOUNDS = LOADER == LOAD_GATHER_ADD || LOADER == LOAD_INTERP_ADD;   // the loader SUMS its inputs
   constexpr bool MFMA0 = LOADER == LOAD_REL_MLP1;   // the xyz-only first layer as one 16-deep MFMA step (f16x2 form only)
   static_assert(!MFMA0 || (PL == 2 && KC == 1), "phase 0 on the matrix cores: f16x2, one panel");
   constexpr bool SEGMAX = (LOADER == LOAD_GATHER_MLP1 || MFMA0) && EPI2 == EPI_MAX;   // may run on distinct rows only (seg4)
+  const int tile = blockIdx.x;
+  const int p0 = tile * BM;
   bool seg_scene = false;   // this tile's scene is in the distinct-row layout (a mostly-full scene keeps the plain one)
   if constexpr (SEGMAX) {
     // distinct-row form: a scene's rows end before its base + rps; the tiles behind them have nothing to do
@@ -1169,8 +1170,8 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb)
       rv0[rb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                                               rrel, ((t >> 6) / CW * WROWS + rb * 32 + (lane & 31)) * 16, 0, 0));
-    const int ch = (t >> 6) % CW * 64 + lane;
+                                               rrel, (wr * WROWS + rb * 32 + li) * 16, 0, 0));
+    const int ch = wc * 64 + lane;
     if (ch < p.Cin) wv0 = p.mlp1[ch];
   } else {
     ld.init(p, p0, g, t);
@@ -1275,6 +1276,13 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
     f32x16 z16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) z16[r] = 0.f;
+    // The fragments above come out of INLINE ASM (v_fma_mix*): the compiler's hazard recognizer does not see an asm
+    // statement as a vector-ALU write, so it does not pad the VALU-write -> MFMA-read distance -- the first MFMA read
+    // the ONE slot's half before the v_fma_mixhi two instructions earlier had landed (found by the test: the bias
+    // term's low plane missing in one row block).  Everywhere else the split's results go through LDS first.
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -1420,6 +1428,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
     __syncthreads();
   } else {
   float tmax = 0.f;
+  const float relu_lo = relu_ph ? 0.f : -__builtin_inff();
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -1433,12 +1442,10 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
         // two v_pk_fma_f32 per four values (each half rounded once, as __fmaf_rn), the tile maximum as max3s
         const f32x2 x01 = pk_fma(f32x2{acc[nb][pb][4 * j], acc[nb][pb][4 * j + 1]}, f32x2{scv[0], scv[1]}, f32x2{bv[0], bv[1]});
         const f32x2 x23 = pk_fma(f32x2{acc[nb][pb][4 * j + 2], acc[nb][pb][4 * j + 3]}, f32x2{scv[2], scv[3]}, f32x2{bv[2], bv[3]});
-        float x[4] = {x01.x, x01.y, x23.x, x23.y};
+        // (ReLU as a max with 0 or -inf: a per-element branch on the runtime flag became select chains)
+        const float x[4] = {fmaxf(x01.x, relu_lo), fmaxf(x01.y, relu_lo), fmaxf(x23.x, relu_lo), fmaxf(x23.y, relu_lo)};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (relu_ph) x[e] = fmaxf(x[e], 0.f);
-          acc[nb][pb][4 * j + e] = x[e];
-        }
+        for (int e = 0; e < 4; ++e) acc[nb][pb][4 * j + e] = x[e];
         if constexpr (PL == 2) {
           tmax = fmaxf(fmaxf(tmax, fabsf(x[0])), fabsf(x[1]));
           tmax = fmaxf(fmaxf(tmax, fabsf(x[2])), fabsf(x[3]));
@@ -1472,7 +1479,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
         }
       if (PL == 2 && oamax) {
         const uint32_t wm = wave_max_u32(__float_as_uint(tmax));
-        if (lane == 0) amax_publish(oamax, wm, (blockIdx.x * 4 + wave) * 5 + g, p0, p_hi, p.rps);
+        if (lane == 0) amax_publish(oamax, wm, (tile * 4 + wave) * 5 + g, p0, p_hi, p.rps);
       }
       return;
     }
@@ -1591,7 +1598,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
         }
       if (p.out_amax) {
         const uint32_t wm = wave_max_u32(__float_as_uint(omax));
-        if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave + strip, p0, p_hi, p.rps);
+        if (lane == 0) amax_publish(p.out_amax, wm, tile * 4 + wave + strip, p0, p_hi, p.rps);
       }
     } else if (SEGMAX && seg_scene) {
       // distinct-row form: the wave's 64 rows are pieces of several centroids, each a run of 4-row groups
@@ -1642,7 +1649,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
       }
       if (PL == 2 && p.out_amax) {
         const uint32_t wm = wave_max_u32(__float_as_uint(omax));
-        if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave + strip, p0, p_hi, p.rps);
+        if (lane == 0) amax_publish(p.out_amax, wm, tile * 4 + wave + strip, p0, p_hi, p.rps);
       }
     } else if (q.relu && p.K == 64) {
       // max over the 64 neighbours FIRST, on the raw accumulators (the scales are positive powers
@@ -1669,7 +1676,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
       }
       if (PL == 2 && p.out_amax) {
         const uint32_t wm = wave_max_u32(__float_as_uint(omax));
-        if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave + strip, p0, p_hi, p.rps);
+        if (lane == 0) amax_publish(p.out_amax, wm, tile * 4 + wave + strip, p0, p_hi, p.rps);
       }
     } else if constexpr (NRB == 2) {
       // (no ReLU behind the last layer: the generic max epilogue, which takes [row block][channel block])
@@ -1693,7 +1700,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
       }
       if (p.out_amax) {
         const uint32_t wm = wave_max_u32(__float_as_uint(fmaxf(omax, 0.f)));
-        if (lane == 0) amax_publish(p.out_amax, wm, blockIdx.x * 4 + wave + strip, p0, p_hi, p.rps);
+        if (lane == 0) amax_publish(p.out_amax, wm, tile * 4 + wave + strip, p0, p_hi, p.rps);
       }
       gemm_epilogue<EPI_MAX, 2>(q, acct, bg2, g, p0, n0, wave, wr, 0, li, lh, smemf);
     }
