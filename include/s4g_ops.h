@@ -48,8 +48,10 @@ extern "C" {
  *    contracts a centroid's distinct rows only); out2 / ldc2 / split_n / out_amax2 (two layers that read the
  *    same tensor as one launch); the operators in double (*_f64); s4g_build_variants.
  * 9: s4g_heads_desc_t.out_batch_stride (the four heads written as channel slices of one packed
- *    (B, 21, N) tensor: the all-gather payload of the multi-GPU path without a packing copy). */
-#define S4G_ABI_VERSION 9
+ *    (B, 21, N) tensor: the all-gather payload of the multi-GPU path without a packing copy).
+ * 10: s4g_group_points_backward_det_f32 / s4g_three_interpolate_backward_det_f32 / s4g_scatter_det_workspace_bytes
+ *    (the backward scatters in a fixed order: run-to-run bit-identical, equal to the oracle's sequential sum). */
+#define S4G_ABI_VERSION 10
 
 /* ---------------------------------------------------------------------------
  * Environment knobs (round 4: the complete list; everything else that used to be read from the
@@ -68,6 +70,8 @@ extern "C" {
  *   S4G_INTERP_MODE=lane           three_interpolate: lane-per-point kernel instead of the LDS tile
  *   S4G_GEMM_SINGLE_CHAIN=0|1      plain single layers never / wherever supported on mlp_chain_kernel's first-layer
  *                                  form (default: where it measured faster: Cout >= 1024 or K >= 1024)
+ *   S4G_BACKWARD=atomic            group_points / three_interpolate backward through the atomicAdd kernels (the reference's
+ *                                  scheme, order undefined) instead of the deterministic sorted-segment sums (Python side)
  *   S4G_MLP1_MFMA=0                first SA level's 3 -> C layer on the vector ALU (the chain kernel's loader) instead of
  *                                  one MFMA step inside the chain kernel (round 5; f16x2 form with rel_xyz4 records)
  *  measurement builds only (make HIPFLAGS_EXTRA=-DS4G_VARIANTS, s4g_build_variants() == 1):
@@ -204,6 +208,22 @@ int s4g_three_interpolate_backward_f32(const float *gout_bcn1,
                                        const float *w_bn3, int64_t B, int64_t C,
                                        int64_t N2, int64_t N1, float *gin_bcn2,
                                        s4g_stream_t stream);
+
+/* ABI >= 10.  The two backward scatters DETERMINISTICALLY: same signatures plus a workspace of
+ * s4g_scatter_det_workspace_bytes(B, N, T) bytes (256-byte aligned; T = M K for group_points, 3 N1 for
+ * three_interpolate; 0 = the sizes are not supported: B T and B N must stay below 2^31).  The contributions are
+ * ordered by a stable radix sort on (scene, target point) and every target is summed by one thread in ascending
+ * position order -- the sum a sequential loop over the positions forms: run-to-run bit-identical and equal to
+ * the CPU oracle bit for bit, where the reference's atomicAdd scatter (grouping_kernel.cu:94,
+ * interpolate_kernel.cu:283; s4g_*_backward_f32 above) leaves the order to the hardware.  An index outside
+ * [0, N) contributes nothing. */
+size_t s4g_scatter_det_workspace_bytes(int64_t B, int64_t N, int64_t T);
+int s4g_group_points_backward_det_f32(const float *gout_bcmk, const int64_t *idx_bmk, int64_t B, int64_t C,
+                                      int64_t N, int64_t M, int64_t K, float *gin_bcn, void *ws,
+                                      size_t ws_bytes, s4g_stream_t stream);
+int s4g_three_interpolate_backward_det_f32(const float *gout_bcn1, const int64_t *idx_bn3, const float *w_bn3,
+                                           int64_t B, int64_t C, int64_t N2, int64_t N1, float *gin_bcn2,
+                                           void *ws, size_t ws_bytes, s4g_stream_t stream);
 
 /* Inverse-distance weights of FeatureInterpolator.forward
  * (modules.py:118-120): w = (1/max(d2,eps)) / sum_k (1/max(d2,eps)). */

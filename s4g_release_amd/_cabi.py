@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # declared symbol are checked either way
 LIB_PATH = os.environ.get("S4G_HIP_LIB") or os.path.join(_HERE, "libs4g_hip.so")
 
-S4G_ABI_VERSION = 9
+S4G_ABI_VERSION = 10
 S4G_EUNSUPPORTED = -3
 S4G_FLAG_FMAD = 1
 S4G_OP_FPS, S4G_OP_BALL_QUERY, S4G_OP_THREE_NN = 1, 2, 3
@@ -95,6 +95,9 @@ SIGNATURES = {
     "s4g_group_points_backward_f64": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
     "s4g_three_interpolate_f64": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp]),
     "s4g_three_interpolate_backward_f64": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "s4g_scatter_det_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "s4g_group_points_backward_det_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "s4g_three_interpolate_backward_det_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "s4g_group_rel_xyz_i32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "s4g_group_rel_xyz_unique_i32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "s4g_expected_score_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),

@@ -36,6 +36,28 @@ def set_distance_mode(mode):
     _DIST_FLAGS = _cabi.S4G_FLAG_FMAD if mode == "fmad" else 0
 
 
+# backward of group_points / three_interpolate: "deterministic" (default; sorted-segment sums in ascending position
+# order, csrc/scatter.hip: run-to-run bit-identical, equal to the sequential sum) or "atomic" (the reference's
+# atomicAdd scatter: fewer passes, undefined order)
+_BACKWARD_MODE = "atomic" if os.environ.get("S4G_BACKWARD", "deterministic") == "atomic" else "deterministic"
+
+
+def set_backward_mode(mode):
+    """'deterministic' (default) or 'atomic' (grouping_kernel.cu:94 / interpolate_kernel.cu:283's scheme)."""
+    global _BACKWARD_MODE
+    if mode not in ("deterministic", "atomic"):
+        raise ValueError("mode must be 'deterministic' or 'atomic'")
+    _BACKWARD_MODE = mode
+
+
+def _scatter_ws(dev, B, N, T):
+    """Workspace of the deterministic scatters, or (None, 0) where the sizes are outside their 32-bit keys."""
+    nbytes = _cabi.lib().s4g_scatter_det_workspace_bytes(B, N, T)
+    if nbytes == 0:
+        return None, 0
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes
+
+
 def _check_dev(t, name):
     if not t.is_cuda:
         raise RuntimeError("%s must be a CUDA tensor" % name)  # CHECK_CUDA of the reference
@@ -325,8 +347,14 @@ def _group_points_backward(grad_output, index, num_points):
         raise RuntimeError("index shape does not match grad_output")  # :120-122
     gin = torch.empty((B, C, int(num_points)), dtype=torch.float32, device=grad_output.device)
     with torch.cuda.device(grad_output.device):
-        rc = _cabi.lib().s4g_group_points_backward_f32(_ptr(grad_output), _ptr(index), B, C,
-                                                       int(num_points), M, K, _ptr(gin), _stream())
+        ws, nbytes = _scatter_ws(grad_output.device, B, int(num_points), M * K) \
+            if _BACKWARD_MODE == "deterministic" and gin.numel() > 0 else (None, 0)
+        if ws is not None:
+            rc = _cabi.lib().s4g_group_points_backward_det_f32(_ptr(grad_output), _ptr(index), B, C, int(num_points),
+                                                               M, K, _ptr(gin), _ptr(ws), nbytes, _stream())
+        else:
+            rc = _cabi.lib().s4g_group_points_backward_f32(_ptr(grad_output), _ptr(index), B, C,
+                                                           int(num_points), M, K, _ptr(gin), _stream())
     _cabi.check(rc, "group_points_backward")
     return gin
 
@@ -441,9 +469,16 @@ def _interpolate_backward(grad_output, index, weight, num_inst):
         raise RuntimeError("index / weight must be (batch_size, N, 3)")  # :307-311
     gin = torch.empty((B, C, int(num_inst)), dtype=torch.float32, device=grad_output.device)
     with torch.cuda.device(grad_output.device):
-        rc = _cabi.lib().s4g_three_interpolate_backward_f32(_ptr(grad_output), _ptr(index),
-                                                            _ptr(weight), B, C, int(num_inst), N1,
-                                                            _ptr(gin), _stream())
+        ws, nbytes = _scatter_ws(grad_output.device, B, int(num_inst), 3 * N1) \
+            if _BACKWARD_MODE == "deterministic" and gin.numel() > 0 else (None, 0)
+        if ws is not None:
+            rc = _cabi.lib().s4g_three_interpolate_backward_det_f32(_ptr(grad_output), _ptr(index), _ptr(weight), B, C,
+                                                                    int(num_inst), N1, _ptr(gin), _ptr(ws), nbytes,
+                                                                    _stream())
+        else:
+            rc = _cabi.lib().s4g_three_interpolate_backward_f32(_ptr(grad_output), _ptr(index),
+                                                                _ptr(weight), B, C, int(num_inst), N1,
+                                                                _ptr(gin), _stream())
     _cabi.check(rc, "interpolate_backward")
     return gin
 

@@ -1,0 +1,121 @@
+"""The two backward scatters in a FIXED order (ABI 10, csrc/scatter.hip).
+
+The reference's backward kernels add with atomicAdd (grouping_kernel.cu:57-96, interpolate_kernel.cu:243-286): the
+order in which a point's contributions meet is undefined and its gradients differ run to run in the last bits.  The
+default backward here sorts the contributions by (scene, target, position) and sums every target in ascending
+position order -- the sum a sequential loop forms, i.e. the CPU oracle's (`linearId order`): BIT-EXACT against the
+oracle, identical run to run.  The atomic kernels stay behind `functions.set_backward_mode("atomic")`."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.fixture()
+def F():
+    from s4g_release_amd import functions
+    functions.set_backward_mode("deterministic")
+    yield functions
+    functions.set_backward_mode("deterministic")
+
+
+def _group_case(rng, B, C, N, M, K, pad=0.0):
+    index = rng.integers(0, N, size=(B, M, K))
+    if pad > 0:      # ball_query's padding: a short ball repeats its first hit -- one point collects dozens of rows
+        cnt = rng.integers(1, K + 1, size=(B, M))
+        short = rng.random((B, M)) < pad
+        for b in range(B):
+            for m in np.nonzero(short[b])[0]:
+                index[b, m, cnt[b, m]:] = index[b, m, 0]
+    # gradients of very different magnitudes: the order of the additions shows in the last bits
+    g = (rng.standard_normal((B, C, M, K)) * np.exp(rng.uniform(-6, 6, size=(B, C, M, K)))).astype(np.float32)
+    return index, g
+
+
+@pytest.mark.parametrize("B,C,N,M,K,pad", [(2, 6, 50, 9, 4, 0.0), (3, 3, 2048, 512, 64, 0.6), (2, 64, 700, 128, 32, 0.3),
+                                           (1, 5, 4096, 1, 16, 0.0), (2, 7, 97, 33, 5, 0.5)])
+def test_group_points_backward_equals_the_sequential_sum_bit_for_bit(F, oracle, dev, B, C, N, M, K, pad):
+    rng = np.random.default_rng(B * 1000 + C)
+    index, g = _group_case(rng, B, C, N, M, K, pad)
+    feat = torch.zeros((B, C, N), device=dev, requires_grad=True)
+    out = F.group_points(feat, _t(index, dev))
+    out.backward(_t(g, dev))
+    ref = oracle.group_points_backward(g, index, N)
+    got = feat.grad.cpu().numpy()
+    assert np.array_equal(got, ref)                       # bit for bit, signed zeros aside
+    untouched = np.ones((B, N), bool)
+    for b in range(B):
+        untouched[b, np.unique(index[b])] = False
+    assert (got.transpose(0, 2, 1)[untouched] == 0).all()  # targets nobody points at: exactly 0
+    # run to run: the same bits
+    for _ in range(3):
+        again = F._group_points_backward(_t(g, dev), _t(index, dev), N).cpu().numpy()
+        assert np.array_equal(again.view(np.uint32), got.view(np.uint32))
+    # the atomic kernels agree to rounding (and are what the flag selects)
+    F.set_backward_mode("atomic")
+    atom = F._group_points_backward(_t(g, dev), _t(index, dev), N).cpu().numpy()
+    scale = np.abs(g).max() * max(1, M * K // max(N, 1) + K)
+    assert np.allclose(atom, ref, rtol=1e-4, atol=1e-5 * scale)
+
+
+@pytest.mark.parametrize("B,C,N2,N1", [(2, 6, 20, 31), (2, 16, 1024, 5120), (1, 3, 3, 100), (3, 33, 257, 1000)])
+def test_three_interpolate_backward_equals_the_sequential_sum_bit_for_bit(F, oracle, dev, B, C, N2, N1):
+    rng = np.random.default_rng(N1)
+    idx = rng.integers(0, N2, size=(B, N1, 3))
+    idx[:, : N1 // 4] = idx[:, :1]                 # a hot key: a quarter of the queries share their neighbours
+    w = rng.random((B, N1, 3), dtype=np.float32)
+    g = (rng.standard_normal((B, C, N1)) * np.exp(rng.uniform(-6, 6, size=(B, C, N1)))).astype(np.float32)
+    feat = torch.zeros((B, C, N2), device=dev, requires_grad=True)
+    out = F.feature_interpolate(feat, _t(idx, dev), _t(w, dev))
+    out.backward(_t(g, dev))
+    ref = oracle.three_interpolate_backward(g, idx, w, N2)
+    got = feat.grad.cpu().numpy()
+    assert np.array_equal(got, ref)
+    for _ in range(3):
+        again = F._interpolate_backward(_t(g, dev), _t(idx, dev), _t(w, dev), N2).cpu().numpy()
+        assert np.array_equal(again.view(np.uint32), got.view(np.uint32))
+    F.set_backward_mode("atomic")
+    atom = F._interpolate_backward(_t(g, dev), _t(idx, dev), _t(w, dev), N2).cpu().numpy()
+    assert np.allclose(atom, ref, rtol=1e-4, atol=1e-5 * np.abs(g).max() * N1)
+
+
+def test_full_size_first_level_backward_is_reproducible(F, dev):
+    """SA1's grouping at the shipped size (16 x 25 600 points, 5 120 x 64 rows, xyz): three runs, the same bits --
+    and the atomic kernels, on the same input, do NOT always repeat theirs (that is the point of the exercise;
+    not asserted: an unlucky box may serve the atomics in the same order twice)."""
+    g0 = torch.Generator(device="cpu").manual_seed(3)
+    B, C, N, M, K = 16, 3, 25600, 5120, 64
+    index = torch.randint(0, N, (B, M, K), generator=g0).to(dev)
+    index[:, :, 40:] = index[:, :, :1]            # padded balls: heavy collisions
+    g = (torch.randn(B, C, M, K, generator=g0) * torch.exp(torch.empty(B, C, M, K).uniform_(-5, 5, generator=g0))).to(dev)
+    a = F._group_points_backward(g, index, N)
+    for _ in range(2):
+        assert torch.equal(F._group_points_backward(g, index, N).view(torch.int32), a.view(torch.int32))
+    ref = torch.zeros(B, C, N, dtype=torch.float64, device=dev)
+    ref.scatter_add_(2, index.view(B, 1, M * K).expand(B, C, M * K), g.double().view(B, C, M * K))
+    assert torch.allclose(a.double(), ref, rtol=1e-4, atol=1e-3)
+
+
+def test_workspace_contract_and_out_of_range_indices(F, dev):
+    from s4g_release_amd import _cabi
+    L = _cabi.lib()
+    assert L.s4g_scatter_det_workspace_bytes(0, 10, 10) == 0
+    assert L.s4g_scatter_det_workspace_bytes(1 << 20, 1 << 12, 4) == 0          # B N beyond 32-bit keys
+    B, C, N, M, K = 1, 2, 8, 3, 2
+    nbytes = L.s4g_scatter_det_workspace_bytes(B, N, M * K)
+    assert nbytes > 0 and nbytes % 256 == 0
+    g = torch.ones(B, C, M, K, device=dev)
+    idx = torch.tensor([[[0, 1], [1, 99], [-3, 7]]], device=dev)               # 99 and -3: outside [0, 8)
+    gin = torch.full((B, C, N), float("nan"), device=dev)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    f = L.s4g_group_points_backward_det_f32
+    assert f(g.data_ptr(), idx.data_ptr(), B, C, N, M, K, gin.data_ptr(), ws.data_ptr(), nbytes - 256, st) == -2   # EWORKSPACE
+    assert f(g.data_ptr(), idx.data_ptr(), B, C, N, M, K, gin.data_ptr(), ws.data_ptr(), nbytes, st) == 0
+    torch.cuda.synchronize()
+    assert gin[0, 0].tolist() == [1.0, 2.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]

@@ -85,5 +85,6 @@ def test_measurement_build_with_the_kernel_variants_compiles(tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     import torch  # noqa: F401  (its HIP runtime first, as _cabi.lib does)
     h = ctypes.CDLL(str(lib))
-    assert h.s4g_build_variants() == 1 and h.s4g_abi_version() == 8
+    from s4g_release_amd import _cabi
+    assert h.s4g_build_variants() == 1 and h.s4g_abi_version() == _cabi.S4G_ABI_VERSION
     shutil.rmtree(tmp_path, ignore_errors=True)
