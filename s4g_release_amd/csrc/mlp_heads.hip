@@ -281,13 +281,18 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
       const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
       const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-      for (int rb = 0; rb < NRB; ++rb)
+      for (int rb = 0; rb < NRB; ++rb) {
+        // two v_pk_fma_f32 per four values (each half rounded once, as __fmaf_rn); the maximum as max3s (x >= 0)
+        const f32x2 x01 = pk_fma(f32x2{acc[rb][4 * j], acc[rb][4 * j + 1]}, f32x2{scv[0], scv[1]}, f32x2{bv[0], bv[1]});
+        const f32x2 x23 = pk_fma(f32x2{acc[rb][4 * j + 2], acc[rb][4 * j + 3]}, f32x2{scv[2], scv[3]}, f32x2{bv[2], bv[3]});
+        const float x[4] = {fmaxf(x01.x, 0.f), fmaxf(x01.y, 0.f), fmaxf(x23.x, 0.f), fmaxf(x23.y, 0.f)};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float x = fmaxf(__fmaf_rn(acc[rb][4 * j + e], scv[e], bv[e]), 0.f);
-          acc[rb][4 * j + e] = x;
-          if constexpr (PL == 2) tmax = fmaxf(tmax, x);
+        for (int e = 0; e < 4; ++e) acc[rb][4 * j + e] = x[e];
+        if constexpr (PL == 2) {
+          tmax = fmaxf(fmaxf(tmax, x[0]), x[1]);
+          tmax = fmaxf(fmaxf(tmax, x[2]), x[3]);
         }
+      }
     }
     float sh = 1.f;
     if constexpr (PL == 2) {
@@ -348,7 +353,11 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
 #pragma unroll
     for (int rb = 0; rb < NRBT; ++rb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc1[rb][r] = acc[rb][r] * inv_sh;
+      for (int r = 0; r < 16; r += 2) {      // (packed fp32: two values per issue slot)
+        const f32x2 v = f32x2{acc[rb][r], acc[rb][r + 1]} * f32x2{inv_sh, inv_sh};
+        acc1[rb][r] = v.x;
+        acc1[rb][r + 1] = v.y;
+      }
     // ---- heads.0 half 1 -> B;  heads.1 over that half, then its epilogue -> B
     stage_sb(0, g * 512 + 256 + wv * 32, inv_sa);
     S4G_HD_STRIP(PA, NRBT, 0, w0(g, 1), 16, w1(g, 1))
@@ -357,7 +366,11 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
 #pragma unroll
     for (int rb = 0; rb < NRBT; ++rb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rb][r] = __fmaf_rn(acc[rb][r], inv_sh, acc1[rb][r]);
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 v = pk_fma(f32x2{acc[rb][r], acc[rb][r + 1]}, f32x2{inv_sh, inv_sh}, f32x2{acc1[rb][r], acc1[rb][r + 1]});
+        acc[rb][r] = v.x;
+        acc[rb][r + 1] = v.y;
+      }
     stage_sb(1, g * 256 + wv * 32, 1.f);
     panel_epilogue(full{}, 0, wv * 32);
     // ---- heads.2 -> B
