@@ -68,7 +68,7 @@ BF16_MFMA_PEAK_TF = 2500.0     # dense bf16 / fp16 MFMA (no sparsity)
 # operands: 2 436
 F16_MFMA_ATTAINABLE_TF = 1248.0
 GFLOP_PER_SCENE = 203.48       # SURVEY.md Appendix B (BN folded, 2*MAC), N = 25 600
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")
 
 
 def parse(argv=None):
@@ -330,6 +330,11 @@ def main():
     use_dist = world > 1 or (os.environ.get("S4G_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL's all-gather runs as channel workgroups beside contraction kernels that fill every CU with one or two
+        # workgroups: each channel can hold a CU's slot for the collective's duration.  8 channels move the 238 MB a rank
+        # receives per step in well under a step and cap that cost at 8 of 256 CUs; a value set by
+        # the caller wins.
+        sdist.bound_rccl_channels()
         dist.init_process_group(**hw.init_kw())
 
     cfg = S4GConfig()
@@ -759,6 +764,7 @@ def main():
                       "payload": args.gather,
                       "payload_bytes_per_rank_per_step": int(gather.payload_bytes),
                       "stream": gather.last_stream,
+                      "rccl_env": {k: os.environ[k] for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS") if k in os.environ},
                       "note": "issued on a side stream behind an event of the collecting stream; the next batch's "
                               "contractions run on their own stream meanwhile"}
     payload = ("all-gather of 21 ch/point" if args.gather == "heads" else

@@ -70,6 +70,8 @@ extern "C" {
  *   S4G_INTERP_MODE=lane           three_interpolate: lane-per-point kernel instead of the LDS tile
  *   S4G_GEMM_SINGLE_CHAIN=0|1      plain single layers never / wherever supported on mlp_chain_kernel's first-layer
  *                                  form (default: where it measured faster: Cout >= 1024 or K >= 1024)
+ *   S4G_PACKED_OUT=0               FusedPointNet2 returns four head tensors of their own instead of channel slices of one
+ *                                  packed (B, 21, N) tensor
  *   S4G_BACKWARD=atomic            group_points / three_interpolate backward through the atomicAdd kernels (the reference's
  *                                  scheme, order undefined) instead of the deterministic sorted-segment sums (Python side)
  *   S4G_MLP1_MFMA=0                first SA level's 3 -> C layer on the vector ALU (the chain kernel's loader) instead of
@@ -90,7 +92,8 @@ extern "C" {
  *   S4G_FPS_PREFIX=0               always sample SA levels 2 and 3 (no prefix proof)
  *   S4G_NN_MODE=scan               3-NN: never the cell-grid search
  *   S4G_GEO_STREAMS=n, S4G_DENSE_STREAMS=n   geometry / contraction streams of the pipeline (2 / 1)
- *  bench.py: S4G_BENCH_FORCE_DIST=1 (RCCL path with one rank), S4G_BENCH_TIMER_EVERY=k
+ *  bench.py: S4G_BENCH_FORCE_DIST=1 (RCCL path with one rank), S4G_BENCH_TIMER_EVERY=k, NCCL_MAX_NCHANNELS (default 8
+ *            set by dist.bound_rccl_channels), S4G_BENCH_BACKEND=gloo (tests/test_bench_world.py ONLY: CPU stub run)
  * ------------------------------------------------------------------------- */
 
 #define S4G_OK 0

@@ -16,6 +16,21 @@ import torch.distributed as dist
 HEADS = ("score", "frame_R", "frame_t", "movable_logits")
 
 
+RCCL_MAX_CHANNELS = "8"
+
+
+def bound_rccl_channels():
+    """Bound the CUs RCCL's collectives can occupy beside the contraction kernels (call before the process group
+    exists): NCCL_MAX_NCHANNELS defaults to 8 here unless the caller's environment already sets it.  A channel is
+    one workgroup; the contraction launches run one or two workgroups per CU with the LDS full, so a channel that
+    lands on a CU holds that slot for the collective's duration (the same mechanism through which the FPS
+    workgroups cost the step 1.6 x their CU-time share, profiles/r04_geometry_cost.md).  The per-batch all-gather
+    (34 MB per rank out, 238 MB in at 8 ranks) needs ~0.3 ms of the seven xGMI links' time per 7.6 ms step; at 8
+    channels it is still several times shorter than a step and overlapped on its own stream."""
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", RCCL_MAX_CHANNELS)
+    return os.environ["NCCL_MAX_NCHANNELS"]
+
+
 def init_from_env(backend=None):
     """Initialise the default process group from torchrun's environment.
     Returns (rank, world, local_rank); a no-op world of 1 without WORLD_SIZE."""
@@ -28,6 +43,7 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
         if backend == "nccl":
+            bound_rccl_channels()
             torch.cuda.set_device(local_rank)
             kw["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend=backend, **kw)

@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round-4 profile capture on the GPU box (run through gpurun from the repo root):
+# Round-5 profile capture on the GPU box (run through gpurun from the repo root):
 #   kernel-trace + stats of the default bench and of configs[4], then separate PMC passes
 #   (FETCH_SIZE / WRITE_SIZE cannot share a pass) for the contraction launches of one step and
-#   for the ball_query + group_points operator pair.  Outputs land in gpurun_out/r4prof/;
-#   tools/make_traffic_json.py turns the PMC csv files into profiles/r03_traffic.json.
+#   for the ball_query + group_points operator pair.  Outputs land in gpurun_out/r5prof/;
+#   S4G_PROFILE_ROUND=5 tools/publish_profiles.py (which runs tools/make_traffic_json.py) turns them into profiles/r05_*.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r4prof
+O=$R/gpurun_out/r5prof
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 CFG4="--points 51200 --batch 32 --precision bf16"
@@ -27,6 +27,14 @@ for d in default cfg4; do
   db=$(find $O/stats_$d -name "*.db" | head -1)
   [ -n "$db" ] && python3 $R/tools/rocpd_summary.py $db 45 > $O/${d}_kernel_stats.md
 done
+# the reference-shaped modules on the HIP operators (INTEGRATION.md levels 1-2): the LAST pass of a kernel trace
+rocprofv3 --kernel-trace --stats -d $O/stats_modules -o run -- python3 $R/bench.py --impl modules --steps 5 --warmup 2 --no-extras --no-cpu-baseline > $O/bench_modules_profiled.json 2> $O/err_modules.txt
+db=$(find $O/stats_modules -name "*.db" | head -1)
+[ -n "$db" ] && python3 $R/tools/rocpd_last_pass.py $db fps_cell_sort 40 > $O/modules_last_pass.md
+# the attainable MFMA rate of the board this capture ran on, and power / clock of every contraction launch alone
+$R/tools/micro/mfma_ceiling 1.5 > $O/mfma_ceiling.md 2>&1
+python3 $R/tools/power_probe.py --seconds 1.5 > $O/power_clock_default.md 2>/dev/null
+python3 $R/tools/power_probe.py --seconds 1.5 --points 51200 --batch 32 --precision bf16 > $O/power_clock_cfg4.md 2>/dev/null
 # un-profiled lines of the same build, for the record
 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_default.json 2>/dev/null
 python3 $R/bench.py $CFG4 --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_cfg4.json 2>/dev/null
