@@ -257,11 +257,17 @@ def query_and_group(points, centroids, radius, num_neighbours):
         return index, count, _group_points_forward(points, index)
     points = _f32c(points, "points")
     centroids = _f32c(centroids, "centroids")
-    if points.dim() != 3 or points.size(1) != 3 or centroids.dim() != 3 or centroids.size(1) != 3:
-        raise RuntimeError("points / centroids must be (B, 3, N)")
+    if points.dim() != 3 or points.size(1) != 3:
+        raise RuntimeError("points.size(1) does not equal to 3")  # ball_query_kernel.cu:102
+    if centroids.dim() != 3 or centroids.size(1) != 3:
+        raise RuntimeError("centroids.size(1) does not equal to 3")  # :103
+    if centroids.size(0) != points.size(0):       # (the C entry takes ONE batch size: a mismatch would read out of bounds)
+        raise RuntimeError("points and centroids must share the batch size")
     B, _, N = points.shape
     M = centroids.size(2)
     K = int(num_neighbours)
+    if K <= 0:
+        raise RuntimeError("num_neighbours must be positive")
     index = torch.empty((B, M, K), dtype=torch.int64, device=points.device)
     count = torch.empty((B, M), dtype=torch.int64, device=points.device)
     grouped = torch.empty((B, 3, M, K), dtype=torch.float32, device=points.device)
@@ -331,7 +337,11 @@ def _group_points_forward(points, index):
 def _group_points_backward(grad_output, index, num_points):
     if _is_f64(grad_output):
         grad_output, index = grad_output.contiguous(), _i64c(index, "index")
+        if grad_output.dim() != 4 or index.dim() != 3:
+            raise RuntimeError("grad_output must be 4-d and index 3-d")  # grouping_kernel.cu:118-119
         B, C, M, K = grad_output.shape
+        if tuple(index.shape) != (B, M, K):
+            raise RuntimeError("index shape does not match grad_output")  # :120-122
         gin = torch.empty((B, C, int(num_points)), dtype=torch.float64, device=grad_output.device)
         with torch.cuda.device(grad_output.device):
             rc = _cabi.lib().s4g_group_points_backward_f64(_ptr(grad_output), _ptr(index), B, C, int(num_points), M, K,
@@ -454,7 +464,11 @@ def _interpolate_forward(feature, index, weight):
 def _interpolate_backward(grad_output, index, weight, num_inst):
     if _is_f64(grad_output, weight):
         grad_output, index, weight = grad_output.contiguous(), _i64c(index, "index"), weight.contiguous()
+        if grad_output.dim() != 3:
+            raise RuntimeError("grad_output must be (batch_size, channels, N)")
         B, C, N1 = grad_output.shape
+        if tuple(index.shape) != (B, N1, 3) or tuple(weight.shape) != (B, N1, 3):
+            raise RuntimeError("index / weight must be (batch_size, N, 3)")  # interpolate_kernel.cu:307-311
         gin = torch.empty((B, C, int(num_inst)), dtype=torch.float64, device=grad_output.device)
         with torch.cuda.device(grad_output.device):
             rc = _cabi.lib().s4g_three_interpolate_backward_f64(_ptr(grad_output), _ptr(index), _ptr(weight), B, C,

@@ -119,3 +119,21 @@ def test_workspace_contract_and_out_of_range_indices(F, dev):
     assert f(g.data_ptr(), idx.data_ptr(), B, C, N, M, K, gin.data_ptr(), ws.data_ptr(), nbytes, st) == 0
     torch.cuda.synchronize()
     assert gin[0, 0].tolist() == [1.0, 2.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]
+
+
+def test_argument_checks_of_the_wrappers_the_advisor_flagged(F, dev):
+    """`query_and_group` (what `QueryGrouper` calls) and the double branches of the two backward wrappers
+    skipped the shape checks their float / two-call counterparts make -- a mismatch became an out-of-bounds device
+    access instead of an error."""
+    pts, ctr = torch.zeros(2, 3, 64, device=dev), torch.zeros(3, 3, 8, device=dev)
+    with pytest.raises(RuntimeError, match="batch size"):
+        F.query_and_group(pts, ctr, 0.1, 4)
+    with pytest.raises(RuntimeError, match="positive"):
+        F.query_and_group(pts, ctr[:2], 0.1, 0)
+    g4 = torch.zeros(2, 3, 5, 4, device=dev, dtype=torch.float64)
+    with pytest.raises(RuntimeError, match="index shape"):
+        F._group_points_backward(g4, torch.zeros(2, 5, 3, dtype=torch.int64, device=dev), 10)
+    g3 = torch.zeros(2, 3, 7, device=dev, dtype=torch.float64)
+    with pytest.raises(RuntimeError, match=r"\(batch_size, N, 3\)"):
+        F._interpolate_backward(g3, torch.zeros(2, 6, 3, dtype=torch.int64, device=dev),
+                                torch.zeros(2, 7, 3, device=dev, dtype=torch.float64), 10)
