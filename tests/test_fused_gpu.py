@@ -4,6 +4,7 @@ loader x epilogue against a plain fp32 torch restatement of the same layer;
 model tests compare against the golden fixtures captured from the reference's
 Python network (1e-4 abs; indices bit-exact)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -14,6 +15,8 @@ from tests.conftest import with_variants
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+# random-architecture tests: 6 seeds in the suite; S4G_FUZZ_SEEDS=n widens them into a sweep (run once per round)
+FUZZ_SEEDS = int(os.environ.get("S4G_FUZZ_SEEDS", "6"))
 
 
 @pytest.fixture(params=with_variants(["chain", "tiled"], ["resident"]))
@@ -928,7 +931,7 @@ def test_pipelined_submissions_match_sequential(dev, monkeypatch, streams):
             assert torch.equal(r[k], o[k]), k
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS))
 def test_fused_equals_modules_random_configs(dev, seed):
     """Random small architectures / cloud sizes (odd point counts, 16/32/64 neighbours,
     channel counts that miss every tile size): fast path == reference-shaped modules path."""
@@ -961,7 +964,7 @@ def test_fused_equals_modules_random_configs(dev, seed):
             assert (a[k] - b[k]).abs().max().item() < TOL * scale, (k, precision, cfg)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS))
 def test_fused_equals_modules_chain_widths(dev, seed):
     """Random architectures whose widths are 128 / 256 (so the two- and three-layer chain
     launches, the deep first head layer and both linear-first restructurings all engage) on
