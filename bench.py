@@ -67,6 +67,8 @@ BF16_MFMA_PEAK_TF = 2500.0     # dense bf16 / fp16 MFMA (no sparsity)
 # sustains 1 248 TFLOP/s at the clock the power governor allows (1.81 GHz, 1.29 kW); registers-only: 1 681; constant
 # operands: 2 436
 F16_MFMA_ATTAINABLE_TF = 1248.0
+# ... and the single-plane bf16 chains' loop (8 MFMAs per step and wave on four row blocks, configs[4]): 1 357 TFLOP/s
+BF16_MFMA_ATTAINABLE_TF = 1357.0
 GFLOP_PER_SCENE = 203.48       # SURVEY.md Appendix B (BN folded, 2*MAC), N = 25 600
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")
 
@@ -273,6 +275,7 @@ def dense_roofline(summary, steps_timed, precision, world_note=""):
                 "bound": "mfma", "achieved": round(dense_tf, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(dense_tf / FP32_MFMA_PEAK_TF, 4), "GFLOP_per_step": round(gemm_flops / 1e9, 1),
                 "ms_per_step": round(gemm_ms, 3)}, kernels
+    attainable = BF16_MFMA_ATTAINABLE_TF if precision == "bf16" else F16_MFMA_ATTAINABLE_TF
     kname = {"bf16": "mlp_chain_kernel<PL=1> (fused layer chains, one bf16 plane) + mlp_heads_kernel<PL=1> + "
                      "mlp_gemm_f16x2_kernel<PL=1> (v_mfma_f32_32x32x16_bf16, ONE product per MAC: REDUCED "
                      "PRECISION, the configs[4] roofline configuration)",
@@ -289,10 +292,11 @@ def dense_roofline(summary, steps_timed, precision, world_note=""):
             "fp32_equivalent_vs_fp32_mfma_peak": round(dense_tf / FP32_MFMA_PEAK_TF, 4),
             "GFLOP_per_step_fp32_equivalent": round(gemm_flops / 1e9, 1), "ms_per_step": round(gemm_ms, 3),
             "timed_passes": steps_timed,
-            "attainable": {"TFLOPs": F16_MFMA_ATTAINABLE_TF, "of_peak": round(F16_MFMA_ATTAINABLE_TF / BF16_MFMA_PEAK_TF, 4),
-                           "source": "profiles/r05_mfma_ceiling.md: this loop (A from LDS, W from L2) on random fp16 "
-                                     "operands, hwmon 1.29 kW / 1.81 GHz; registers only 1 681 TF, constant operands 2 436"},
-            "frac_of_attainable": round(products * dense_tf / F16_MFMA_ATTAINABLE_TF, 4),
+            "attainable": {"TFLOPs": attainable, "of_peak": round(attainable / BF16_MFMA_PEAK_TF, 4),
+                           "source": "profiles/r05_mfma_ceiling.md: this precision's inner loop (A fragments from LDS, W "
+                                     "fragments from L2) on random operands under hwmon sampling, 1.29-1.34 kW / 1.8-1.95 GHz; "
+                                     "f16x2 registers only 1 681 TF, constant operands 2 436"},
+            "frac_of_attainable": round(products * dense_tf / attainable, 4),
             "peak_note": "peak is the nominal 2.4 GHz figure; measured (profiles/r03_power_clock.md: hwmon power / "
                          "clock sensors while each kernel runs back to back) these kernels draw 1.24-1.40 kW of the "
                          "1.40 kW board cap and are clocked at 1.8-2.2 GHz"}, kernels

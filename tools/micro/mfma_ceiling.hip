@@ -73,6 +73,55 @@ __global__ __launch_bounds__(256, 2) void k(const uint4* __restrict__ w, const u
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// The single-plane bf16 form of the chains (configs[4]): ONE product per step, a wave owns FOUR 32-row blocks x 64
+// channels (8 x v_mfma_f32_32x32x16_bf16 per step: 4 A fragments from LDS, 2 W fragments from L2).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int RING, bool LDSR, bool GLD>
+__global__ __launch_bounds__(256, 2) void kb(const uint4* __restrict__ w, const uint4* __restrict__ a, float* out,
+                                             int steps, int wstride) {
+  extern __shared__ uint4 lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = a[i];
+  __syncthreads();
+  f32x16 acc[2][4];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 4; ++j)
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const uint4* wl = w + (size_t)wave * wstride + lane;
+  uint4 ring[RING][2], aring[RING][4];
+  for (int d = 0; d < RING; ++d) {
+    for (int q = 0; q < 2; ++q) ring[d][q] = wl[(d * 2 + q) * 64];
+    for (int q = 0; q < 4; ++q) aring[d][q] = lds[d * 256 + lane + 64 * q];
+  }
+  for (int s0 = 0; s0 < steps; s0 += RING) {
+#pragma unroll
+    for (int d = 0; d < RING; ++d) {
+      uint4 af[4], bf[2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        af[q] = aring[d][q];
+        if (LDSR) aring[d][q] = lds[((s0 + d + RING) & 15) * 256 + lane + 64 * q];
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        bf[q] = ring[d][q];
+        if (GLD) ring[d][q] = wl[(((s0 + d + RING) & 511) * 2 + q) * 64];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[j]),
+                                                              __builtin_bit_cast(bf16x8, bf[i]), acc[i][j], 0, 0, 0);
+    }
+  }
+  float s = 0;
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 4; ++j)
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 // ---------------------------------------------------------------- sensors (hwmon of the GPU in use)
 static std::string read_file(const std::string& p) {
   FILE* f = fopen(p.c_str(), "r");
@@ -188,18 +237,20 @@ struct Bufs {
   int wstride;
 };
 
-template <int RING, bool LDSR, bool GLD>
+typedef void (*kern_t)(const uint4*, const uint4*, float*, int, int);
+template <int RING, bool LDSR, bool GLD, bool BF16 = false>
 static void run(const char* feed, const char* data, const Bufs& b, const Sensors& sens, double seconds, int blocks) {
-  hipFuncSetAttribute(reinterpret_cast<const void*>(&k<RING, LDSR, GLD>),
-                      hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  kern_t kf = BF16 ? (kern_t)&kb<RING, LDSR, GLD> : (kern_t)&k<RING, LDSR, GLD>;
+  const double mfma_per_step = BF16 ? 8.0 : 12.0;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
   const int steps = 4096;
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  k<RING, LDSR, GLD><<<blocks, 256, 65536>>>(b.w, b.a, b.out, 64, b.wstride);
+  kf<<<blocks, 256, 65536>>>(b.w, b.a, b.out, 64, b.wstride);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  for (int i = 0; i < 3; ++i) k<RING, LDSR, GLD><<<blocks, 256, 65536>>>(b.w, b.a, b.out, steps, b.wstride);
+  for (int i = 0; i < 3; ++i) kf<<<blocks, 256, 65536>>>(b.w, b.a, b.out, steps, b.wstride);
   hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms;
@@ -207,16 +258,16 @@ static void run(const char* feed, const char* data, const Bufs& b, const Sensors
   const int n = (int)(seconds * 1e3 / (ms / 3)) + 1;
   Sampler smp(sens);
   hipEventRecord(e0);
-  for (int i = 0; i < n; ++i) k<RING, LDSR, GLD><<<blocks, 256, 65536>>>(b.w, b.a, b.out, steps, b.wstride);
+  for (int i = 0; i < n; ++i) kf<<<blocks, 256, 65536>>>(b.w, b.a, b.out, steps, b.wstride);
   hipEventRecord(e1);
   hipDeviceSynchronize();
   Stats st = smp.finish();
   hipEventElapsedTime(&ms, e0, e1);
-  const double flops = (double)n * steps * 12.0 * blocks * 4 * 32768.0;
+  const double flops = (double)n * steps * mfma_per_step * blocks * 4 * 32768.0;
   const double tf = flops / ms / 1e9;
   // an MFMA of 32 x 32 x 16 occupies the SIMD's matrix pipe for 8 passes x 4 cycles: rate in MFMA-busy cycles per
   // second and SIMD, i.e. the clock the pipe would need if it never idled
-  const double busy_mhz = (double)n * steps * 12.0 * blocks * 4 * 32.0 / 1024.0 / (ms * 1e-3) / 1e6;
+  const double busy_mhz = (double)n * steps * mfma_per_step * blocks * 4 * 32.0 / 1024.0 / (ms * 1e-3) / 1e6;
   printf("| %s | %s | %.0f | %.3f | %.0f | %.0f | %.0f | %.0f | %.0f | %d |\n", feed, data, tf, tf / 2500.0,
          st.w_mean, st.w_max, st.mhz_mean, st.mhz_min, busy_mhz, st.n);
   fflush(stdout);
@@ -271,5 +322,22 @@ int main(int argc, char** argv) {
   }
   // one workgroup per CU (one wave per SIMD), the product loop, random data: what half the occupancy costs
   run<4, true, true>("+ both, ONE wave per SIMD", dn[1], b[1], sens, seconds, prop.multiProcessorCount);
+  // the single-plane bf16 form (configs[4]): random bf16 operands (the same bit patterns read as bf16 are not normal
+  // numbers: a buffer of its own)
+  {
+    Bufs bb = b[1];
+    std::vector<uint16_t> hw(wn * 8), ha(an * 8);
+    auto f2bf = [](float x) { uint32_t u; memcpy(&u, &x, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
+    for (auto& v : hw) v = f2bf(nd(rng));
+    for (auto& v : ha) v = f2bf(nd(rng));
+    hipMemcpy(bb.w, hw.data(), wn * 16, hipMemcpyHostToDevice);
+    hipMemcpy(bb.a, ha.data(), an * 16, hipMemcpyHostToDevice);
+    printf("\n| bf16 single-plane loop (per step and wave: 8 MFMA 32x32x16 bf16, 4 row blocks x 64 channels) | operand data | TFLOP/s | of 2.5 PF "
+           "| W mean | W max | sclk MHz mean | sclk MHz min | MFMA-busy MHz per SIMD | samples |\n|---|---|---:|---:|---:|---:|---:|---:|---:|---:|\n");
+    run<2, false, false, true>("registers only (ring of 2 operand sets)", "random bf16 (normal)", bb, sens, seconds, blocks);
+    run<2, true, false, true>("+ A fragments from LDS (4 x ds_read_b128)", "random bf16 (normal)", bb, sens, seconds, blocks);
+    run<2, false, true, true>("+ W fragments from L2 (2 x global_load_dwordx4)", "random bf16 (normal)", bb, sens, seconds, blocks);
+    run<2, true, true, true>("+ both: the bf16 chains' loop", "random bf16 (normal)", bb, sens, seconds, blocks);
+  }
   return 0;
 }
