@@ -31,9 +31,11 @@ def bound_rccl_channels():
     return os.environ["NCCL_MAX_NCHANNELS"]
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, bound_channels=False):
     """Initialise the default process group from torchrun's environment.
-    Returns (rank, world, local_rank); a no-op world of 1 without WORLD_SIZE."""
+    Returns (rank, world, local_rank); a no-op world of 1 without WORLD_SIZE.
+    bound_channels: call `bound_rccl_channels()` first (an inference job whose only collective is the per-batch
+    all-gather; NOT the default: the bound is process-wide and would also throttle a training job's all-reduce)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -43,7 +45,8 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
         if backend == "nccl":
-            bound_rccl_channels()
+            if bound_channels:
+                bound_rccl_channels()
             torch.cuda.set_device(local_rank)
             kw["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend=backend, **kw)
