@@ -67,7 +67,7 @@ def pack_outputs(pred):
     chans = [pred[k].shape[1] for k in HEADS]
     packed = getattr(pred, "packed", None)
     if (packed is not None and packed.is_contiguous() and packed.shape[1] == sum(chans) and
-            all(pred[k].data_ptr() == packed.data_ptr() + 4 * packed.shape[2] * c0
+            all(pred[k].data_ptr() == packed.data_ptr() + packed.element_size() * packed.shape[2] * c0
                 for k, c0 in zip(HEADS, [sum(chans[:i]) for i in range(len(chans))]))):
         return packed, chans
     return torch.cat([pred[k] for k in HEADS], dim=1).contiguous(), chans
