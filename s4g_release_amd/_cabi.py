@@ -96,6 +96,7 @@ SIGNATURES = {
     "s4g_three_interpolate_f64": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp]),
     "s4g_three_interpolate_backward_f64": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "s4g_scatter_det_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "s4g_scatter_det_workspace_bytes_c": (_sz, [_i64, _i64, _i64, _i64, _int]),
     "s4g_group_points_backward_det_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "s4g_three_interpolate_backward_det_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "s4g_group_rel_xyz_i32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),

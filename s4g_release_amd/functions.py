@@ -50,9 +50,10 @@ def set_backward_mode(mode):
     _BACKWARD_MODE = mode
 
 
-def _scatter_ws(dev, B, N, T):
-    """Workspace of the deterministic scatters, or (None, 0) where the sizes are outside their 32-bit keys."""
-    nbytes = _cabi.lib().s4g_scatter_det_workspace_bytes(B, N, T)
+def _scatter_ws(dev, B, N, T, C=0, weighted=False):
+    """Workspace of the deterministic scatters (with room for the channels-last copy of the gradients from 32 channels
+    on), or (None, 0) where the sizes are outside their 32-bit keys."""
+    nbytes = _cabi.lib().s4g_scatter_det_workspace_bytes_c(B, C, N, T, int(weighted))
     if nbytes == 0:
         return None, 0
     return torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes
@@ -357,7 +358,7 @@ def _group_points_backward(grad_output, index, num_points):
         raise RuntimeError("index shape does not match grad_output")  # :120-122
     gin = torch.empty((B, C, int(num_points)), dtype=torch.float32, device=grad_output.device)
     with torch.cuda.device(grad_output.device):
-        ws, nbytes = _scatter_ws(grad_output.device, B, int(num_points), M * K) \
+        ws, nbytes = _scatter_ws(grad_output.device, B, int(num_points), M * K, C) \
             if _BACKWARD_MODE == "deterministic" and gin.numel() > 0 else (None, 0)
         if ws is not None:
             rc = _cabi.lib().s4g_group_points_backward_det_f32(_ptr(grad_output), _ptr(index), B, C, int(num_points),
@@ -483,7 +484,7 @@ def _interpolate_backward(grad_output, index, weight, num_inst):
         raise RuntimeError("index / weight must be (batch_size, N, 3)")  # :307-311
     gin = torch.empty((B, C, int(num_inst)), dtype=torch.float32, device=grad_output.device)
     with torch.cuda.device(grad_output.device):
-        ws, nbytes = _scatter_ws(grad_output.device, B, int(num_inst), 3 * N1) \
+        ws, nbytes = _scatter_ws(grad_output.device, B, int(num_inst), 3 * N1, C, True) \
             if _BACKWARD_MODE == "deterministic" and gin.numel() > 0 else (None, 0)
         if ws is not None:
             rc = _cabi.lib().s4g_three_interpolate_backward_det_f32(_ptr(grad_output), _ptr(index), _ptr(weight), B, C,
