@@ -50,8 +50,9 @@ extern "C" {
  * 9: s4g_heads_desc_t.out_batch_stride (the four heads written as channel slices of one packed
  *    (B, 21, N) tensor: the all-gather payload of the multi-GPU path without a packing copy).
  * 10: s4g_group_points_backward_det_f32 / s4g_three_interpolate_backward_det_f32 / s4g_scatter_det_workspace_bytes
- *    (the backward scatters in a fixed order: run-to-run bit-identical, equal to the oracle's sequential sum). */
-#define S4G_ABI_VERSION 10
+ *    (the backward scatters in a fixed order: run-to-run bit-identical, equal to the oracle's sequential sum).
+ * 11: s4g_heads_desc_t.head_mask (a launch may evaluate a subset of the four heads). */
+#define S4G_ABI_VERSION 11
 
 /* ---------------------------------------------------------------------------
  * Environment knobs (round 4: the complete list; everything else that used to be read from the
@@ -469,6 +470,10 @@ typedef struct s4g_heads_desc {
    * slices of ONE packed (B, C_total, N) tensor -- out[h] = packed + first_channel_h * N, out_batch_stride =
    * C_total * N -- which is what the multi-GPU path all-gathers (dist.py), so no copy packs the outputs. */
   int64_t out_batch_stride;
+  /* ABI >= 11, optional: bit h set = evaluate head h; 0 = all four.  Heads that are not evaluated leave their out[h]
+   * untouched (it may be NULL).  A serving path that only decodes the best-scoring points runs the score head (bit 0) on
+   * every point and the pose heads (bits 1..3) on the points it keeps: FusedPointNet2(..., topk=). */
+  int32_t head_mask;
 } s4g_heads_desc_t;
 
 int s4g_heads_chain_f32(const s4g_heads_desc_t *desc, s4g_stream_t stream);

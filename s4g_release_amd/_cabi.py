@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # declared symbol are checked either way
 LIB_PATH = os.environ.get("S4G_HIP_LIB") or os.path.join(_HERE, "libs4g_hip.so")
 
-S4G_ABI_VERSION = 10
+S4G_ABI_VERSION = 11
 S4G_EUNSUPPORTED = -3
 S4G_FLAG_FMAD = 1
 S4G_OP_FPS, S4G_OP_BALL_QUERY, S4G_OP_THREE_NN = 1, 2, 3
@@ -60,7 +60,7 @@ class HeadsDesc(ctypes.Structure):
         ("a_amax", _vp), ("a_amax_floor", _f32), ("rows_per_scene", _i32),
         ("pre_W_frag", _vp * 2), ("pre_bias", _vp * 2), ("pre_w_inv_scale", _vp * 2),
         ("pre_nidx", _vp), ("pre_nw", _vp), ("pre_sparse", _vp), ("pre_dense", _vp),
-        ("pre_lbias", _vp), ("pre_a_amax2", _vp), ("pre_N2", _i32), ("out_batch_stride", _i64),
+        ("pre_lbias", _vp), ("pre_a_amax2", _vp), ("pre_N2", _i32), ("out_batch_stride", _i64), ("head_mask", _i32),
     ]
 
 

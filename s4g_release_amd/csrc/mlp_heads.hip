@@ -48,6 +48,7 @@ struct HeadsParams {
   float* out[4];
   int ch[4];
   long long obs[4];        // floats between two scenes' blocks of out[h] (ch[h] * N, or the packed tensor's C_total * N)
+  int head_mask;           // bit h: evaluate head h (1 .. 15; the others' outputs are not touched)
   int sigmoid_head;
   const float* a_amax;     // per-scene maxima of X (PL == 2); PRE: of the sparse features
   float a_floor;
@@ -120,9 +121,13 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
   const WRef wp0 = PRE ? wref(p.Wp[0], woff(wv, 16, 0)) : wrs[0];
   const WRef wp1 = PRE ? wref(p.Wp[1], woff(wv, 16, 0)) : wrs[0];
 
+  // the heads this launch evaluates, in ascending order (head_mask: all four by default; a serving path may ask for the
+  // score head alone on every point and for the pose heads on the points it keeps: FusedPointNet2(..., topk=))
+  const int hmask = p.head_mask;
+  const int g_first = __builtin_ctz(hmask);
   uint4 ring[HD_RING][PL];
   {
-    const WRef w = PRE ? wp0 : w0(0, 0);
+    const WRef w = PRE ? wp0 : w0(g_first, 0);
 #pragma unroll
     for (int d = 0; d < HD_RING; ++d)
 #pragma unroll
@@ -338,12 +343,15 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
     S4G_HD_STRIP(PA, NRBT, 0, wp0, 16, wp1)
     panel_epilogue(full{}, 0, wv * 32);
     stage_sb2(p.wsc_p[1], p.bias_p[1], wv * 32, inv_sh);
-    S4G_HD_STRIP(PB, NRBT, 0, wp1, 16, w0(0, 0))
+    S4G_HD_STRIP(PB, NRBT, 0, wp1, 16, w0(g_first, 0))
     panel_epilogue_to(PA, full{}, 0, wv * 32);
     inv_sa = inv_sh;
   }
 
-  for (int g = 0; g < 4; ++g) {
+  for (int g = g_first, gn; g >= 0; g = gn) {
+    const int rest = hmask >> (g + 1);
+    gn = rest ? g + 1 + __builtin_ctz(rest) : -1;      // the next head of this launch
+    const int gnx = gn >= 0 ? gn : g;                  // whose first fragments the last strips prefetch (the last head: its own again)
     f32x16 acc1[NRBT];   // heads.1 accumulated over the two halves of its 512 inputs, in units of 1 / w_scale
     // ---- heads.0 half 0 -> B;  heads.1 over that half
     stage_sb(0, g * 512 + wv * 32, inv_sa);
@@ -381,14 +389,14 @@ __global__ __launch_bounds__(512, 2) void mlp_heads_kernel(const HeadsParams p) 
     {
       const int row3 = (wv >> 2) * (BM / 2), cg = wv & 3;
       stage_sb(3, g * 128 + cg * 32, inv_sh);
-      const WRef after = wv < NRBT ? wl(g) : w0(g < 3 ? g + 1 : g, 0);
+      const WRef after = wv < NRBT ? wl(g) : w0(gnx, 0);
       S4G_HD_STRIP(PB, NRBT / 2, row3, w3(g), 16, after)
       panel_epilogue(half{}, row3, cg * 32);
     }
     // ---- logits: waves 0 .. NRBT - 1, one 32-position block each; (B, c, N) channel-first stores
     if (wv < NRBT) {
       stage_sb(4, g * 32, inv_sh);
-      S4G_HD_STRIP(PB, 1, wv * 32, wl(g), 8, w0(g < 3 ? g + 1 : g, 0))
+      S4G_HD_STRIP(PB, 1, wv * 32, wl(g), 8, w0(gnx, 0))
       const int row = p0 + wv * 32 + li;
       const int b = row / p.N, pt = row - b * p.N;
       const int nch = p.ch[g];
@@ -454,7 +462,13 @@ extern "C" int s4g_heads_chain_f32(const s4g_heads_desc_t* d, s4g_stream_t strea
     p.bias[l] = d->bias[l];
     p.wsc[l] = d->w_inv_scale[l];
   }
+  p.head_mask = d->head_mask ? d->head_mask : 15;
+  if (p.head_mask < 0 || p.head_mask > 15) return S4G_EINVAL;
   for (int h = 0; h < 4; ++h) {
+    p.out[h] = nullptr;
+    p.ch[h] = 0;
+    p.obs[h] = 0;
+    if (!((p.head_mask >> h) & 1)) continue;
     if (!d->out[h] || d->channels[h] <= 0 || d->channels[h] > 32) return S4G_EINVAL;
     p.out[h] = d->out[h];
     p.ch[h] = d->channels[h];

@@ -426,7 +426,7 @@ class FusedPointNet2:
             rc = _cabi.lib().s4g_mlp_gemm_f32(ctypes.byref(d), _F._stream())
         _cabi.check(rc, "mlp_gemm " + name)
 
-    def _heads(self, x, x_amax, outs, B, N0, pre=None):
+    def _heads(self, x, x_amax, outs, B, N0, pre=None, head_mask=0):
         """heads.0 .. heads.3 + logits of all four heads: one launch (s4g_heads_chain_f32).
         pre: the last FP level's tail rides in front (its loader state + its two 256-wide layers):
         the per-point feature tensor between the FP stack and the heads never exists in HBM."""
@@ -453,23 +453,30 @@ class FusedPointNet2:
             d.pre_a_amax2 = None if pre["a_amax2"] is None else pre["a_amax2"].data_ptr()
             x_amax = pre["a_amax"]
             name = "%s+%s" % (pre["name"], name)
+        nrun = len([h for h in range(4) if (head_mask or 15) >> h & 1])
         for l, layer in enumerate(self.heads_fused):
             d.W_frag[l] = (layer.Wfrag_bf16 if bf16 else layer.Wfrag).data_ptr()
             d.bias[l] = layer.bias.data_ptr()
             d.w_inv_scale[l] = layer.w_inv_scale.data_ptr()
-            if l < 4:
-                flops += 2.0 * B * N0 * layer.cout * layer.cin * layer.groups
-        flops += 2.0 * B * N0 * sum(self.head_channels) * 128      # the logit layers' real channels
+            if l < 4:     # (layer 0 is the four first layers stacked along Cout, the others are grouped by head)
+                flops += 2.0 * B * N0 * layer.cout * layer.cin * layer.groups * nrun / 4.0
+        flops += 2.0 * B * N0 * sum(c for h, c in enumerate(self.head_channels) if (head_mask or 15) >> h & 1) * 128
+        d.head_mask = head_mask
+        run = [h for h in range(4) if (head_mask or 15) >> h & 1]
         for h, o in enumerate(outs):
-            d.out[h] = o.data_ptr()
             d.channels[h] = self.head_channels[h]
+            if h not in run:
+                continue
+            d.out[h] = o.data_ptr()
             if o.stride(0) != self.head_channels[h] * N0:    # channel slices of the packed (B, 21, N) tensor
                 d.out_batch_stride = o.stride(0)
         d.sigmoid_head = 3
         d.a_amax = None if x_amax is None else x_amax.data_ptr()
         d.a_amax_floor = 0.0 if pre is None else pre["a_amax_floor"]
         d.rows_per_scene = N0
-        with _F._timed("gemm[%s P=%d K=256 N=4x(512,256,256,128,c)]" % (name, B * N0), 0, flops):
+        if head_mask not in (0, 15):
+            name += "[heads %s]" % "".join(str(h) for h in range(4) if head_mask >> h & 1)
+        with _F._timed("gemm[%s P=%d K=256 N=%dx(512,256,256,128,c)]" % (name, B * N0, nrun), 0, flops):
             rc = _cabi.lib().s4g_heads_chain_f32(ctypes.byref(d), _F._stream())
         _cabi.check(rc, "heads_chain")
 
@@ -644,7 +651,7 @@ class FusedPointNet2:
             sparse_xyz = dense_xyz
         return geo
 
-    def _dense(self, xyz, geo):
+    def _dense(self, xyz, geo, topk=None):
         """The shared-MLP contractions of every layer (MFMA).
 
         f16x2 precision: every launch leaves max|out| PER SCENE in a (B, 64)-slot block of
@@ -870,6 +877,10 @@ class FusedPointNet2:
         P = B * N0
         x, x_amax = sparse_feat, sparse_amax
         names = ("score", "frame_R", "frame_t", "movable_logits")
+        if topk is not None:
+            if self.heads_fused is None or heads_pre is None:
+                raise NotImplementedError("topk= needs the one-launch heads with the FP tail in front (the shipped widths)")
+            return self._heads_topk(heads_pre, B, N0, int(topk), dev)
         if self.heads_fused is not None and (heads_pre is not None or x.shape[1] == 256):
             packed, outs = self._head_outputs(B, N0, dev)
             self._heads(x, x_amax, outs, B, N0, pre=heads_pre)
@@ -920,6 +931,36 @@ class FusedPointNet2:
                    cf_sigmoid_from=self.sigmoid_from, cf_N=N0, a_amax=x_amax)
         return PackedPred(zip(names, outs), packed=packed)
 
+    def _heads_topk(self, pre, B, N0, K, dev):
+        """The heads for a serving path that only decodes a scene's best-scoring points (row f1): the score head
+        (+ the FP tail in front of it) on EVERY point, then the rotation / translation / movable heads on the K points
+        per scene with the largest expected score -- the heads are 46 % of a step and three quarters of them is work
+        on points nobody decodes.  Same kernel both times (`s4g_heads_desc_t.head_mask`, ABI 11); the second launch
+        re-forms its panel from the gathered interpolation indices / weights / skip rows of the kept points, so nothing
+        per-point is stored in between.  Returns a PackedPred over the kept points: score / frame_R / frame_t /
+        movable_logits as (B, c, K) slices of one packed tensor, plus "index" (B, K) int64, best first.  The kept
+        points' values are the full forward's up to the hidden layers' per-tile scales (f16x2: 1e-7 of the output
+        scale; tests/test_sparse_heads_gpu.py)."""
+        K = min(K, N0)
+        score = torch.empty((B, self.head_channels[0], N0), dtype=torch.float32, device=dev)
+        self._heads(None, None, [score, None, None, None], B, N0, pre=pre, head_mask=1)
+        # the expected score over the classes decides -- the decode's own kernel and class values, so that its top-K of
+        # the kept points is its top-K of the scene (the detector's convention differs by a constant: same order)
+        from . import postprocess as _pp
+        es = _pp.expected_score(score, "demo")                                     # (B, N0)
+        sel = torch.topk(es, K, dim=1, largest=True, sorted=True)[1]               # (B, K), best first
+        flat = (sel + torch.arange(B, device=dev).view(B, 1) * N0).reshape(-1)     # rows of the (B N0, .) tensors
+        sub = dict(pre, nidx=pre["nidx"].reshape(B * N0, 3).index_select(0, flat).contiguous(),
+                   nw=pre["nw"].reshape(B * N0, 3).index_select(0, flat).contiguous(),
+                   dense=None if pre["dense"] is None else pre["dense"].index_select(0, flat).contiguous())
+        packed = torch.empty((B, sum(self.head_channels), K), dtype=torch.float32, device=dev)
+        outs = list(packed.split(self.head_channels, dim=1))
+        outs[0].copy_(torch.gather(score, 2, sel.unsqueeze(1).expand(-1, score.shape[1], -1)))
+        self._heads(None, None, outs, B, K, pre=sub, head_mask=0b1110)
+        pred = PackedPred(zip(("score", "frame_R", "frame_t", "movable_logits"), outs), packed=packed)
+        pred["index"] = sel
+        return pred
+
     def _head_outputs(self, B, N0, dev):
         """(packed (B, sum c_h, N) tensor or None, the four (B, c_h, N) head tensors -- its channel slices)."""
         if not self.packed_out:
@@ -928,7 +969,7 @@ class FusedPointNet2:
         return packed, list(packed.split(self.head_channels, dim=1))
 
     @torch.no_grad()
-    def submit(self, data_batch):
+    def submit(self, data_batch, topk=None):
         """Enqueue one forward pass and return a `Handle` without waiting.
 
         The coordinate-only work (FPS pyramid, ball queries, 3-NN) runs on a
@@ -966,7 +1007,7 @@ class FusedPointNet2:
                 geo["done"] = gs.record_event()
             ds.wait_event(ev_in)
             with torch.cuda.stream(ds):
-                pred = self._dense(xyz, geo)
+                pred = self._dense(xyz, geo, topk=topk)
                 ev_out = ds.record_event()
             # tensors cross streams: tell the caching allocator
             xyz.record_stream(gs)
@@ -987,8 +1028,8 @@ class FusedPointNet2:
         """Record one forward pass of `example_batch`'s shape as a HIP graph: see `GraphedForward`."""
         return GraphedForward(self, example_batch)
 
-    def __call__(self, data_batch, return_intermediates=False):
-        h = self.submit(data_batch)
+    def __call__(self, data_batch, return_intermediates=False, topk=None):
+        h = self.submit(data_batch, topk=topk)
         pred = h.result()
         if return_intermediates:
             inter = {}

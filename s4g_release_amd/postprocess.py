@@ -37,9 +37,24 @@ def expected_score(score_logits, convention="demo"):
     return out
 
 
+def _kept_points(predictions, scene_points):
+    """Predictions of `FusedPointNet2(..., topk=K)` cover a scene's K best-scoring points only and carry their point
+    numbers in "index": (those points' coordinates (B, 3, K), index) -- or (scene_points, None) for a full forward."""
+    idx = predictions.get("index") if hasattr(predictions, "get") else None
+    if idx is None:
+        return scene_points, None
+    return torch.gather(scene_points, 2, idx.unsqueeze(1).expand(-1, 3, -1)).contiguous(), idx
+
+
 def decode_top_poses(predictions, scene_points, num_poses=50, convention="demo"):
     """-> (H (B,K,4,4) fp32, score (B,K) fp32, index (B,K) int64), best first
-    (file_logger_cls.py:196-218: K = 50, argsort(-score)[:K], Gram-Schmidt)."""
+    (file_logger_cls.py:196-218: K = 50, argsort(-score)[:K], Gram-Schmidt).  Predictions over a scene's kept points
+    (`FusedPointNet2(..., topk=)`) are accepted too: the returned index numbers the scene's points either way."""
+    scene_points, kept = _kept_points(predictions, scene_points)
+    if kept is not None:
+        H, top, sel = decode_top_poses({k: v for k, v in predictions.items() if k != "index"}, scene_points,
+                                       num_poses, convention)
+        return H, top, torch.gather(kept, 1, sel)
     xyz = _F._f32c(scene_points, "scene_points")
     R = _F._f32c(predictions["frame_R"], "frame_R")
     t = _F._f32c(predictions["frame_t"], "frame_t")
@@ -143,6 +158,16 @@ def detect_poses(predictions, scene_points, score_threshold=0.7, verticalness_th
     :149-167 actually compute (a position list used as point indices and a numpy transpose that is
     a no-op; see `_detect_poses_as_written`): same poses, scores and order as the reference, pinned
     by tests/golden/post_detector.npz which the reference's own function generated."""
+    scene_points, kept = _kept_points(predictions, scene_points)
+    if kept is not None:
+        # (exact whenever the kept points contain every candidate the filters would pass among the best max_poses:
+        #  always when fewer than K points of a scene exceed the score threshold)
+        if reference_indexing:
+            raise ValueError("reference_indexing=True restates the reference's point-axis quirks: it needs the full forward")
+        H, top, sel, count = detect_poses({k: v for k, v in predictions.items() if k != "index"}, scene_points,
+                                          score_threshold, verticalness_threshold, direction_matrix=direction_matrix,
+                                          vertical_direction=vertical_direction, frame=frame, max_poses=max_poses)
+        return H, top, torch.where(sel >= 0, torch.gather(kept, 1, sel.clamp(min=0)), sel), count
     if reference_indexing:
         return _detect_poses_as_written(predictions, scene_points, score_threshold, verticalness_threshold,
                                         direction_matrix, vertical_direction, frame, max_poses)
