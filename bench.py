@@ -35,6 +35,8 @@ Extra objects on the line:
                 only the extension buys), scenes/s
   precision_legs  the fast path in true-fp32 MFMA and exact 3 x bf16 arithmetic on the same batch
   mixed_batch   2 of the 16 scenes tie-heavy: the conditional level-2 / level-3 FPS samplers run timed
+  kept_points   clouds in, 50 grasp frames per scene out with the pose heads evaluated on the 2 048 best-scoring points
+                per scene only (FusedPointNet2(..., topk=)), next to the full forward + decode; NOT the headline
   collective    the per-batch all-gather: payload (--gather heads | poses), bytes, the stream it ran on
   distributed   world, communicator size, every rank's scene range and device (self-verifying)
   cpu_baseline  the CPU oracle forward (oracle/pn2_forward.py) on ONE scene,
@@ -489,7 +491,7 @@ def main():
     roofline_dense, kernels = dense_roofline(summary, timed_passes, precision)
 
     N, M, K = args.points, cfg.num_centroids[0], cfg.num_neighbours[0]
-    roofline = latency = io = configs4 = modules_path = precision_legs = mixed_batch = None
+    roofline = latency = io = configs4 = modules_path = precision_legs = mixed_batch = kept_points = None
     # (the single-GPU probes below run at N = 1 only: at N > 1 the other ranks have left, rank 0 prints its line
     #  and tears the communicator down without making the job wait for figures the N = 1 line already carries)
     if not args.no_extras and world == 1:
@@ -671,6 +673,49 @@ def main():
                                         "warmup": p_warm, "roofline_frac": p_roof["frac"] if p_roof else None,
                                         "roofline_peak_TFLOPs": p_roof["peak"] if p_roof else None}
                 del p_runner
+            # ---- clouds in, grasp frames out, with the heads evaluated where the decode reads them: the
+            # score head on every point, the rotation / translation / movable heads on the 2 048 best-scoring points per
+            # scene (FusedPointNet2(..., topk=): the same top-50 frames as the full forward + decode,
+            # tests/test_sparse_heads_gpu.py), then the device-side top-50 decode -- pipelined like the headline run.
+            # NOT the headline: the headline leaves all 21 channels of every point in HBM.
+            from s4g_release_amd import postprocess as PP
+
+            class _KeptPoints:
+                def __init__(self, r, k, poses):
+                    self.r, self.k, self.poses = r, k, poses
+
+                class _H:
+                    def __init__(self, h, data, poses):
+                        self.h, self.data, self.poses = h, data, poses
+
+                    def result(self):
+                        return PP.decode_top_poses(self.h.result(), self.data["scene_points"], self.poses)
+
+                def submit(self, data):
+                    return self._H(self.r.submit(data, topk=self.k), data, self.poses)
+
+                def __call__(self, data):
+                    return self.submit(data).result()
+            k_steps, k_warm, k_keep = 20, 5, 2048
+            kp_el, kp_step, kp_sum, kp_tp = timed_region(k_steps, k_warm, collective=False, run=_KeptPoints(runner, k_keep, 50),
+                                                         data=batch, gathered=False)
+            kp_roof, _ = dense_roofline(kp_sum, kp_tp, precision)
+            with torch.no_grad():
+                f_el, _, _, _ = timed_region(k_steps, k_warm, collective=False, timers=False,
+                                             run=type("_FullDecode", (), {
+                                                 "submit": lambda self, d: _KeptPoints._H(runner.submit(d), d, 50),
+                                                 "__call__": lambda self, d: PP.decode_top_poses(runner(d), d["scene_points"], 50)})(),
+                                             data=batch, gathered=False)
+            kept_points = {"workload": "clouds in, the 50 best grasp frames per scene out: score head on every point, pose heads "
+                                       "on the %d best-scoring points per scene, device-side decode; same %d scenes, pipelined"
+                                       % (k_keep, B),
+                           "value": round(B * k_steps / kp_el, 2), "unit": "scenes/sec",
+                           "ms_per_step": round(1e3 * kp_el / k_steps, 3), "step_ms_median": kp_step["median"],
+                           "steps": k_steps, "warmup": k_warm, "kept_points_per_scene": k_keep, "poses_per_scene": 50,
+                           "contraction_ms_per_step": kp_roof["ms_per_step"] if kp_roof else None,
+                           "full_forward_plus_decode": {"value": round(B * k_steps / f_el, 2),
+                                                        "ms_per_step": round(1e3 * f_el / k_steps, 3)},
+                           "note": "not the headline metric: the headline forward leaves all 21 channels of every point"}
             # ---- a batch that is NOT all "proven": 2 of the 16 scenes are `lattice` clouds (coordinates
             # snapped to a 3.9 mm lattice: exact distance ties), so the FPS prefix check refuses them and
             # the level-2 / level-3 samplers run inside the timed region (the headline's scenes all pass)
@@ -793,7 +838,7 @@ def main():
         # `roofline_ball_query_group_points`: the HBM-bound operator pair the north star names.
         "roofline": roofline_dense, "roofline_ball_query_group_points": roofline,
         "configs4": configs4, "modules_path": modules_path, "precision_legs": precision_legs,
-        "mixed_batch": mixed_batch, "collective": collective, "distributed": shards,
+        "mixed_batch": mixed_batch, "kept_points": kept_points, "collective": collective, "distributed": shards,
         "step_ms": step_ms, "latency": latency, "io": io, "kernels": kernels,
         "cpu_baseline": cpu_baseline,
     }

@@ -25,10 +25,23 @@ def score_values(num_classes, convention="demo"):
     return (v[:-1] if convention == "demo" else v[1:]).float()
 
 
+_DEV_CONST = {}
+
+
+def _dev_const(key, make, device):
+    """Small constant tensors on the device, created once: a host -> device copy from pageable memory makes the HOST wait
+    for everything queued in front of it on the stream (measured: a pipelined submit went from 0.6 to 10 ms of host time)."""
+    k = (key, str(device))
+    t = _DEV_CONST.get(k)
+    if t is None:
+        t = _DEV_CONST[k] = make().to(device)
+    return t
+
+
 def expected_score(score_logits, convention="demo"):
     logits = _F._f32c(score_logits, "score")
     B, C, N = logits.shape
-    vals = score_values(C, convention).to(logits.device)
+    vals = _dev_const(("score_values", C, convention), lambda: score_values(C, convention), logits.device)
     out = torch.empty((B, N), dtype=torch.float32, device=logits.device)
     with torch.cuda.device(logits.device):
         rc = _cabi.lib().s4g_expected_score_f32(logits.data_ptr(), B, C, N, vals.data_ptr(),
@@ -63,7 +76,7 @@ def decode_top_poses(predictions, scene_points, num_poses=50, convention="demo")
     K = min(int(num_poses), N)
     top, sel = torch.topk(score, K, dim=1, largest=True, sorted=True)
     sel = sel.contiguous()
-    bins = torch.tensor(T_BINS[:t.shape[1]], dtype=torch.float32, device=xyz.device)
+    bins = _dev_const(("t_bins", t.shape[1]), lambda: torch.tensor(T_BINS[:t.shape[1]], dtype=torch.float32), xyz.device)
     H = torch.empty((B, K, 4, 4), dtype=torch.float32, device=xyz.device)
     with torch.cuda.device(xyz.device):
         rc = _cabi.lib().s4g_decode_poses_f32(xyz.data_ptr(), R.data_ptr(), t.data_ptr(),
@@ -189,7 +202,7 @@ def detect_poses(predictions, scene_points, score_threshold=0.7, verticalness_th
     top, sel = torch.sort(key, dim=1, descending=True, stable=True)
     top, sel = top[:, :K], sel[:, :K].contiguous()
     count = keep.sum(dim=1).clamp(max=K)
-    bins = torch.tensor(T_BINS[:t.shape[1]], dtype=torch.float32, device=dev)
+    bins = _dev_const(("t_bins", t.shape[1]), lambda: torch.tensor(T_BINS[:t.shape[1]], dtype=torch.float32), dev)
     H = torch.empty((B, K, 4, 4), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = _cabi.lib().s4g_decode_poses_f32(xyz.data_ptr(), R.data_ptr(), t.data_ptr(),
