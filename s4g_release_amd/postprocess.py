@@ -38,6 +38,16 @@ def _dev_const(key, make, device):
     return t
 
 
+def _small_on_device(x, dtype, device):
+    """A caller's small matrix / vector (nested tuples, numpy, CPU tensor) on the device WITHOUT a per-call host -> device
+    copy: cached by value (a tensor already on the device passes through)."""
+    if isinstance(x, torch.Tensor) and x.device == device:
+        return x.to(dtype)
+    t = torch.as_tensor(x, dtype=torch.float64)
+    key = ("small", tuple(t.flatten().tolist()), tuple(t.shape), str(dtype))
+    return _dev_const(key, lambda: t.to(dtype), device)
+
+
 def expected_score(score_logits, convention="demo"):
     logits = _F._f32c(score_logits, "score")
     B, C, N = logits.shape
@@ -190,9 +200,9 @@ def detect_poses(predictions, scene_points, score_threshold=0.7, verticalness_th
     score = expected_score(predictions["score"], "detector")                    # (B, N)
     B, _, N = xyz.shape
     dev = xyz.device
-    dm = torch.eye(3, device=dev) if direction_matrix is None else \
-        torch.as_tensor(direction_matrix, dtype=torch.float32, device=dev)
-    v = torch.as_tensor(vertical_direction, dtype=torch.float32, device=dev)
+    dm = _small_on_device(((1., 0., 0.), (0., 1., 0.), (0., 0., 1.)) if direction_matrix is None else direction_matrix,
+                          torch.float32, dev)
+    v = _small_on_device(vertical_direction, torch.float32, dev)
     w = -(dm.t() @ v)                                                           # (-A r0) . v == r0 . (-A^T v)
     r0 = R.view(B, 3, 3, N)[:, :, 0, :]                                         # first column of every R
     vertical = (r0 * w.view(1, 3, 1)).sum(dim=1)                                # (B, N)
@@ -209,7 +219,7 @@ def detect_poses(predictions, scene_points, score_threshold=0.7, verticalness_th
                                               sel.data_ptr(), B, N, K, t.shape[1], bins.data_ptr(),
                                               H.data_ptr(), _F._stream())
     _cabi.check(rc, "decode_poses")
-    fr = torch.as_tensor(frame, dtype=torch.float32, device=dev)
+    fr = _small_on_device(frame, torch.float32, dev)
     H = torch.matmul(fr.view(1, 1, 4, 4), H)
     valid = torch.arange(K, device=dev).view(1, K) < count.view(B, 1)
     H = torch.where(valid.view(B, K, 1, 1), H, torch.zeros_like(H))
