@@ -662,6 +662,7 @@ class FusedPointNet2:
         dev = xyz.device
         self._batch = B
         level_xyz, level_n = geo["level_xyz"], geo["level_n"]
+        keep = geo.get("feats")                      # return_intermediates: every level feature tensor that exists
         n_launch = sum(len(sa["layers"]) for sa in self.sa) + \
             sum(len(fp["layers"]) for fp in self.fp) + len(self.head_layers) + 1 + len(self.sa) + 2 * len(self.fp)
         amax = torch.zeros((n_launch, B, 64), dtype=torch.float32, device=dev)
@@ -744,6 +745,8 @@ class FusedPointNet2:
                 x, x_amax = out, out_amax
             feat, feat_amax = x, x_amax
             level_feat.append((feat, feat_amax))
+            if keep is not None:
+                keep["sa%d" % li] = feat.view(B, M, -1)
 
         cur.wait_event(geo["done"])               # the 3-NN searches of the FP path
         (sparse_feat, sparse_amax), n_sparse = level_feat[-1], level_n[-1]
@@ -872,6 +875,8 @@ class FusedPointNet2:
                     heads0_fused = l3 is not None
                 x, x_amax = out, out_amax
             sparse_feat, sparse_amax, n_sparse = x, x_amax, n_dense
+            if keep is not None and x is not None and not heads0_fused:      # (a level folded into its consumer's launch has no tensor)
+                keep["fp%d" % fi] = x.view(B, n_dense, -1)
 
         # heads
         P = B * N0
@@ -969,7 +974,7 @@ class FusedPointNet2:
         return packed, list(packed.split(self.head_channels, dim=1))
 
     @torch.no_grad()
-    def submit(self, data_batch, topk=None):
+    def submit(self, data_batch, topk=None, keep_feats=False):
         """Enqueue one forward pass and return a `Handle` without waiting.
 
         The coordinate-only work (FPS pyramid, ball queries, 3-NN) runs on a
@@ -1005,6 +1010,8 @@ class FusedPointNet2:
             with torch.cuda.stream(gs):
                 geo = self._geometry(xyz)
                 geo["done"] = gs.record_event()
+                if keep_feats:
+                    geo["feats"] = {}
             ds.wait_event(ev_in)
             with torch.cuda.stream(ds):
                 pred = self._dense(xyz, geo, topk=topk)
@@ -1029,10 +1036,13 @@ class FusedPointNet2:
         return GraphedForward(self, example_batch)
 
     def __call__(self, data_batch, return_intermediates=False, topk=None):
-        h = self.submit(data_batch, topk=topk)
+        h = self.submit(data_batch, topk=topk, keep_feats=return_intermediates)
         pred = h.result()
         if return_intermediates:
             inter = {}
+            h.event.synchronize()
+            for name, t in h.geo["feats"].items():      # (B, n, C) rows -> the reference's (B, C, n)
+                inter["feat_" + name] = t.transpose(1, 2)
             for li, (idx, ctr, gidx, gcnt) in enumerate(h.geo["sa"]):
                 inter["fps%d" % li], inter["ball%d" % li], inter["cnt%d" % li] = idx, gidx, gcnt
             for fi, (nidx, nw) in enumerate(h.geo["fp"]):

@@ -150,3 +150,42 @@ def load_checkpoint(model, path, strict=True):
     sd = blob["model"] if isinstance(blob, dict) and "model" in blob else blob
     model.load_state_dict(strip_module_prefix(sd), strict=strict)
     return model
+
+
+def calibrate_bn_(model, seed, data_batch, decades=1.0, beta_std=0.5):
+    """BatchNorm parameters of a TRAINED-LIKE network: gamma log-uniform over `decades` around 1,
+    beta = gamma N(0, beta_std), and running statistics CALIBRATED on the network's own activations --
+    one pass over `data_batch` with only the BatchNorm layers in train mode and momentum 1, so that
+    `running_mean` / `running_var` are what the preceding layers really produce (as after training).
+
+    `randomize_bn_`'s sigma^2 in [0.5, 1.5] sits orders of magnitude above the real variance of a
+    default-initialised network's activations: the signal dies in the first layers and every output is
+    a per-channel constant -- no good as a parity fixture.  With calibrated statistics each layer is
+    re-normalised to unit variance, so the outputs depend on the input at every point.
+
+    Works on any module tree with BatchNorm1d/2d (the product's `PointNet2` and the reference's, through
+    whichever operators that network calls).  `SharedMLP` stays in eval mode: no dropout."""
+    g = torch.Generator().manual_seed(seed)
+    bns = [m for m in model.modules() if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d))]
+    with torch.no_grad():
+        for m in bns:
+            C = m.weight.numel()
+            gamma = 10.0 ** ((torch.rand(C, generator=g) - 0.5) * decades)
+            m.weight.copy_(gamma)
+            m.bias.copy_(gamma * torch.randn(C, generator=g) * beta_std)
+        model.eval()
+        saved = [m.momentum for m in bns]
+        for m in bns:
+            m.train()
+            m.momentum = 1.0
+        model(data_batch)
+        for m, mom in zip(bns, saved):
+            m.eval()
+            m.momentum = mom
+    return model
+
+
+def bn_state(state_dict):
+    """The BatchNorm entries of a state_dict (everything a calibrated fixture stores by value; the
+    convolutions are regenerated from the seed)."""
+    return {k: v for k, v in state_dict.items() if ".bn." in k}

@@ -46,3 +46,66 @@ def build_full_model(seed):
     net = PointNet2(**FULL)
     randomize_bn_(net, seed + 1)
     return net.eval()
+
+
+# ---- the calibrated family (tools/gen_golden_calib.py): outputs and level features that depend on the input
+HEADS = ("score", "frame_R", "frame_t", "movable_logits")
+LEVELS = ("sa0", "sa1", "sa2", "fp0", "fp1", "fp2")
+CALIB_TOL = 1e-4          # x max(1, max|ref|): BASELINE.json north_star's 1e-4 fp32, relative to the tensor's scale
+
+
+def calib_full_model(g=None):
+    """The calibrated golden run's network rebuilt with the product model: convolutions from the seed,
+    BatchNorm tensors from the fixture; the sha256 over the whole state_dict must be the reference network's."""
+    from s4g_release_amd.model import PointNet2
+    g = g if g is not None else load("pn2_calib_full.npz")
+    torch.manual_seed(int(g["seed"]))
+    net = PointNet2(**FULL)
+    sd = net.state_dict()
+    for k in g.files:
+        if k.startswith("bn/"):
+            sd[k[3:]] = torch.from_numpy(g[k])
+    net.load_state_dict(sd, strict=True)
+    assert state_dict_sha256(net.state_dict()) == str(g["state_dict_sha256"])
+    return net.eval()
+
+
+def calib_scenes(g=None):
+    """{"tabletop": (1,3,25600), "real": (1,3,25600)} -- regenerated / read from pn2_real.npz, sha-checked."""
+    from s4g_release_amd import synth
+    g = g if g is not None else load("pn2_calib_full.npz")
+    out = {"tabletop": synth.make_batch([0], 25600),
+           "real": np.ascontiguousarray(load("pn2_real.npz")["points"][:1])}
+    for n, h in zip(g["scenes"], g["points_sha256"]):
+        assert sha(out[str(n)]) == str(h), n
+    return out
+
+
+def calib_compare_full(g, scene, outputs, feats, tol=CALIB_TOL, need_levels=LEVELS):
+    """outputs {head: (1, C, N) array}, feats {level: (1, C, n) array} of ONE scene against the fixture: outputs at
+    the stored positions and their float64 sums, every level's 64 x 32 sample and sum.  Returns the worst error
+    as a fraction of the tensor's scale, per tensor."""
+    pos = g["positions"]
+    worst = {}
+    for k in HEADS:
+        ref = g["out/%s/%s" % (scene, k)]
+        a = np.asarray(outputs[k], dtype=np.float64)[0]
+        scale = max(1.0, float(np.abs(ref).max()))
+        worst[k] = float(np.abs(a[:, pos] - ref).max()) / scale
+        worst[k + "/f64"] = float(np.abs(a[:, pos] - g["out64/%s/%s" % (scene, k)]).max()) / scale   # reported only
+        assert worst[k] < tol, (scene, k, worst[k])
+        assert worst[k + "/f64"] < max(tol, CALIB_TOL), (scene, k, "vs float64", worst[k + "/f64"])
+        # the sum over ALL points: a mean error of tol / 10 per element (far below the max bound) would show
+        s = float(a.sum())
+        assert abs(s - float(g["outsum/%s/%s" % (scene, k)])) < 0.1 * tol * scale * a.size, (scene, k, s)
+    for lv in need_levels:
+        assert lv in feats, "level %s missing (have %s)" % (lv, sorted(feats))
+    for lv, t in feats.items():
+        a = np.asarray(t, dtype=np.float64)[0]
+        ref = g["feat/%s/%s" % (scene, lv)]
+        scale = max(1.0, float(g["featabs/%s/%s" % (scene, lv)]))
+        got = a[np.ix_(g["featch/" + lv], g["featpos/" + lv])]
+        worst[lv] = float(np.abs(got - ref).max()) / scale
+        assert worst[lv] < tol, (scene, lv, worst[lv])
+        assert abs(float(a.sum()) - float(g["featsum/%s/%s" % (scene, lv)])) < 0.1 * tol * scale * a.size, (scene, lv)
+    return worst
