@@ -34,6 +34,8 @@ Extra objects on the line:
   modules_path  the reference-shaped modules over the HIP operators on the same scenes (what swapping
                 only the extension buys), scenes/s
   precision_legs  the fast path in true-fp32 MFMA and exact 3 x bf16 arithmetic on the same batch
+  weights_leg   the same step on the other network (--weights: `calibrated` is the default and the headline; `randomized`
+                is what rounds 1-5 timed)
   mixed_batch   2 of the 16 scenes tie-heavy: the conditional level-2 / level-3 FPS samplers run timed
   kept_points   clouds in, 50 grasp frames per scene out with the pose heads evaluated on the 2 048 best-scoring points
                 per scene only (FusedPointNet2(..., topk=)), next to the full forward + decode; NOT the headline
@@ -107,6 +109,12 @@ def parse(argv=None):
                          "8.84 ms with none, profiles/r03_timer_sampling.md)")
     ap.add_argument("--no-configs4", action="store_true",
                     help="skip the configs[4] (bf16, 51 200 points, 32 scenes) leg after the timed region")
+    ap.add_argument("--weights", default="calibrated", choices=["calibrated", "randomized"],
+                    help="the network the step is timed on: 'calibrated' (default) = the golden run's network "
+                         "(tests/golden/pn2_calib_full.npz: seeded convolutions, BatchNorm statistics calibrated through "
+                         "the reference's own modules -- activations that carry signal at every point, as a trained "
+                         "network's do); 'randomized' = rounds 1-5's network (randomize_bn_: every activation a "
+                         "per-channel constant after the first layers)")
     ap.add_argument("--precision", default=None, choices=["f16x2", "bf16x3", "fp32", "bf16"],
                     help="contraction arithmetic of the fast path (default f16x2 = fp32-class); "
                          "'bf16' is the reduced-precision roofline configuration (configs[4]), "
@@ -351,10 +359,15 @@ def main():
         net, runner, impl = None, StubRunner(), "stub"
         args.no_extras = args.no_cpu_baseline = True
     else:
-        torch.manual_seed(20260101)
-        net = build_pointnet2_cls(cfg)
-        randomize_bn_(net, 20260102)
-        net = net.to(dev).eval()
+        def make_net(kind):
+            if kind == "calibrated":
+                from tests import golden_util as GU      # data fixture: BatchNorm tensors by value, sha-checked
+                return GU.calib_full_model().to(dev).eval()
+            torch.manual_seed(20260101)
+            n_ = build_pointnet2_cls(cfg)
+            randomize_bn_(n_, 20260102)
+            return n_.to(dev).eval()
+        net = make_net(args.weights)
         if impl in ("auto", "fused"):
             try:
                 from s4g_release_amd.fused import FusedPointNet2 as fused_cls
@@ -491,7 +504,7 @@ def main():
     roofline_dense, kernels = dense_roofline(summary, timed_passes, precision)
 
     N, M, K = args.points, cfg.num_centroids[0], cfg.num_neighbours[0]
-    roofline = latency = io = configs4 = modules_path = precision_legs = mixed_batch = kept_points = None
+    roofline = latency = io = configs4 = modules_path = precision_legs = mixed_batch = kept_points = weights_leg = None
     # (the single-GPU probes below run at N = 1 only: at N > 1 the other ranks have left, rank 0 prints its line
     #  and tears the communicator down without making the job wait for figures the N = 1 line already carries)
     if not args.no_extras and world == 1:
@@ -673,6 +686,24 @@ def main():
                                         "warmup": p_warm, "roofline_frac": p_roof["frac"] if p_roof else None,
                                         "roofline_peak_TFLOPs": p_roof["peak"] if p_roof else None}
                 del p_runner
+            # ---- the same step on the OTHER network: rounds 1-5 timed `randomized` (randomize_bn_: sigma^2 in
+            # [0.5, 1.5] against real variances of 1e-4 .. 1e-2 -- every activation panel a per-channel constant after the
+            # first layers); the headline is now timed on `calibrated` weights, whose activations toggle the MFMA operand
+            # lanes the way a trained network's do (MFMA throughput under the power cap depends on operand toggle rate:
+            # profiles/r05_mfma_ceiling.md).  Same 16 scenes, same pipelining, 20 steps.
+            other = "randomized" if args.weights == "calibrated" else "calibrated"
+            o_runner = fused_cls(make_net(other), precision=precision)
+            o_steps, o_warm = 20, 5
+            o_el, o_step, o_sum, o_tp = timed_region(o_steps, o_warm, collective=False, run=o_runner, data=batch,
+                                                     gathered=False)
+            o_roof, _ = dense_roofline(o_sum, o_tp, precision)
+            weights_leg = {"weights": other, "value": round(B * o_steps / o_el, 2), "unit": "scenes/sec",
+                           "ms_per_step": round(1e3 * o_el / o_steps, 3), "step_ms_median": o_step["median"],
+                           "steps": o_steps, "warmup": o_warm,
+                           "contraction_ms_per_step": o_roof["ms_per_step"] if o_roof else None,
+                           "roofline_frac": o_roof["frac"] if o_roof else None,
+                           "headline_over_this": round(value / (B * o_steps / o_el), 4)}
+            del o_runner
             # ---- clouds in, grasp frames out, with the heads evaluated where the decode reads them: the
             # score head on every point, the rotation / translation / movable heads on the 2 048 best-scoring points per
             # scene (FusedPointNet2(..., topk=): the same top-50 frames as the full forward + decode,
@@ -790,6 +821,14 @@ def main():
         with torch.no_grad():
             got = runner({"scene_points": pts[:1]})
         err = max(float(np.max(np.abs(got[k].cpu().numpy() - ref[k]))) for k in heads)
+        err_rel = max(float(np.max(np.abs(got[k].cpu().numpy() - ref[k]))) / max(1.0, float(np.abs(ref[k]).max()))
+                      for k in heads)
+        from tests.ref64 import forward64      # float64 arithmetic on the same weights and indices (test infrastructure)
+        ref64 = forward64(sd, host_pts[:1], cfg.num_centroids, cfg.radius, cfg.num_neighbours)
+        sc = {k: max(1.0, float(np.abs(ref64[k]).max())) for k in heads}
+        err_gpu64 = max(float(np.max(np.abs(got[k].cpu().numpy().astype(np.float64) - ref64[k]))) / sc[k] for k in heads)
+        err_cpu64 = max(float(np.max(np.abs(ref[k].astype(np.float64) - ref64[k]))) / sc[k] for k in heads)
+        spread = min(float((ref[k].std(axis=2) / np.maximum(np.abs(ref[k]).max(axis=2), 1e-30)).min()) for k in heads)
         cpu_baseline = {"value": round(n_cpu / t_cpu, 4), "unit": "scenes/sec",
                         "cores": nt, "kind": "port",
                         "sample": "%d scenes (scenes %d..%d) of the same workload, one at a time: oracle C operators "
@@ -798,7 +837,13 @@ def main():
                                   % (n_cpu, scene_ids[0], scene_ids[0] + n_cpu - 1,
                                      sorted({min(ncores, 16), min(ncores, 64)}), scene_ids[0], ncores),
                         "seconds": round(t_cpu, 2), "scenes": n_cpu,
-                        "max_abs_err_gpu_vs_cpu": err}
+                        "max_abs_err_gpu_vs_cpu": err, "max_err_over_scale_gpu_vs_cpu": err_rel,
+                        "max_err_over_scale_gpu_vs_float64": err_gpu64, "max_err_over_scale_cpu_vs_float64": err_cpu64,
+                        "output_spread_min_std_over_max": round(spread, 4),
+                        "err_note": "scene %d, %s weights, all four heads over all points; scale = max(1, max|ref|) per "
+                                    "head; float64 = tests/ref64.py (the same composition in float64 on the same indices): "
+                                    "the device and torch's CPU fp32 kernels are each that far from exact arithmetic; the spread says the outputs depend on the input (a per-channel constant "
+                                    "would read 0)" % (scene_ids[0], args.weights)}
 
     arith = {"f16x2": "fp32-class: contraction as scaled 2xfp16 split, 3 MFMA products, fp32 accumulate",
              "bf16x3": "fp32-class: contraction as exact 3xbf16 split, fp32 accumulate",
@@ -829,6 +874,7 @@ def main():
         "config": {"workload": "S4G PN2_CLS forward (3 SA + 3 FP + 4 heads), %d scenes/GPU/step, "
                                "%d-pt %s clouds, %s, impl=%s%s" % (B, args.points, args.variant, arith,
                                                                    impl, pipe_label),
+                   "weights": args.weights if not stub else None,
                    "scenes_per_gpu": B, "num_points": args.points, "global_batch": world * B,
                    "in_flight": args.in_flight if pipelined else 0,
                    "kernel_timers": "HIP event pairs around every native launch of every %s forward pass of the "
@@ -838,7 +884,7 @@ def main():
         # `roofline_ball_query_group_points`: the HBM-bound operator pair the north star names.
         "roofline": roofline_dense, "roofline_ball_query_group_points": roofline,
         "configs4": configs4, "modules_path": modules_path, "precision_legs": precision_legs,
-        "mixed_batch": mixed_batch, "kept_points": kept_points, "collective": collective, "distributed": shards,
+        "weights_leg": weights_leg, "mixed_batch": mixed_batch, "kept_points": kept_points, "collective": collective, "distributed": shards,
         "step_ms": step_ms, "latency": latency, "io": io, "kernels": kernels,
         "cpu_baseline": cpu_baseline,
     }

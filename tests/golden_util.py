@@ -109,3 +109,18 @@ def calib_compare_full(g, scene, outputs, feats, tol=CALIB_TOL, need_levels=LEVE
         assert worst[lv] < tol, (scene, lv, worst[lv])
         assert abs(float(a.sum()) - float(g["featsum/%s/%s" % (scene, lv)])) < 0.1 * tol * scale * a.size, (scene, lv)
     return worst
+
+
+def shipped_net(dev):
+    """The shipped architecture with the calibrated golden run's weights (pinned to the reference network by
+    sha256): what every GPU test of the full-size model runs on -- its activations carry signal at every point, so
+    an A/B between two launch plans or two paths would see a wiring difference (with `randomize_bn_` statistics
+    every activation is a per-channel constant and such a difference stays below 1e-6)."""
+    return calib_full_model().to(dev).eval()
+
+
+def calibrated(net, seed, pts):
+    """`net` (already on the device) with trained-like BatchNorm parameters, its running statistics calibrated on
+    `pts` (B, 3, N) through the reference-shaped modules over the HIP operators (model.calibrate_bn_)."""
+    from s4g_release_amd.model import calibrate_bn_
+    return calibrate_bn_(net, seed, {"scene_points": pts}).eval()

@@ -31,11 +31,11 @@ def _run(desc_kwargs):
 def test_b16_full_size_every_scene_equals_itself_alone_and_the_oracle(dev):
     """configs[2]: 16 scenes x 25 600 points through the fused path: every scene's four outputs
     equal the same scene run alone (<= 1e-6; bit-identical in practice), indices identical, and
-    scenes 0 and 15 are within 1e-4 of the CPU oracle forward."""
+    scenes 0 and 15 are within 1e-4 (of scale) of the CPU oracle forward -- on CALIBRATED weights."""
     from oracle import pn2_forward
     from s4g_release_amd import synth
     from s4g_release_amd.fused import FusedPointNet2
-    net = GU.build_full_model(20260101).to(dev)
+    net = GU.shipped_net(dev)
     run = FusedPointNet2(net)
     pts = torch.from_numpy(synth.make_batch(list(range(16)), 25600)).to(dev)
     with torch.no_grad():
@@ -53,12 +53,29 @@ def test_b16_full_size_every_scene_equals_itself_alone_and_the_oracle(dev):
     assert worst <= 1e-6, worst
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     cfg = GU.FULL
+    # calibrated weights (tests/golden_util.shipped_net): the outputs vary from point to point, so these bounds see
+    # the backbone and not only the last layers' biases.  Scene 0 is the calibrated fixture's `tabletop` scene:
+    # checked against the REFERENCE network's outputs as well.
+    g = GU.load("pn2_calib_full.npz")
+    GU.calib_compare_full(g, "tabletop", {k: full[k][0:1].cpu().numpy() for k in HEADS}, {}, need_levels=())
+    from tests.ref64 import forward64
     for s in (0, 15):
-        ref = pn2_forward.forward(sd, pts[s:s + 1].cpu().numpy(), cfg["num_centroids"], cfg["radius"],
-                                  cfg["num_neighbours"])
+        one = pts[s:s + 1].cpu().numpy()
+        ref = pn2_forward.forward(sd, one, cfg["num_centroids"], cfg["radius"], cfg["num_neighbours"])
+        ref64 = forward64(sd, one, cfg["num_centroids"], cfg["radius"], cfg["num_neighbours"])
         for k in HEADS:
-            err = float(np.max(np.abs(full[k][s:s + 1].cpu().numpy() - ref[k])))
-            assert err < 1e-4, (s, k, err)
+            assert float((ref[k].std(axis=2) / np.abs(ref[k]).max(axis=2)).min()) > 0.05, (s, k)     # signal
+            scale = max(1.0, float(np.abs(ref64[k]).max()))
+            got = full[k][s:s + 1].cpu().numpy().astype(np.float64)
+            e64 = float(np.abs(got - ref64[k]).max()) / scale             # the device from float64 arithmetic
+            o64 = float(np.abs(ref[k] - ref64[k]).max()) / scale          # torch's CPU fp32 kernels from the same
+            eo = float(np.abs(got - ref[k]).max()) / scale
+            print("scene %d %-14s gpu-f64 %.1e  cpu_fp32-f64 %.1e  gpu-cpu_fp32 %.1e" % (s, k, e64, o64, eo))
+            # over ALL 25 600 points of a scene two fp32-class forwards of the calibrated network differ by up to
+            # ~1.1e-4 of scale (measured: f16x2 vs torch CPU 1.06e-4 on frame_t, each ~6e-5 from float64): bound the
+            # device against the exact result, and against the CPU forward by the triangle
+            assert e64 < 1e-4, (s, k, e64)
+            assert eo < 1e-4 + o64, (s, k, eo, o64)
 
 
 def _layer(w):
@@ -132,7 +149,7 @@ def test_batch_with_a_rescaled_scene_leaves_the_others_unchanged(dev):
     single-scene results, every index tensor included."""
     from s4g_release_amd import synth
     from s4g_release_amd.fused import FusedPointNet2
-    net = GU.build_full_model(20260101).to(dev)
+    net = GU.shipped_net(dev)
     run = FusedPointNet2(net)
     pts = torch.from_numpy(synth.make_batch([0, 1, 2, 3], 25600)).to(dev)
     c = pts[1].mean(dim=1, keepdim=True)
@@ -156,7 +173,7 @@ def test_proven_and_sampled_scenes_share_a_batch(dev, monkeypatch):
     from oracle import oracle as O
     from s4g_release_amd import synth
     from s4g_release_amd.fused import FusedPointNet2
-    net = GU.build_full_model(20260101).to(dev)
+    net = GU.shipped_net(dev)
     rng = np.random.default_rng(23)
     pts = synth.make_batch([1, 2, 3, 4], 25600)
     for b in (1, 3):

@@ -25,8 +25,8 @@ assert sdist.bound_rccl_channels() == "8"
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 dist.init_process_group(backend="nccl", device_id=dev)
-torch.manual_seed(3)
-net = randomize_bn_(build_pointnet2_cls(S4GConfig()), 4).to(dev).eval()
+from tests import golden_util as GU
+net = GU.shipped_net(dev)
 run = FusedPointNet2(net)
 pts = torch.from_numpy(synth.make_batch([0, 1, 2], 25600)).to(dev)
 with torch.no_grad():

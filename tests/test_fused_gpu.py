@@ -336,11 +336,7 @@ def test_model_with_and_without_pregathered_rows(dev, monkeypatch):
     same outputs bit for bit as the loader following the indices itself."""
     from s4g_release_amd import synth
     from s4g_release_amd.fused import FusedPointNet2
-    from s4g_release_amd.model import S4GConfig, build_pointnet2_cls, randomize_bn_
-    torch.manual_seed(3)
-    net = build_pointnet2_cls(S4GConfig())
-    randomize_bn_(net, 4)
-    net = net.to(dev).eval()
+    net = GU.shipped_net(dev)
     pts = torch.from_numpy(synth.make_batch([5, 6], 25600)).to(dev)
     monkeypatch.setenv("S4G_SA_UNIQUE", "0")     # (the distinct-row form has its own tests: test_sa_unique_gpu.py)
     mfma = FusedPointNet2(net)({"scene_points": pts})          # round 5: the 3 -> 128 layer on the matrix cores
@@ -351,7 +347,8 @@ def test_model_with_and_without_pregathered_rows(dev, monkeypatch):
     for k in a:
         assert torch.equal(a[k], b[k]), k
         err = (mfma[k] - a[k]).abs().max().item()              # the same layer as an f16x2 product: fp32-class, not bitwise
-        assert err < 2e-5 * max(1.0, a[k].abs().max().item()), (k, err)
+        # (calibrated weights: two fp32-class forms of the network differ by ~3e-5 of scale, each ~5e-5 from float64)
+        assert err < TOL * max(1.0, a[k].abs().max().item()), (k, err)
 
 
 def _h2_second(W2):
@@ -894,13 +891,13 @@ def test_fused_equals_modules_path_batch(dev):
                fp_channels=((128, 128), (64, 64), (32, 32, 32)), num_fp_neighbours=(3, 3, 3),
                seg_channels=(64, 32, 32, 16), num_removal_directions=5, dropout_prob=0.5)
     torch.manual_seed(99)
-    net = randomize_bn_(PointNet2(**cfg), 100).to(dev).eval()
     pts = torch.from_numpy(synth.make_batch([1, 2, 3], 1500, variant="dup-heavy")).to(dev)
+    net = GU.calibrated(PointNet2(**cfg).to(dev), 100, pts)
     with torch.no_grad():
         a = net({"scene_points": pts})
     b = FusedPointNet2(net)({"scene_points": pts})
     for k in a:
-        assert (a[k] - b[k]).abs().max().item() < TOL, k
+        assert (a[k] - b[k]).abs().max().item() < TOL * max(1.0, a[k].abs().max().item()), k
 
 
 @pytest.mark.parametrize("streams", [("1", "1"), ("3", "2")])
@@ -917,9 +914,9 @@ def test_pipelined_submissions_match_sequential(dev, monkeypatch, streams):
                fp_channels=((256, 256), (128, 128), (64, 64, 64)), num_fp_neighbours=(3, 3, 3),
                seg_channels=(128, 64, 64, 32), num_removal_directions=5, dropout_prob=0.5)
     torch.manual_seed(5)
-    net = randomize_bn_(PointNet2(**cfg), 6).to(dev).eval()
-    fast = FusedPointNet2(net)
     batches = [torch.from_numpy(synth.make_batch([10 * i, 10 * i + 1], 3000)).to(dev) for i in range(5)]
+    net = GU.calibrated(PointNet2(**cfg).to(dev), 6, batches[0])
+    fast = FusedPointNet2(net)
     with torch.no_grad():
         ref = [{k: v.clone() for k, v in fast({"scene_points": b}).items()} for b in batches]
         torch.cuda.synchronize()
@@ -952,9 +949,9 @@ def test_fused_equals_modules_random_configs(dev, seed):
                seg_channels=(ch(8, 32), ch(4, 24), ch(4, 24), ch(2, 12)), num_removal_directions=5,
                dropout_prob=0.5)
     torch.manual_seed(seed)
-    net = randomize_bn_(PointNet2(**cfg), seed + 50).to(dev).eval()
     variant = ["tabletop-v1", "dup-heavy", "uniform-box"][seed % 3]
     pts = torch.from_numpy(synth.make_batch([seed, seed + 1, seed + 2][: 1 + seed % 3], n_pts, variant=variant)).to(dev)
+    net = GU.calibrated(PointNet2(**cfg).to(dev), seed + 50, pts)
     with torch.no_grad():
         a = net({"scene_points": pts})
     for precision in ("f16x2", "bf16x3"):
@@ -990,9 +987,9 @@ def test_fused_equals_modules_chain_widths(dev, seed):
     if f2 != h:
         cfg["fp_channels"] = ((192, 160), (f2 * 2, f2 * 2), (h, h, h))
     torch.manual_seed(seed)
-    net = randomize_bn_(PointNet2(**cfg), seed + 70).to(dev).eval()
     variant = ["tabletop-v1", "dup-heavy", "uniform-box"][seed % 3]
     pts = torch.from_numpy(synth.make_batch([seed, seed + 3][: 1 + seed % 2], n_pts, variant=variant)).to(dev)
+    net = GU.calibrated(PointNet2(**cfg).to(dev), seed + 70, pts)
     with torch.no_grad():
         a = net({"scene_points": pts})
     fused = FusedPointNet2(net)
@@ -1009,10 +1006,7 @@ def test_fused_layer_pairs_match_layer_by_layer(dev, monkeypatch):
     from s4g_release_amd import synth
     from s4g_release_amd.fused import FusedPointNet2
     from s4g_release_amd.model import S4GConfig, build_pointnet2_cls, randomize_bn_
-    torch.manual_seed(11)
-    net = build_pointnet2_cls(S4GConfig())
-    randomize_bn_(net, 12)
-    net = net.to(dev).eval()
+    net = GU.shipped_net(dev)
     pts = torch.from_numpy(synth.make_batch([0, 1], 25600)).to(dev)
     a = FusedPointNet2(net)({"scene_points": pts})
     monkeypatch.setenv("S4G_GEMM_FUSE2", "0")
@@ -1021,7 +1015,8 @@ def test_fused_layer_pairs_match_layer_by_layer(dev, monkeypatch):
     b = FusedPointNet2(net)({"scene_points": pts})
     for k in a:
         scale = max(1.0, b[k].abs().max().item())
-        assert (a[k] - b[k]).abs().max().item() < 2e-5 * scale, k
+        # (calibrated weights: measured 3.1e-5 of scale; 2e-6 on the old per-channel-constant network)
+        assert (a[k] - b[k]).abs().max().item() < TOL * scale, k
 
 
 @pytest.mark.parametrize("precision", ["f16x2", "bf16"])
@@ -1033,8 +1028,7 @@ def test_shared_input_layers_as_one_launch_match_separate_launches(dev, monkeypa
     from s4g_release_amd import synth
     from s4g_release_amd.fused import FusedPointNet2
     from s4g_release_amd.model import S4GConfig, build_pointnet2_cls, randomize_bn_
-    torch.manual_seed(5)
-    net = randomize_bn_(build_pointnet2_cls(S4GConfig()), 5).to(dev).eval()
+    net = GU.shipped_net(dev)
     batch = {"scene_points": torch.from_numpy(synth.make_batch([3, 4], 25600)).to(dev)}
 
     def run():
@@ -1060,8 +1054,7 @@ def test_forward_recorded_as_a_hip_graph_replays_bit_identically(dev):
     from s4g_release_amd import synth
     from s4g_release_amd.fused import FusedPointNet2
     from s4g_release_amd.model import S4GConfig, build_pointnet2_cls, randomize_bn_
-    torch.manual_seed(8)
-    net = randomize_bn_(build_pointnet2_cls(S4GConfig()), 9).to(dev).eval()
+    net = GU.shipped_net(dev)
     run = FusedPointNet2(net)
     a = torch.from_numpy(synth.make_batch([0, 1], 25600)).to(dev)
     b = torch.from_numpy(synth.make_batch([7, 8], 25600, variant="dup-heavy")).to(dev)
@@ -1085,8 +1078,7 @@ def test_heads_written_into_one_packed_tensor_bit_identical(dev, monkeypatch, pr
     from s4g_release_amd import dist as sdist, synth
     from s4g_release_amd.fused import FusedPointNet2, PackedPred
     from s4g_release_amd.model import S4GConfig, build_pointnet2_cls, randomize_bn_
-    torch.manual_seed(18)
-    net = randomize_bn_(build_pointnet2_cls(S4GConfig()), 19).to(dev).eval()
+    net = GU.shipped_net(dev)
     x = {"scene_points": torch.from_numpy(synth.make_batch([2, 3, 4], 25600 - 40)).to(dev)}
     packed = FusedPointNet2(net, precision=precision)(x)
     assert isinstance(packed, PackedPred) and packed.packed.shape == (3, 21, 25600 - 40)

@@ -6,6 +6,8 @@ import ctypes
 import pytest
 import torch
 
+from tests import golden_util as GU
+
 pytestmark = pytest.mark.gpu
 CH = (3, 9, 4, 5)
 
@@ -205,10 +207,7 @@ def test_fused_model_with_and_without_the_tail_in_the_heads_launch(dev, monkeypa
     from s4g_release_amd import functions as F, synth
     from s4g_release_amd.fused import FusedPointNet2
     from s4g_release_amd.model import S4GConfig, build_pointnet2_cls, randomize_bn_
-    torch.manual_seed(3)
-    net = build_pointnet2_cls(S4GConfig())
-    randomize_bn_(net, 4)
-    net = net.to(dev).eval()
+    net = GU.shipped_net(dev)
     pts = torch.from_numpy(synth.make_batch([0, 1], 25600)).to(dev)
     res = {}
     for flag in ("0", "1"):
@@ -234,10 +233,7 @@ def test_fused_model_fp1_chain_into_the_next_levels_first_layer(dev, monkeypatch
     from s4g_release_amd import functions as F, synth
     from s4g_release_amd.fused import FusedPointNet2
     from s4g_release_amd.model import S4GConfig, build_pointnet2_cls, randomize_bn_
-    torch.manual_seed(5)
-    net = build_pointnet2_cls(S4GConfig())
-    randomize_bn_(net, 6)
-    net = net.to(dev).eval()
+    net = GU.shipped_net(dev)
     pts = torch.from_numpy(synth.make_batch([2, 3], 25600)).to(dev)
     res = {}
     for flag in ("0", "1"):

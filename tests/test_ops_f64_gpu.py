@@ -134,14 +134,14 @@ def test_reference_shaped_model_in_double(dev):
     cfg = dict(score_classes=3, num_centroids=(256, 64, 16), radius=(0.05, 0.12, 0.4), num_neighbours=(16, 16, 16),
                sa_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128)), fp_channels=((128, 128), (64, 64), (32, 32, 32)),
                num_fp_neighbours=(3, 3, 3), seg_channels=(64, 32, 32, 16), num_removal_directions=5, dropout_prob=0.5)
+    from tests import golden_util as GU
     torch.manual_seed(5)
-    net = PointNet2(**cfg)
-    randomize_bn_(net, 6)
-    net = net.to(dev).eval()
     pts = torch.from_numpy(synth.make_batch([1, 2], 1024)).to(dev)
+    net = GU.calibrated(PointNet2(**cfg).to(dev), 6, pts)
     with torch.no_grad():
         a = net({"scene_points": pts})
         b = net.double()({"scene_points": pts.double()})
     for k in a:
         assert b[k].dtype == torch.float64
-        assert (a[k].double() - b[k]).abs().max().item() < 1e-5, k
+        # calibrated weights (outputs up to +-4 that depend on the input): fp32 through the modules vs the same in double
+        assert (a[k].double() - b[k]).abs().max().item() < 1e-4 * max(1.0, b[k].abs().max().item()), k

@@ -14,21 +14,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _net(dev, seed=21):
-    """The shipped architecture with random weights -- and a score head CALIBRATED to have an order: a freshly initialised
-    one is flat to 1e-7 across a scene (every point ties), so its logit layer is rescaled to unit spread per class over a
-    probe scene (a per-class affine map of the logits: still the same network function family)."""
-    from s4g_release_amd import synth
-    from s4g_release_amd.fused import FusedPointNet2
-    from s4g_release_amd.model import S4GConfig, build_pointnet2_cls, randomize_bn_
-    torch.manual_seed(seed)
-    net = randomize_bn_(build_pointnet2_cls(S4GConfig()), seed + 1).to(dev).eval()
-    probe = torch.from_numpy(synth.make_batch([99], 25600)).to(dev)
-    logits = FusedPointNet2(net, precision="fp32")({"scene_points": probe})["score"][0].double()     # (3, N)
-    mean, std = logits.mean(dim=1), logits.std(dim=1).clamp_min(1e-12)
-    with torch.no_grad():
-        net.seg_logit.weight.copy_((net.seg_logit.weight.double() / std.view(-1, 1, 1)).float())
-        net.seg_logit.bias.copy_(((net.seg_logit.bias.double() - mean) / std).float())
-    return net
+    """The shipped architecture with the calibrated golden run's weights (tests/golden_util.shipped_net): its score head
+    has a real order over a scene's points (a `randomize_bn_` network's is flat to 1e-7 -- every point ties)."""
+    from tests import golden_util as GU
+    return GU.shipped_net(dev)
 
 
 @pytest.mark.parametrize("precision,K", [("f16x2", 2048), ("f16x2", 100), ("bf16", 1024)])
