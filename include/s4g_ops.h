@@ -51,15 +51,29 @@ extern "C" {
  *    (B, 21, N) tensor: the all-gather payload of the multi-GPU path without a packing copy).
  * 10: s4g_group_points_backward_det_f32 / s4g_three_interpolate_backward_det_f32 / s4g_scatter_det_workspace_bytes
  *    (the backward scatters in a fixed order: run-to-run bit-identical, equal to the oracle's sequential sum).
- * 11: s4g_heads_desc_t.head_mask (a launch may evaluate a subset of the four heads). */
-#define S4G_ABI_VERSION 11
+ * 11: s4g_heads_desc_t.head_mask (a launch may evaluate a subset of the four heads).
+ * 12: s4g_test_knobs_enabled (the A/B knobs below are ignored without S4G_TEST_KNOBS=1; no layout change). */
+#define S4G_ABI_VERSION 12
 
 /* ---------------------------------------------------------------------------
- * Environment knobs (round 4: the complete list; everything else that used to be read from the
- * environment is gone).  None is needed in production -- the defaults are the measured-fastest exact
- * paths; every alternative below is exact too and exists for tests and A/B measurements.
+ * Environment variables.
  *
- *  read inside libs4g_hip.so (per call unless noted):
+ * PRODUCTION SURFACE -- the only variables the shipped library and its Python host read on their own (7):
+ *   S4G_TEST_KNOBS=1               master switch for everything in the second list (library and host side)
+ *   S4G_HIP_LIB=path               load another build of this library (warns; tools/ab_libs.sh)
+ *   S4G_GEMM_MODE=f16x2|bf16x3|fp32|bf16   default contraction arithmetic of FusedPointNet2 (constructor argument wins)
+ *   S4G_DIST_MODE=fmad             distance arithmetic contract (S4G_FLAG_FMAD) instead of strict
+ *   S4G_BACKWARD=atomic            group_points / three_interpolate backward through the atomicAdd kernels (the
+ *                                  reference's scheme, order undefined) instead of the deterministic sorted-segment sums
+ *   S4G_GEO_STREAMS=n, S4G_DENSE_STREAMS=n   geometry / contraction streams of the pipeline (2 / 1)
+ *  (bench.py reads S4G_BENCH_FORCE_DIST, S4G_BENCH_TIMER_EVERY, NCCL_MAX_NCHANNELS, and for tests/test_bench_world.py
+ *   S4G_BENCH_BACKEND=gloo; the oracle reads S4G_ORACLE_LIB / S4G_ORACLE_F64 -- test infrastructure, not the product.)
+ *
+ * A/B AND TEST KNOBS -- IGNORED unless the process sets S4G_TEST_KNOBS=1 (tests/conftest.py does; tools that set one set
+ * it too) or the library is a -DS4G_VARIANTS measurement build (s4g_test_knobs_enabled() says which).  Round 6: a stray
+ * variable in a launcher's environment can no longer change which kernel a production rank runs.  Every alternative is
+ * exact (same results; the defaults are the measured-fastest paths), so the switch can change speed, never values.
+ *  library side (s4g::knob in csrc/s4g_common.h; per call unless noted):
  *   S4G_FPS_MODE=dense|pruned      FPS kernel for N <= 25 600: full scan | group-pruned (default: pruned
  *                                  above 10 240 points, and above 5 120 when M >= 2 048).  =dense also turns the L2-resident pruned kernel
  *                                  off for 25 600 < N <= 65 535 (the streaming kernel runs instead)
@@ -71,18 +85,10 @@ extern "C" {
  *   S4G_INTERP_MODE=lane           three_interpolate: lane-per-point kernel instead of the LDS tile
  *   S4G_GEMM_SINGLE_CHAIN=0|1      plain single layers never / wherever supported on mlp_chain_kernel's first-layer
  *                                  form (default: where it measured faster: Cout >= 1024 or K >= 1024)
- *   S4G_PACKED_OUT=0               FusedPointNet2 returns four head tensors of their own instead of channel slices of one
- *                                  packed (B, 21, N) tensor
- *   S4G_BACKWARD=atomic            group_points / three_interpolate backward through the atomicAdd kernels (the reference's
- *                                  scheme, order undefined) instead of the deterministic sorted-segment sums (Python side)
  *   S4G_MLP1_MFMA=0                first SA level's 3 -> C layer on the vector ALU (the chain kernel's loader) instead of
- *                                  one MFMA step inside the chain kernel (round 5; f16x2 form with rel_xyz4 records)
- *  measurement builds only (make HIPFLAGS_EXTRA=-DS4G_VARIANTS, s4g_build_variants() == 1):
- *   S4G_FPS_MODE=cluster|hybrid, S4G_BQ_MODE=cell (+ S4G_BQ_CELL_WGS), S4G_GEMM_RESIDENT=0|1
- *  read by the Python host side (s4g_release_amd/):
- *   S4G_HIP_LIB=path               load another build of this library (warns; tools/ab_libs.sh)
- *   S4G_DIST_MODE=fmad             distance arithmetic contract (S4G_FLAG_FMAD) instead of strict
- *   S4G_GEMM_MODE=f16x2|bf16x3|fp32|bf16   default contraction arithmetic of FusedPointNet2
+ *                                  one MFMA step inside the chain kernel (f16x2 form with rel_xyz4 records)
+ *   measurement builds only: S4G_FPS_MODE=cluster|hybrid, S4G_BQ_MODE=cell (+ S4G_BQ_CELL_WGS), S4G_GEMM_RESIDENT=0|1
+ *  host side (_cabi.knob; read when a FusedPointNet2 is built / an operator is called):
  *   S4G_SA_UNIQUE=0                first SA level contracts all K rows, padding copies included
  *   S4G_REL_XYZ=0                  first SA level's loader follows the indices itself
  *   S4G_SA_LINEAR_FIRST=0, S4G_FP_LINEAR_FIRST=0   no linear-layer-before-grouping / -interpolation
@@ -92,9 +98,8 @@ extern "C" {
  *   S4G_HEADS_FUSED=0, S4G_HEADS_PRE=0   heads layer by layer / FP tail outside the heads launch
  *   S4G_FPS_PREFIX=0               always sample SA levels 2 and 3 (no prefix proof)
  *   S4G_NN_MODE=scan               3-NN: never the cell-grid search
- *   S4G_GEO_STREAMS=n, S4G_DENSE_STREAMS=n   geometry / contraction streams of the pipeline (2 / 1)
- *  bench.py: S4G_BENCH_FORCE_DIST=1 (RCCL path with one rank), S4G_BENCH_TIMER_EVERY=k, NCCL_MAX_NCHANNELS (default 8
- *            set by dist.bound_rccl_channels), S4G_BENCH_BACKEND=gloo (tests/test_bench_world.py ONLY: CPU stub run)
+ *   S4G_PACKED_OUT=0               FusedPointNet2 returns four head tensors of their own instead of channel slices of one
+ *                                  packed (B, 21, N) tensor
  * ------------------------------------------------------------------------- */
 
 #define S4G_OK 0
@@ -117,6 +122,9 @@ int s4g_abi_version(void);
  * the cell-centric ball query, the resident-A single-layer contraction); 0 for the shipped library,
  * where S4G_FPS_MODE=cluster|hybrid, S4G_BQ_MODE=cell and S4G_GEMM_RESIDENT select nothing. */
 int s4g_build_variants(void);
+/* 1 when the A/B / test knobs listed above are honoured in this process (S4G_TEST_KNOBS=1 in the environment, or a
+ * measurement build); 0: the library ignores every one of them. */
+int s4g_test_knobs_enabled(void);
 const char *s4g_error_string(int code);
 
 /* Bytes of device scratch an operator needs for the given problem
@@ -177,7 +185,12 @@ int s4g_gather_points_f32(const float *in_bcn, const int64_t *idx_bm, int64_t B,
 /* PointSearch(query (B,3,N1), key (B,3,N2), 3)
  *   -> index (B,N1,3) int64, SQUARED distance (B,N1,3) fp32
  * replaces csrc/interpolate.h:8-11, csrc/interpolate_kernel.cu:92-132.
- * Requires N2 >= 3 (interpolate_kernel.cu:106). */
+ * Requires N2 >= 3 (interpolate_kernel.cu:106).
+ * Out of contract, but contained: a query with a NaN / inf coordinate (or squared distances that all overflow) enters no
+ * key at all; the reference then leaves its initialisers -- index -1, distance +inf in slot 0 -- and its consumers read
+ * row -1.  Every 3-NN entry point of this library (this one, _i32, _grid, _weights*, _f64) writes index 0 for such a
+ * slot and keeps the distance: the interpolation weight of that slot is 0 either way, and nothing downstream can be
+ * driven out of bounds by a bad depth pixel (a GPU memory fault takes the process down). */
 int s4g_three_nn_f32(const float *q_b3n1, const float *k_b3n2, int64_t B,
                      int64_t N1, int64_t N2, int64_t *idx_bn3, float *d2_bn3,
                      void *ws, size_t ws_bytes, int flags, s4g_stream_t stream);

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # declared symbol are checked either way
 LIB_PATH = os.environ.get("S4G_HIP_LIB") or os.path.join(_HERE, "libs4g_hip.so")
 
-S4G_ABI_VERSION = 11
+S4G_ABI_VERSION = 12
 S4G_EUNSUPPORTED = -3
 S4G_FLAG_FMAD = 1
 S4G_OP_FPS, S4G_OP_BALL_QUERY, S4G_OP_THREE_NN = 1, 2, 3
@@ -87,6 +87,7 @@ SIGNATURES = {
     "s4g_fps_gather_ex_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp]),
     "s4g_fps_prefix_check_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _int, _vp]),
     "s4g_build_variants": (_int, []),
+    "s4g_test_knobs_enabled": (_int, []),
     # double dispatch of the five operators (csrc/ops_f64.hip)
     "s4g_fps_f64": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _sz, _int, _vp]),
     "s4g_ball_query_f64": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _int, _vp]),
@@ -166,6 +167,15 @@ def lib():
         raise RuntimeError("libs4g_hip.so ABI version %d != expected %d" % (ver, S4G_ABI_VERSION))
     _lib = L
     return _lib
+
+
+def knob(name, default=None):
+    """An A/B / test knob of include/s4g_ops.h's second list: read from the environment ONLY when the process also sets
+    S4G_TEST_KNOBS=1 (tests/conftest.py does), else `default` -- the host-side twin of csrc/s4g_common.h's s4g::knob.
+    A production process cannot have its launch plan changed by a stray variable."""
+    if os.environ.get("S4G_TEST_KNOBS") != "1":
+        return default
+    return os.environ.get(name, default)
 
 
 def check(code, what):

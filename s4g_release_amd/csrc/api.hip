@@ -17,6 +17,9 @@ extern "C" int s4g_build_variants(void) {
 #endif
 }
 
+// 1: the A/B knobs of include/s4g_ops.h are being honoured in this process (S4G_TEST_KNOBS=1 or a measurement build)
+extern "C" int s4g_test_knobs_enabled(void) { return s4g::test_knobs_enabled() ? 1 : 0; }
+
 extern "C" const char* s4g_error_string(int code) {
   if (code == S4G_OK) return "ok";
   if (code == S4G_EINVAL) return "invalid argument (size, null pointer or range)";

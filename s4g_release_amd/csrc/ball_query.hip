@@ -503,7 +503,7 @@ int launch_grid_build(const float* xyz, int64_t B, int64_t N, float inv_h, GridW
   // (1024 threads x up to 128 registers) need a whole free CU: alone they are faster (36 -> 20 us at
   // 16 x 25 600 points), underneath a saturating contraction stream they wait longer for one
   // (ball query 0.19 -> 0.42 ms per batch; the step time does not move, geometry has slack there).
-  static const bool loop = [] { const char* e = getenv("S4G_GRID_BUILD"); return e && e[0] == 'l'; }();
+  static const bool loop = [] { const char* e = s4g::knob("S4G_GRID_BUILD"); return e && e[0] == 'l'; }();
   if (loop) S4G_GB_LAUNCH(0);
   else if (N <= 8 * GR_BUILD_THREADS) S4G_GB_LAUNCH(8);
   else if (N <= 25 * GR_BUILD_THREADS) S4G_GB_LAUNCH(25);
@@ -532,7 +532,7 @@ int launch_grid_build_queries(const float* xyz, const float* ctr, int64_t B, int
 enum { BQ_AUTO = 0, BQ_SCAN = 1, BQ_GRID = 2, BQ_CELL = 3 };
 
 static int bq_mode() {  // S4G_BQ_MODE=scan|grid|cell|auto (tuning / test knob, read per call)
-  const char* e = getenv("S4G_BQ_MODE");
+  const char* e = s4g::knob("S4G_BQ_MODE");
   if (e && e[0] == 's') return BQ_SCAN;
   if (e && e[0] == 'g') return BQ_GRID;
   if (e && e[0] == 'c') return BQ_CELL;
@@ -608,7 +608,7 @@ static int ball_query_dispatch(const float* xyz, const float* ctr, int64_t B,
     if (int rc = launch_grid_build_queries(xyz, ctr, B, N, M, inv_h, g, cw, st, false)) return rc;
     // workgroups per scene: a workgroup strides over the scene's non-empty centre quads
     int64_t wps = 4096 / B;
-    if (const char* e = getenv("S4G_BQ_CELL_WGS")) wps = atoi(e);
+    if (const char* e = s4g::knob("S4G_BQ_CELL_WGS")) wps = atoi(e);
     if (wps < 32) wps = 32;
     const int64_t max_quads = (M < GR_RANGES * GR_RANGE_SLOTS / 4) ? M : GR_RANGES * GR_RANGE_SLOTS / 4;
     if (wps > max_quads) wps = max_quads;

@@ -1603,7 +1603,7 @@ static FpsSortWs fps_sort_ws(void* base, int64_t B, int64_t N) {
 // S4G_FPS_MODE=cluster the two-CU full scan (opt-in, B <= 128), =hybrid the one-CU full scan
 static bool fps_use_pruned_l2(int64_t N, int64_t M) {
   if (N <= (int64_t)512 * 50 || N > FPS_L2_CAP_BIG || M < 64) return false;
-  const char* e = getenv("S4G_FPS_MODE");
+  const char* e = s4g::knob("S4G_FPS_MODE");
   return !(e && (e[0] == 'c' || e[0] == 'h' || e[0] == 'd'));
 }
 
@@ -1614,7 +1614,7 @@ static bool fps_use_pruned(int64_t N, int64_t M) {
   // bookkeeping (SA2 size, 5 120 -> 1 024: 0.94 ms dense vs 1.28 ms pruned) -- unless the chain is long:
   // from 2 048 picks on the pruned kernel wins from 10 points per lane (round 4, 16 scenes in step,
   // M = 5 120: N = 6 000 4.2 vs 7.3 ms, 8 192 4.3 vs 7.4, 10 240 4.5 vs 7.2)
-  const char* e = getenv("S4G_FPS_MODE");
+  const char* e = s4g::knob("S4G_FPS_MODE");
   if (e && e[0] == 'd') return false;
   if (N > (int64_t)512 * 50) return false;
   if (e && e[0] == 'p') return N > 512 * 5;
@@ -1643,7 +1643,7 @@ static int ref_block_lg(int64_t n) {
 // single-CU hybrid kernel, which has no such requirement.
 #ifdef S4G_VARIANTS
 static bool fps_use_cluster(int64_t B) {
-  const char* e = getenv("S4G_FPS_MODE");
+  const char* e = s4g::knob("S4G_FPS_MODE");
   return e && e[0] == 'c' && 2 * B <= 256;
 }
 static size_t fps_cluster_ws_bytes(int64_t B) { return (size_t)B * 4 * sizeof(FpsXch) + 64; }
@@ -1733,7 +1733,7 @@ static int launch_fps(const float* xyz, int64_t B, int64_t N, int64_t M,
   // steps the full-scan kernel runs in front of the pruned one (S4G_FPS_DENSE_STEPS; 0 = none: the pruned
   // kernel starts from +inf min-distances by itself)
   int dense_steps = 0;
-  if (const char* e = getenv("S4G_FPS_DENSE_STEPS")) dense_steps = atoi(e) > 1 ? atoi(e) : 0;
+  if (const char* e = s4g::knob("S4G_FPS_DENSE_STEPS")) dense_steps = atoi(e) > 1 ? atoi(e) : 0;
   if (dense_steps >= M) pruned = false;
   if (pruned) {
     const int G = 8 * (N <= 512 * 10 ? 10 : N <= 512 * 20 ? 20 : N <= 512 * 32 ? 32 : 50);   // groups of the pruned launch below

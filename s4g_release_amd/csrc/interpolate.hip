@@ -379,7 +379,7 @@ extern "C" int s4g_three_interpolate_ws_f32(const float* feat_bcn2, const int64_
                      dim3((unsigned)((N2 + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B), dim3(256), 0,
                      st, feat_bcn2, (int)C, (int)N2, featT);
   S4G_LAUNCH_CHECK();
-  const bool tiled = getenv("S4G_INTERP_MODE") == nullptr || getenv("S4G_INTERP_MODE")[0] != 'l';
+  const bool tiled = s4g::knob("S4G_INTERP_MODE") == nullptr || s4g::knob("S4G_INTERP_MODE")[0] != 'l';
   if (tiled && ((uintptr_t)out_bcn1 & 15) == 0) {
     const int tiles_x = (int)((N1 + s4g::IPT_PTS - 1) / s4g::IPT_PTS);
     const int tiles_y = (int)((C + s4g::IPT_CH - 1) / s4g::IPT_CH);

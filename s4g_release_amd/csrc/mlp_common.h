@@ -27,25 +27,48 @@ __device__ __forceinline__ uint32_t pack_h2(float a, float b) {
 // x s and the residual are exact in fp32 and every half is rounded once; the mixed-precision FMA
 // forms convert on the way out and read h's halves directly (4 instructions per pair instead of
 // the 10 of multiply / convert / convert back / subtract / convert / pack).
-__device__ __forceinline__ void split_pair_h(float x0, float x1, float s, uint32_t& h, uint32_t& l) {
-  uint32_t hh, ll;
-  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hh) : "v"(x0), "v"(s));
-  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hh) : "v"(x1), "v"(s));
-  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ll) : "v"(x0), "v"(s), "v"(hh));
-  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ll) : "v"(x1), "v"(s), "v"(hh));
-  h = hh;
-  l = ll;
+//
+// ONE asm block per two pairs, interleaved: v_fma_mixhi writes a register HALF (op_sel destination), and gfx940-class
+// hardware wants a wait state between such a write and a VALU read of that register (LLVM's dst-sel forwarding hazard).
+// The hazard recognizer does not look inside inline asm and is free to place separate asm statements back to back, so the
+// distance is built into the block: every read of h01 / h23 sits at least two instructions behind the mixhi that
+// completed it, whatever the compiler schedules around the block.
+__device__ __forceinline__ void split_quad_h2(float x0, float x1, float x2, float x3, float s0, float s1, float s2, float s3,
+                                              uint32_t& h01, uint32_t& l01, uint32_t& h23, uint32_t& l23) {
+  uint32_t ha, hb, la, lb;
+  asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
+      "v_fma_mixhi_f16 %0, %5, %9, 0\n\t"
+      "v_fma_mixlo_f16 %1, %6, %10, 0\n\t"
+      "v_fma_mixhi_f16 %1, %7, %11, 0\n\t"
+      "v_fma_mixlo_f16 %2, %4, %8, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %2, %5, %9, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %3, %6, %10, -%1 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %3, %7, %11, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(ha), "=&v"(hb), "=&v"(la), "=&v"(lb)
+      : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(s0), "v"(s1), "v"(s2), "v"(s3));
+  h01 = ha;
+  h23 = hb;
+  l01 = la;
+  l23 = lb;
 }
 
-// the same with a scale of its own per element (per-channel factors in an accumulator epilogue)
-__device__ __forceinline__ void split_pair_h2(float x0, float x1, float s0, float s1, uint32_t& h, uint32_t& l) {
-  uint32_t hh, ll;
-  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hh) : "v"(x0), "v"(s0));
-  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hh) : "v"(x1), "v"(s1));
-  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ll) : "v"(x0), "v"(s0), "v"(hh));
-  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ll) : "v"(x1), "v"(s1), "v"(hh));
-  h = hh;
-  l = ll;
+__device__ __forceinline__ void split_quad_h(float x0, float x1, float x2, float x3, float s,
+                                             uint32_t& h01, uint32_t& l01, uint32_t& h23, uint32_t& l23) {
+  uint32_t ha, hb, la, lb;
+  asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
+      "v_fma_mixhi_f16 %0, %5, %8, 0\n\t"
+      "v_fma_mixlo_f16 %1, %6, %8, 0\n\t"
+      "v_fma_mixhi_f16 %1, %7, %8, 0\n\t"
+      "v_fma_mixlo_f16 %2, %4, %8, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %2, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %3, %6, %8, -%1 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(ha), "=&v"(hb), "=&v"(la), "=&v"(lb)
+      : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(s));
+  h01 = ha;
+  h23 = hb;
+  l01 = la;
+  l23 = lb;
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -58,11 +81,9 @@ __device__ __forceinline__ void split2_h(const float4 v, float s, uint2& h, uint
     float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
 #pragma unroll
     for (int e = 0; e < 4; ++e) x[e] = __builtin_amdgcn_fmed3f(x[e], -65504.f, 65504.f);
-    split_pair_h(x[0], x[1], 1.0f, h.x, l.x);
-    split_pair_h(x[2], x[3], 1.0f, h.y, l.y);
+    split_quad_h(x[0], x[1], x[2], x[3], 1.0f, h.x, l.x, h.y, l.y);
   } else {
-    split_pair_h(v.x, v.y, s, h.x, l.x);
-    split_pair_h(v.z, v.w, s, h.y, l.y);
+    split_quad_h(v.x, v.y, v.z, v.w, s, h.x, l.x, h.y, l.y);
   }
 }
 

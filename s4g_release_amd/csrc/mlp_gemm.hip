@@ -1256,8 +1256,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
     const float s_w = __uint_as_float((268u - ew) << 23);
     epi_s[lane] = __uint_as_float((ew - 14u) << 23) * inv_a * sa;
     uint32_t wh01, wl01, wh23, wl23;
-    split_pair_h(wv0.x, wv0.y, s_w, wh01, wl01);
-    split_pair_h(wv0.z, bq, s_w, wh23, wl23);
+    split_quad_h(wv0.x, wv0.y, wv0.z, bq, s_w, wh01, wl01, wh23, wl23);
     uint4 af0[NRB][2], bf0[2][2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
@@ -1268,8 +1267,7 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
     for (int rb = 0; rb < NRB; ++rb) {
       const float one_r = p0 + wr * WROWS + rb * 32 + li < p.P ? one : 0.f;
       uint32_t h01, l01, h23, l23;
-      split_pair_h(rv0[rb].x, rv0[rb].y, s_a, h01, l01);
-      split_pair_h(rv0[rb].z, one_r, s_a, h23, l23);
+      split_quad_h(rv0[rb].x, rv0[rb].y, rv0[rb].z, one_r, s_a, h01, l01, h23, l23);
       af0[rb][0] = make_uint4(h01, h23, 0u, 0u);
       af0[rb][1] = make_uint4(l01, l23, 0u, 0u);
     }
@@ -1280,8 +1278,12 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
     // statement as a vector-ALU write, so it does not pad the VALU-write -> MFMA-read distance -- the first MFMA read
     // the ONE slot's half before the v_fma_mixhi two instructions earlier had landed (found by the test: the bias
     // term's low plane missing in one row block).  Everywhere else the split's results go through LDS first.
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 7" ::: "memory");
+    // The wait is TIED to the registers it protects: the s_nop's asm statement takes every asm-produced fragment word as
+    // an in/out operand, so the splits must be scheduled before it and the MFMAs (which read its outputs) after it -- by
+    // data dependence, not by where the statement happens to sit between two scheduling barriers.
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+      asm volatile("s_nop 7" : "+v"(af0[rb][0].x), "+v"(af0[rb][0].y), "+v"(af0[rb][1].x), "+v"(af0[rb][1].y));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
@@ -1300,8 +1302,9 @@ __global__ __launch_bounds__(RW == 8 ? 512 : 256, (PL == 1 && RW != 8 && S4G_CHA
         for (int pb = 0; pb < NRB; ++pb) {
           uint16_t* dst = Ah + (wr * WROWS + pb * 32 + li) * astr + wc * 64 + nb * 32 + 8 * j + 4 * lh;
           uint2 h, l;
-          split_pair_h2(fmaxf(acc[nb][pb][4 * j], 0.f), fmaxf(acc[nb][pb][4 * j + 1], 0.f), f4.x, f4.y, h.x, l.x);
-          split_pair_h2(fmaxf(acc[nb][pb][4 * j + 2], 0.f), fmaxf(acc[nb][pb][4 * j + 3], 0.f), f4.z, f4.w, h.y, l.y);
+          split_quad_h2(fmaxf(acc[nb][pb][4 * j], 0.f), fmaxf(acc[nb][pb][4 * j + 1], 0.f),
+                        fmaxf(acc[nb][pb][4 * j + 2], 0.f), fmaxf(acc[nb][pb][4 * j + 3], 0.f), f4.x, f4.y, f4.z, f4.w,
+                        h.x, l.x, h.y, l.y);
           *reinterpret_cast<uint2*>(dst) = h;
           *reinterpret_cast<uint2*>(dst + aplane) = l;
         }
@@ -1738,7 +1741,7 @@ static int launch_gemm_f16x2(const GemmParams& p, int groups, hipStream_t st) {
   // S4G_GEMM_RESIDENT=0 never / 1 whenever the shape qualifies / unset: only where it
   // measured faster than the tiled kernel (Cout >= 1024: +6 %; short strips lose to
   // the per-workgroup prologue)
-  const char* rmode = getenv("S4G_GEMM_RESIDENT");
+  const char* rmode = s4g::knob("S4G_GEMM_RESIDENT");
   const bool no_resident = rmode && rmode[0] == '0';
   const bool any_resident = rmode && rmode[0] == '1';
   if constexpr (EPI != EPI_CHANNEL_FIRST && LOADER != LOAD_INTERP && LOADER != LOAD_INTERP_ADD) {
@@ -1981,7 +1984,7 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
     // (f16x2 form; S4G_MLP1_MFMA=0, read per launch: the vector-ALU loader, for tests and A/B runs)
     if (h2 && d->loader == S4G_GEMM_LOAD_GATHER_MLP1 && d->rel_xyz4 && d->epilogue == S4G_GEMM_EPI_MAX &&
         d->Kpad16 == d->Cout && d->Cin <= d->Cout && (c128 || c256)) {
-      const char* m0 = getenv("S4G_MLP1_MFMA");
+      const char* m0 = s4g::knob("S4G_MLP1_MFMA");
       if (!(m0 && m0[0] == '0'))
         return c128 ? launch_mlp_chain<LOAD_REL_MLP1, EPI_MAX, 2, 1, 2>(p, d->groups, st)
                     : launch_mlp_chain<LOAD_REL_MLP1, EPI_MAX, 1, 1, 2>(p, d->groups, st);
@@ -1999,7 +2002,7 @@ extern "C" int s4g_mlp_gemm_f32(const s4g_gemm_desc_t* d, s4g_stream_t stream) {
   // 64 positions x 256 channels per workgroup, the 256-channel strips of a wider layer as groups that
   // share A (S4G_GEMM_SINGLE_CHAIN=0: the tiled kernel)
   {
-    const char* sc_env = getenv("S4G_GEMM_SINGLE_CHAIN");   // (read per launch: a test knob)
+    const char* sc_env = s4g::knob("S4G_GEMM_SINGLE_CHAIN");   // (read per launch: a test knob)
     const bool single_chain = !(sc_env && sc_env[0] == '0');
     const bool bf1 = d->precision == S4G_GEMM_BF16;
     const int kc = d->Kpad16 / 256;

@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void three_nn_f64_kernel(const double* __restr
     }
   }
   const size_t o = ((size_t)b * N1 + i) * 3;
-  idx[o] = i0; idx[o + 1] = i1; idx[o + 2] = i2;
+  // (an unfilled slot -- non-finite query -- as index 0, never the initialiser -1: see three_nn.hip nn_safe_index)
+  idx[o] = i0 < 0 ? 0 : i0; idx[o + 1] = i1; idx[o + 2] = i2;
   d2[o] = b0; d2[o + 1] = b1; d2[o + 2] = b2;
 }
 

@@ -15,6 +15,24 @@
   } while (0)
 
 #include <atomic>
+#include <cstdlib>
+#include <cstring>
+
+namespace s4g {
+// A/B and test knobs (include/s4g_ops.h lists them): read from the environment ONLY when the process also sets
+// S4G_TEST_KNOBS=1 (or the library is a -DS4G_VARIANTS measurement build).  A production process that does not set the
+// master switch cannot have its kernel selection changed by a stray variable in some launcher's environment; every knob
+// selects an exact path, so the switch changes speed, never results.  Not cached: tests flip it within one process.
+inline bool test_knobs_enabled() {
+#ifdef S4G_VARIANTS
+  return true;
+#else
+  const char* m = getenv("S4G_TEST_KNOBS");
+  return m && m[0] == '1' && m[1] == 0;
+#endif
+}
+inline const char* knob(const char* name) { return test_knobs_enabled() ? getenv(name) : nullptr; }
+}  // namespace s4g
 
 namespace s4g {
 

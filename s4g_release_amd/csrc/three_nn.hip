@@ -20,6 +20,15 @@ namespace s4g {
 
 constexpr int NN_THREADS = 256;
 
+// A slot that no key ever entered (a query with a NaN / inf coordinate, or coordinates so large that every squared
+// distance overflows: `d < best` is never true) keeps the reference's distance, but its index is written as 0 where the
+// reference leaves its initialiser -1 (interpolate_kernel.cu:54) and the grid search its internal sentinel: the
+// consumers -- three_interpolate, its backward scatter, the fused loaders -- index feature rows with it, and an
+// out-of-range row is a GPU memory fault that takes the whole process down (found by
+// tests/test_batch_invariance_gpu.py::test_nonfinite_scene_is_contained_and_refused_on_request).  In-contract inputs
+// (finite coordinates, N2 >= 3) fill all three slots: nothing changes for them, bit for bit.
+__device__ __forceinline__ int nn_safe_index(int j, int N2) { return (unsigned)j < (unsigned)N2 ? j : 0; }
+
 // WEIGHTS: write the inverse-distance weights of modules.py:118-120 instead of
 // the squared distances (same arithmetic as interp_weights_kernel below).
 template <bool FMAD, bool WEIGHTS, typename IdxT>
@@ -54,9 +63,9 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(
   }
   if (i < N1) {
     const size_t o = ((size_t)b * N1 + i) * 3;
-    idx[o + 0] = (IdxT)i0;
-    idx[o + 1] = (IdxT)i1;
-    idx[o + 2] = (IdxT)i2;
+    idx[o + 0] = (IdxT)nn_safe_index(i0, N2);
+    idx[o + 1] = (IdxT)nn_safe_index(i1, N2);
+    idx[o + 2] = (IdxT)nn_safe_index(i2, N2);
     if constexpr (WEIGHTS) {
       const float ia = __fdiv_rn(1.0f, b0 < eps ? eps : b0);
       const float ib = __fdiv_rn(1.0f, b1 < eps ? eps : b1);
@@ -93,10 +102,10 @@ __device__ __forceinline__ bool nn_less(float d, int j, float bd, int bj) {
 template <bool WEIGHTS, typename IdxT>
 __device__ __forceinline__ void nn_write(IdxT* __restrict__ idx, float* __restrict__ out, size_t o,
                                          int i0, int i1, int i2, float b0, float b1, float b2,
-                                         float eps) {
-  idx[o + 0] = (IdxT)i0;
-  idx[o + 1] = (IdxT)i1;
-  idx[o + 2] = (IdxT)i2;
+                                         float eps, int N2) {
+  idx[o + 0] = (IdxT)nn_safe_index(i0, N2);
+  idx[o + 1] = (IdxT)nn_safe_index(i1, N2);
+  idx[o + 2] = (IdxT)nn_safe_index(i2, N2);
   if constexpr (WEIGHTS) {
     const float ia = __fdiv_rn(1.0f, b0 < eps ? eps : b0);
     const float ib = __fdiv_rn(1.0f, b1 < eps ? eps : b1);
@@ -171,14 +180,14 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_split_kernel(
     }
   }
   if (i < N1 && sub == 0)
-    nn_write<WEIGHTS, IdxT>(idx, out, ((size_t)b * N1 + i) * 3, i0, i1, i2, b0, b1, b2, eps);
+    nn_write<WEIGHTS, IdxT>(idx, out, ((size_t)b * N1 + i) * 3, i0, i1, i2, b0, b1, b2, eps, N2);
 }
 
 // lane-per-query scan or, for the small key sets, the split scan (S4G_NN_SPLIT=0: never)
 template <bool FMAD, bool WEIGHTS, typename IdxT>
 static int launch_three_nn_scan(const float* q, const float* k, int64_t B, int64_t N1, int64_t N2,
                                 float eps, IdxT* idx, float* out, hipStream_t st) {
-  const char* e = getenv("S4G_NN_SPLIT");
+  const char* e = s4g::knob("S4G_NN_SPLIT");
   const bool split = !(e && e[0] == '0') && N2 >= 24 && N2 <= 2048;
   if (split) {
     const size_t lds = sizeof(float4) * (size_t)N2;
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_grid_kernel(
   }
   const bool done = exact && i2 != 0x7FFFFFFF && b2 < d2_done;
   if (done) {
-    nn_write<WEIGHTS, IdxT>(idx, out, ((size_t)b * N1 + i) * 3, i0, i1, i2, b0, b1, b2, eps);
+    nn_write<WEIGHTS, IdxT>(idx, out, ((size_t)b * N1 + i) * 3, i0, i1, i2, b0, b1, b2, eps, N2);
   } else {
     fail_list[atomicAdd(fail_count, 1)] = b * N1 + i;
   }
@@ -512,7 +521,7 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_fallback_kernel(
       merge3(b0, b1, b2, i0, i1, i2, rd, rj);
       if (lane == 0)
         nn_write<WEIGHTS, IdxT>(idx, out, ((size_t)b * N1 + i) * 3, rj[0], rj[1], rj[2], rd[0],
-                                rd[1], rd[2], eps);
+                                rd[1], rd[2], eps, N2);
     }
     __syncthreads();
   }
@@ -609,7 +618,7 @@ static int launch_three_nn_grid(const float* q, const float* k, int64_t B, int64
   float* cell_dev = nullptr;   // header words 4, 5 of the fail list
   if (auto_cell) {
     cell_dev = reinterpret_cast<float*>(fail_count + 4);
-    static const float factor = [] { const char* e = getenv("S4G_NN_CELL_FACTOR"); return e ? (float)atof(e) : 1.75f; }();
+    static const float factor = [] { const char* e = s4g::knob("S4G_NN_CELL_FACTOR"); return e ? (float)atof(e) : 1.75f; }();
     hipLaunchKernelGGL(nn_auto_cell_kernel, dim3(NN_SAMPLES), dim3(64), 0, st, k, (int)B, (int)N2, fail_count, factor);
     S4G_LAUNCH_CHECK();
     cell = 1.0f;

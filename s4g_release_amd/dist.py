@@ -64,6 +64,11 @@ def pack_outputs(pred):
     """dict of (B, C_h, N) -> one contiguous (B, sum C_h, N) tensor + channel splits.  The fast path's
     `fused.PackedPred` already IS that tensor (the heads launch wrote the four outputs as its channel
     slices): it is returned as it stands, no copy; any other dict is concatenated."""
+    if hasattr(pred, "get") and pred.get("index") is not None:
+        # FusedPointNet2(..., topk=K): the (B, 21, K) tensor covers a scene's K kept points only and "index" says which --
+        # gathered without it the per-point channels would no longer say which scene points they belong to
+        raise ValueError("predictions over kept points (topk=) carry an 'index' entry that the head gather would drop: "
+                         "gather decoded poses instead (OutputGather('poses')), or gather pred['index'] alongside")
     chans = [pred[k].shape[1] for k in HEADS]
     packed = getattr(pred, "packed", None)
     if (packed is not None and packed.is_contiguous() and packed.shape[1] == sum(chans) and
@@ -253,6 +258,8 @@ def gather_check(gather, pred, scene_points=None, group=None):
     returns a summary for the bench line."""
     local = gather.local_payload(pred, scene_points)
     out = gather.as_list(gather(pred, scene_points))
+    if group is None:
+        group = getattr(gather, "group", None)      # the sub-group the gather itself runs on
     if dist.is_initialized():
         world, rank = dist.get_world_size(group), dist.get_rank(group)
     else:

@@ -19,6 +19,7 @@ Differences, all deliberate:
   * inputs are consumed channel-first as they come -- no transposed copies.
 """
 import os
+import warnings
 
 import torch
 
@@ -50,11 +51,20 @@ def set_backward_mode(mode):
     _BACKWARD_MODE = mode
 
 
+_DET_FALLBACK_WARNED = False
+
+
 def _scatter_ws(dev, B, N, T, C=0, weighted=False):
     """Workspace of the deterministic scatters (with room for the channels-last copy of the gradients from 32 channels
     on), or (None, 0) where the sizes are outside their 32-bit keys."""
     nbytes = _cabi.lib().s4g_scatter_det_workspace_bytes_c(B, C, N, T, int(weighted))
     if nbytes == 0:
+        global _DET_FALLBACK_WARNED
+        if not _DET_FALLBACK_WARNED:      # once: the mode still says 'deterministic', the sums below are not
+            _DET_FALLBACK_WARNED = True
+            warnings.warn("s4g backward: B*T or B*N reaches 2^31 (B=%d, N=%d, T=%d): outside the deterministic scatter's "
+                          "32-bit keys, falling back to the atomic (order-nondeterministic) kernels for this size"
+                          % (B, N, T), RuntimeWarning, stacklevel=3)
         return None, 0
     return torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes
 
@@ -399,7 +409,7 @@ def _point_search(query_xyz, key_xyz, num_neighbours):
     dist = torch.empty((B, N1, 3), dtype=torch.float32, device=query_xyz.device)
     nbytes_alg = B * (12 * N2 + 12 * N1 + 24 * N1 + 12 * N1)
     use_grid = (2048 <= N2 <= 65536 and B * N1 > 0 and
-                os.environ.get("S4G_NN_MODE", "grid") != "scan")
+                _cabi.knob("S4G_NN_MODE", "grid") != "scan")
     cell = -1.0   # the library derives the cell edge from the keys' extent on the device
     with torch.cuda.device(query_xyz.device):
         if use_grid:

@@ -139,7 +139,7 @@ class _Layer:
 class FusedPointNet2:
     """Callable with the reference forward's signature: {"scene_points": (B,3,N)} -> dict."""
 
-    def __init__(self, net, precision=None, fold_only=False):
+    def __init__(self, net, precision=None, fold_only=False, check_finite=False):
         """net: `model.PointNet2` or the reference's own `PointNet2_tcls.PointNet2` instance (the attributes read
         are the reference's: `sa_modules[i].{sampler, grouper.{radius, num_neighbours}, mlp, in_channels,
         num_centroids}`, `fp_modules[i].{interpolator._eps, mlp}`, `mlp_seg / seg_logit / mlp_R / R_logit / mlp_t /
@@ -153,7 +153,14 @@ class FusedPointNet2:
         fp32 round-off, half the speed), "fp32" (fp32-input MFMA, an exact fma
         chain) or "bf16" (plain bf16 inputs, fp32 accumulate -- reduced precision,
         outside the 1e-4 bar; the bf16 roofline configuration of BASELINE.json
-        configs[4]).  S4G_GEMM_MODE overrides the default."""
+        configs[4]).  S4G_GEMM_MODE overrides the default.
+        check_finite: (debug) `submit` refuses a batch with a NaN / inf coordinate, naming the scenes -- costs one
+        device synchronisation per call.  Non-finite coordinates are out of contract (as for the reference's kernels:
+        SURVEY.md Appendix A.1); without the check a non-finite scene is contained -- it can neither fault nor touch
+        another scene's results (per-scene grids and per-scene activation scales: tests/test_batch_invariance_gpu.py)
+        -- but ITS outputs are unspecified: the contraction kernels are built with -fno-honor-nans (csrc/Makefile), so
+        where the reference would hand a visible NaN through ReLU / max-pool, these may return finite garbage."""
+        self.check_finite = bool(check_finite)
         if precision is None:
             precision = os.environ.get("S4G_GEMM_MODE", "f16x2")
         if precision not in ("f16x2", "bf16x3", "fp32", "bf16"):
@@ -161,31 +168,31 @@ class FusedPointNet2:
         self.precision = precision
         self.dense_streams = max(1, int(os.environ.get("S4G_DENSE_STREAMS", "1")))
         # S4G_GEMM_FUSE2=0: never fuse the last two layers of an SA level into one launch
-        self.fuse2 = os.environ.get("S4G_GEMM_FUSE2", "1") != "0"
-        self.fuse3 = os.environ.get("S4G_GEMM_FUSE3", "1") != "0"   # + first head layer
+        self.fuse2 = _cabi.knob("S4G_GEMM_FUSE2", "1") != "0"
+        self.fuse3 = _cabi.knob("S4G_GEMM_FUSE3", "1") != "0"   # + first head layer
         # S4G_FP_LINEAR_FIRST=0: interpolate first, like the reference (fused into the
         # contraction's loader); default: first FP layer before the interpolation
-        self.fp_linear_first = os.environ.get("S4G_FP_LINEAR_FIRST", "1") != "0"
+        self.fp_linear_first = _cabi.knob("S4G_FP_LINEAR_FIRST", "1") != "0"
         # FP levels whose interpolate + add + ReLU happens in the next launch's loader:
         # S4G_FP_LOADER_ADD = "auto" (default: where that launch is a fused chain, whose panel is
         # loaded once -- the tiled kernel would repeat the gathers per column tile: measured
         # 0.41 ms against 0.14 + 0.18 ms at FP level 1), "none", or a comma list of levels
-        v = os.environ.get("S4G_FP_LOADER_ADD", "auto")
+        v = _cabi.knob("S4G_FP_LOADER_ADD", "auto")
         self.fp_loader_add = v if v in ("auto", "none") else set(int(t) for t in v.split(",") if t)
         self.geo_streams = max(1, int(os.environ.get("S4G_GEO_STREAMS", "2")))
-        self.rel_xyz = os.environ.get("S4G_REL_XYZ", "1") != "0"
+        self.rel_xyz = _cabi.knob("S4G_REL_XYZ", "1") != "0"
         # first SA level on a centroid's DISTINCT rows only (ball_query pads short balls with copies of the
         # first hit, the max over the neighbours cannot see them): S4G_SA_UNIQUE=0 contracts all K rows
-        self.sa_unique = os.environ.get("S4G_SA_UNIQUE", "1") != "0"
-        self.heads_pre = os.environ.get("S4G_HEADS_PRE", "1") != "0"
+        self.sa_unique = _cabi.knob("S4G_SA_UNIQUE", "1") != "0"
+        self.heads_pre = _cabi.knob("S4G_HEADS_PRE", "1") != "0"
         # layers that read the SAME tensor as one launch with two outputs (an SA level's per-point layer and
         # the mirror FP level's skip-feature layer both read that level's features): S4G_MERGE_SHARED=0 splits
-        self.merge_shared = os.environ.get("S4G_MERGE_SHARED", "1") != "0"
-        self.fp_chain_next = os.environ.get("S4G_FP_CHAIN_NEXT", "1") != "0"
-        self.fps_prefix = os.environ.get("S4G_FPS_PREFIX", "1") != "0"
+        self.merge_shared = _cabi.knob("S4G_MERGE_SHARED", "1") != "0"
+        self.fp_chain_next = _cabi.knob("S4G_FP_CHAIN_NEXT", "1") != "0"
+        self.fps_prefix = _cabi.knob("S4G_FPS_PREFIX", "1") != "0"
         # the four head tensors as channel slices of ONE (B, 21, N) tensor (`PackedPred.packed`: the payload of
         # the multi-GPU all-gather, dist.py, without a packing copy); S4G_PACKED_OUT=0: four tensors of their own
-        self.packed_out = os.environ.get("S4G_PACKED_OUT", "1") != "0"
+        self.packed_out = _cabi.knob("S4G_PACKED_OUT", "1") != "0"
         p = next(net.parameters())
         self.fold_only = bool(fold_only)
         if not p.is_cuda and not fold_only:
@@ -220,7 +227,7 @@ class FusedPointNet2:
             radius = float(sa.grouper.radius)
             pre = None
             if (sa.in_channels > 0 and sa.in_channels % 4 == 0 and len(sa.mlp) > 1 and
-                    layers[0].cout % 4 == 0 and os.environ.get("S4G_SA_LINEAR_FIRST", "1") != "0"):
+                    layers[0].cout % 4 == 0 and _cabi.knob("S4G_SA_LINEAR_FIRST", "1") != "0"):
                 # a level WITH input features: its first layer is linear, so the feature part is
                 # applied once per POINT (N rows) instead of once per (centroid, neighbour) pair
                 # (M*K rows, every point ~K*M/N times); the xyz part + bias + ReLU move into the
@@ -279,7 +286,7 @@ class FusedPointNet2:
         # the layer-chain launches
         hl = self.head_layers
         self.heads_fused = None
-        if (os.environ.get("S4G_HEADS_FUSED", "1") != "0" and precision in ("f16x2", "bf16") and depth == 4 and
+        if (_cabi.knob("S4G_HEADS_FUSED", "1") != "0" and precision in ("f16x2", "bf16") and depth == 4 and
                 hl[0].cin == 256 and hl[0].cout == 4 * 512 and
                 [(l.cout, l.cin, l.groups) for l in hl[1:]] == [(256, 512, 4), (256, 256, 4), (128, 256, 4)] and
                 cl == 128 and max(chans) <= 32 and len(chans) == 4):
@@ -332,7 +339,7 @@ class FusedPointNet2:
                 l2.cin == c and l2.kpad16 == c and l2.cout % 64 == 0 and
                 l1.Wfrag is not None and l2.Wfrag is not None):
             return False
-        if c == 512 and os.environ.get("S4G_GEMM_FUSE512", "1") == "0":
+        if c == 512 and _cabi.knob("S4G_GEMM_FUSE512", "1") == "0":
             return False
         if l1.kpad16 != c and not self.fuse3:
             return False
@@ -570,7 +577,7 @@ class FusedPointNet2:
         N2 = k.shape[2]
         idx = torch.empty((B, N1, 3), dtype=torch.int32, device=q.device)
         w = torch.empty((B, N1, 3), dtype=torch.float32, device=q.device)
-        if cell != 0.0 and 2048 <= N2 <= 65536 and os.environ.get("S4G_NN_MODE", "grid") != "scan":
+        if cell != 0.0 and 2048 <= N2 <= 65536 and _cabi.knob("S4G_NN_MODE", "grid") != "scan":
             # cell > 0: that edge; cell < 0: chosen on the device from the keys' measured spacing
             nbytes = _cabi.lib().s4g_three_nn_grid_workspace_bytes(B, N1, N2)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
@@ -988,6 +995,10 @@ class FusedPointNet2:
         if xyz.dim() != 3 or xyz.size(1) != 3:
             raise RuntimeError("scene_points must be (B, 3, N)")
         dev = xyz.device
+        if self.check_finite:
+            bad = (~torch.isfinite(xyz)).flatten(1).any(dim=1).nonzero().flatten().tolist()
+            if bad:
+                raise ValueError("scene_points: non-finite coordinates in scene(s) %s of the batch" % bad)
         _F.OpTimer.begin_pass()
         if self._streams is None or self._streams[0][0].device != dev:
             # high-priority geometry streams: FPS is a latency chain on one CU per

@@ -8,6 +8,8 @@ instead of 21 x N.  Collision filtering (row f2) is not part of it.
 """
 import ctypes
 import math
+import threading
+from collections import OrderedDict
 from dataclasses import dataclass
 
 import torch
@@ -38,14 +40,36 @@ def _dev_const(key, make, device):
     return t
 
 
+_SMALL_LRU = OrderedDict()      # caller-supplied small matrices by value, at most _SMALL_LRU_MAX of them
+_SMALL_LRU_MAX = 16
+_SMALL_LOCK = threading.Lock()
+
+
 def _small_on_device(x, dtype, device):
     """A caller's small matrix / vector (nested tuples, numpy, CPU tensor) on the device WITHOUT a per-call host -> device
-    copy: cached by value (a tensor already on the device passes through)."""
-    if isinstance(x, torch.Tensor) and x.device == device:
-        return x.to(dtype)
+    copy where the value repeats: a BOUNDED least-recently-used cache by value (16 entries -- `direction_matrix =
+    camera2base[:3, :3] @ TRAIN2REAL` changes per capture on a moving camera; an unbounded cache would pin one device
+    allocation per distinct pose for good).  A value holding NaN is never cached (NaN != NaN: it would miss on every
+    call and leak).  A tensor that already lives on a device is passed through (`.to`): no host copy, no `.tolist()`
+    synchronisation -- a serving loop that builds its matrices on the device pays nothing here."""
+    if isinstance(x, torch.Tensor) and x.device.type != "cpu":
+        return x.to(device=device, dtype=dtype)
     t = torch.as_tensor(x, dtype=torch.float64)
-    key = ("small", tuple(t.flatten().tolist()), tuple(t.shape), str(dtype))
-    return _dev_const(key, lambda: t.to(dtype), device)
+    vals = tuple(t.flatten().tolist())
+    if any(v != v for v in vals):
+        return t.to(dtype).to(device)
+    key = (vals, tuple(t.shape), str(dtype), str(device))
+    with _SMALL_LOCK:
+        hit = _SMALL_LRU.get(key)
+        if hit is not None:
+            _SMALL_LRU.move_to_end(key)
+            return hit
+    d = t.to(dtype).to(device)
+    with _SMALL_LOCK:
+        _SMALL_LRU[key] = d
+        while len(_SMALL_LRU) > _SMALL_LRU_MAX:
+            _SMALL_LRU.popitem(last=False)
+    return d
 
 
 def expected_score(score_logits, convention="demo"):
@@ -228,7 +252,7 @@ def detect_poses(predictions, scene_points, score_threshold=0.7, verticalness_th
     return H, top, sel, count
 
 
-def importance_sampling(score, count, num_selected, generator=None):
+def importance_sampling(score, count, num_selected, generator=None, uniforms=None):
     """grasp_detector.py:237-251 on the device: `num_selected` draws per scene from the first
     count[b] poses with probability proportional to exp(5 score) (sorted uniforms against the
     cumulative sum = systematic inverse-CDF sampling).  Returns indices (B, num_selected) into the
@@ -238,7 +262,10 @@ def importance_sampling(score, count, num_selected, generator=None):
     valid = torch.arange(K, device=dev).view(1, K) < count.view(B, 1)
     wgt = torch.where(valid, torch.exp(5.0 * score.double()), torch.zeros((), dtype=torch.float64, device=dev))
     cum = torch.cumsum(wgt, dim=1)
-    u = torch.rand((B, num_selected), generator=generator, device=dev, dtype=torch.float64)
+    if uniforms is not None:      # the draws passed in (tests; the reference calls np.random.rand(num_selected) unseeded)
+        u = torch.as_tensor(uniforms, dtype=torch.float64).to(dev).reshape(-1, num_selected).expand(B, -1)
+    else:
+        u = torch.rand((B, num_selected), generator=generator, device=dev, dtype=torch.float64)
     target = torch.sort(u, dim=1)[0] * cum[:, -1:]
     pick = torch.searchsorted(cum, target, right=False).clamp(max=K - 1)
     ar = torch.arange(num_selected, device=dev).view(1, -1).expand(B, -1)

@@ -7,6 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The A/B knobs of include/s4g_ops.h are honoured only with the master switch: the tests drive them (every alternative
+# path is checked against the default / the oracle), a production process never sets it.
+os.environ["S4G_TEST_KNOBS"] = "1"
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")

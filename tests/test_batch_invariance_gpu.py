@@ -202,3 +202,38 @@ def test_proven_and_sampled_scenes_share_a_batch(dev, monkeypatch):
     c0 = O.gather_points(pts[1:2], i0)
     assert np.array_equal(inf_["fps0"][1:2].cpu().numpy().astype(np.int64), i0)
     assert np.array_equal(f1[1:2], O.fps(c0, 1024))
+
+
+def test_nonfinite_scene_is_contained_and_refused_on_request(dev):
+    """Non-finite coordinates are out of contract (the reference's kernels: SURVEY.md Appendix A.1) and the contraction
+    kernels are built with -fno-honor-nans, so the behaviour is PINNED here rather than left to chance: a scene with a NaN
+    and an inf coordinate (an invalid depth pixel) shares a batch with two clean scenes -- the call completes, the clean
+    scenes' outputs and index tensors are bit-identical to their single-scene runs (the bad scene's outputs are
+    unspecified), and `FusedPointNet2(check_finite=True)` refuses the batch naming scene 1."""
+    from s4g_release_amd import synth
+    from s4g_release_amd.fused import FusedPointNet2
+    net = GU.shipped_net(dev)
+    pts = torch.from_numpy(synth.make_batch([0, 1, 2], 25600)).to(dev)
+    pts[1, 0, 77] = float("nan")
+    pts[1, 2, 4099] = float("inf")
+    run = FusedPointNet2(net)
+    with torch.no_grad():
+        full, inter = run({"scene_points": pts}, return_intermediates=True)
+        full = {k: v.clone() for k, v in full.items()}
+        inter = {k: v.clone() for k, v in inter.items()}
+        torch.cuda.synchronize()
+        for s in (0, 2):
+            one, i1 = run({"scene_points": pts[s:s + 1].contiguous()}, return_intermediates=True)
+            for k in HEADS:
+                assert torch.isfinite(full[k][s]).all() and torch.equal(one[k][0], full[k][s]), (s, k)
+            for k in ("fps0", "fps1", "fps2", "ball0", "ball2", "cnt0", "nn0", "nn2"):
+                assert torch.equal(i1[k][0], inter[k][s]), (k, s)
+    with torch.no_grad():      # the drop-in level too: the operators alone, under the reference-shaped modules
+        mod = net({"scene_points": pts})
+        torch.cuda.synchronize()
+        alone = net({"scene_points": pts[2:3].contiguous()})
+    for k in HEADS:
+        assert torch.isfinite(mod[k][2]).all() and (mod[k][2] - alone[k][0]).abs().max().item() <= 1e-4, k
+    with pytest.raises(ValueError, match=r"scene\(s\) \[1\]"):
+        FusedPointNet2(net, check_finite=True)({"scene_points": pts})
+    FusedPointNet2(net, check_finite=True)({"scene_points": pts[:1].contiguous()})

@@ -88,3 +88,38 @@ def test_measurement_build_with_the_kernel_variants_compiles(tmp_path):
     from s4g_release_amd import _cabi
     assert h.s4g_build_variants() == 1 and h.s4g_abi_version() == _cabi.S4G_ABI_VERSION
     shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+def test_ab_knobs_are_ignored_without_the_master_switch(monkeypatch):
+    """include/s4g_ops.h: the A/B / test knobs are read only with S4G_TEST_KNOBS=1 (tests/conftest.py sets it).  Host side
+    (`_cabi.knob`) and library side (`s4g_test_knobs_enabled`, csrc/s4g_common.h s4g::knob) agree; the production surface
+    is the seven variables the header lists and nothing else in the package reads the environment."""
+    import re
+    from s4g_release_amd import _cabi
+    monkeypatch.setenv("S4G_GEMM_FUSE2", "0")
+    assert _cabi.knob("S4G_GEMM_FUSE2", "1") == "0"
+    monkeypatch.delenv("S4G_TEST_KNOBS")
+    assert _cabi.knob("S4G_GEMM_FUSE2", "1") == "1" and _cabi.knob("S4G_GEMM_FUSE2") is None
+    monkeypatch.setenv("S4G_TEST_KNOBS", "yes")                    # only the literal "1" enables
+    assert _cabi.knob("S4G_GEMM_FUSE2", "1") == "1"
+    L = ctypes.CDLL(_cabi.LIB_PATH)                                 # no compute call: the symbol and its answer
+    L.s4g_test_knobs_enabled.restype = ctypes.c_int
+    variants = ctypes.CDLL(_cabi.LIB_PATH).s4g_build_variants()
+    assert L.s4g_test_knobs_enabled() == (1 if variants else 0)
+    monkeypatch.setenv("S4G_TEST_KNOBS", "1")
+    assert L.s4g_test_knobs_enabled() == 1
+    # every direct environment read in the package is one of the production variables (or torch.distributed's own)
+    allowed = {"S4G_TEST_KNOBS", "S4G_HIP_LIB", "S4G_GEMM_MODE", "S4G_DIST_MODE", "S4G_BACKWARD", "S4G_GEO_STREAMS",
+               "S4G_DENSE_STREAMS", "NCCL_MAX_NCHANNELS", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR"}
+    pkg = os.path.join(ROOT, "s4g_release_amd")
+    for f in sorted(os.listdir(pkg)):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            for name in re.findall(r'os\.environ(?:\.get|\.setdefault)?[\(\[]\s*"([A-Z0-9_]+)"', src):
+                assert name in allowed, (f, name)
+    csrc = os.path.join(pkg, "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            src = open(os.path.join(csrc, f)).read()
+            direct = re.findall(r'(?<![:\w])getenv\("([A-Z0-9_]+)"\)', src)
+            assert set(direct) <= {"S4G_TEST_KNOBS"}, (f, direct)

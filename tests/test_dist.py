@@ -221,6 +221,13 @@ def test_pack_outputs_hands_a_packed_pred_over_without_a_copy():
     pred["score"] = pred["score"].clone()
     out3, _ = sdist.pack_outputs(pred)
     assert out3.data_ptr() != packed.data_ptr() and torch.equal(out3, packed)
+    # predictions over kept points (topk=) carry "index": the head gather would drop it -> refused, not silently lossy
+    kept = PackedPred(zip(sdist.HEADS, packed.split([3, 9, 4, 5], dim=1)), packed=packed)
+    kept["index"] = torch.arange(11).expand(3, 11)
+    with pytest.raises(ValueError):
+        sdist.pack_outputs(kept)
+    with pytest.raises(ValueError):
+        sdist.all_gather_outputs(kept)
 
 
 def test_gather_check_passes_a_faithful_gather_and_refuses_a_corrupted_one():

@@ -149,3 +149,26 @@ def test_detector_oracle_literal_restatement_and_its_index_mixup():
     R = a[0][:, :3, :3]
     assert np.allclose(np.einsum("nij,nik->njk", R, R), np.eye(3), atol=1e-5)
     assert np.allclose(np.abs(np.linalg.det(R)), 1.0, atol=1e-5)
+
+
+def test_small_matrix_cache_is_bounded_and_skips_nan():
+    """postprocess._small_on_device: a caller's direction_matrix changes per capture on a moving camera -- the by-value
+    cache must stay bounded (LRU of 16), must not keep NaN-valued entries (NaN != NaN: a miss and a leak per call), and
+    must hand back the SAME device tensor for a repeated value (that is the point: no per-call host -> device copy)."""
+    from s4g_release_amd import postprocess as pp
+    cpu = torch.device("cpu")
+    pp._SMALL_LRU.clear()
+    a = pp._small_on_device(((1., 0., 0.), (0., 1., 0.), (0., 0., 1.)), torch.float32, cpu)
+    assert pp._small_on_device(np.eye(3), torch.float32, cpu) is a and len(pp._SMALL_LRU) == 1
+    for i in range(100):                                          # a moving camera: 100 distinct poses
+        m = pp._small_on_device(np.eye(3) * (1.0 + i), torch.float32, cpu)
+        assert float(m[0, 0]) == 1.0 + i and m.dtype == torch.float32
+    assert len(pp._SMALL_LRU) == pp._SMALL_LRU_MAX == 16
+    assert pp._small_on_device(np.eye(3), torch.float32, cpu) is not a      # evicted long ago, rebuilt
+    n = len(pp._SMALL_LRU)
+    for _ in range(5):
+        bad = pp._small_on_device((float("nan"), 0., 1.), torch.float32, cpu)
+        assert bad.shape == (3,) and bool(torch.isnan(bad[0]))
+    assert len(pp._SMALL_LRU) == n                                # NaN values never enter the cache
+    last = pp._small_on_device(np.eye(3) * 100.0, torch.float32, cpu)
+    assert pp._small_on_device(np.eye(3) * 100.0, torch.float64, cpu) is not last    # dtype is part of the key

@@ -40,6 +40,7 @@ def main():
         fps_mode = str(rng.choice(["", "dense", "pruned"]))
         bq_mode = str(rng.choice(["", "grid", "cell", "scan"]))
         fmad = bool(rng.integers(4) == 0)
+        os.environ["S4G_TEST_KNOBS"] = "1"      # the kernel-selection knobs are ignored without the master switch
         for k, v in (("S4G_FPS_MODE", fps_mode), ("S4G_BQ_MODE", bq_mode)):
             if v:
                 os.environ[k] = v
