@@ -34,6 +34,8 @@ Extra objects on the line:
   modules_path  the reference-shaped modules over the HIP operators on the same scenes (what swapping
                 only the extension buys), scenes/s
   precision_legs  the fast path in true-fp32 MFMA and exact 3 x bf16 arithmetic on the same batch
+  detect        the reference's production entry GraspDetector.detect composed on the device (detector.py): raw clouds in,
+                selected grasp poses out; scenes/s pipelined at the step's batch, per-stage ms, one-scene latency (eager / graph)
   weights_leg   the same step on the other network (--weights: `calibrated` is the default and the headline; `randomized`
                 is what rounds 1-5 timed)
   mixed_batch   2 of the 16 scenes tie-heavy: the conditional level-2 / level-3 FPS samplers run timed
@@ -504,7 +506,7 @@ def main():
     roofline_dense, kernels = dense_roofline(summary, timed_passes, precision)
 
     N, M, K = args.points, cfg.num_centroids[0], cfg.num_neighbours[0]
-    roofline = latency = io = configs4 = modules_path = precision_legs = mixed_batch = kept_points = weights_leg = None
+    roofline = latency = io = configs4 = modules_path = precision_legs = mixed_batch = kept_points = weights_leg = detect_leg = None
     # (the single-GPU probes below run at N = 1 only: at N > 1 the other ranks have left, rank 0 prints its line
     #  and tears the communicator down without making the job wait for figures the N = 1 line already carries)
     if not args.no_extras and world == 1:
@@ -747,6 +749,60 @@ def main():
                            "full_forward_plus_decode": {"value": round(B * k_steps / f_el, 2),
                                                         "ms_per_step": round(1e3 * f_el / k_steps, 3)},
                            "note": "not the headline metric: the headline forward leaves all 21 channels of every point"}
+            # ---- the reference's production entry, `GraspDetector.detect` (grasp_detector.py:187-254), composed on the
+            # device (s4g_release_amd/detector.py): raw 48 902-point clouds in (the size of the reference's sample scene),
+            # selected grasp poses out -- subsample + REAL2TRAIN, forward with the pose heads on the 2 048 best-scoring
+            # points, thresholds / decode / Gram-Schmidt, ONE batched collision launch against the whole raw cloud (the
+            # reference: a Python loop with a launch sequence and a host sync per pose, :216-234), survivor compaction,
+            # importance sampling; no host synchronisation inside.  NOT the headline.
+            from s4g_release_amd.detector import GraspDetector
+            n_raw = 48902
+            t_raw = synth.make_batch(scene_ids, n_raw, variant=args.variant)                 # TRAIN frame
+            raw = torch.from_numpy(np.ascontiguousarray(np.stack([t_raw[:, 1], t_raw[:, 0], -t_raw[:, 2]], axis=1))).to(dev)
+            det = GraspDetector(runner, topk=2048)
+            with torch.no_grad():
+                probe = PP.expected_score(runner({"scene_points": det.pre_processing(raw)})["score"].contiguous(), "detector")
+                d_thr = float(torch.quantile(probe.flatten().float()[:: 7], 0.98))      # ~500 candidates per scene
+            d_kw = dict(num_selected=5, score_threshold=d_thr, verticalness_threshold=-2.0, collision_check=True)
+
+            class _Detect:
+                def submit(self, data):
+                    return det.submit(data["cloud"], **d_kw)
+
+                def __call__(self, data):
+                    return self.submit(data).result()
+            d_steps, d_warm = 20, 5
+            with torch.no_grad():
+                d_el, d_step, _, _ = timed_region(d_steps, d_warm, collective=False, timers=False, run=_Detect(),
+                                                  data={"cloud": raw, "scene_points": raw}, gathered=False)
+                det.stage_events = []
+                out16 = det.detect_device(raw, **d_kw)
+                stage16 = det.stage_ms()
+                det.stage_events = []
+                det.detect_device(raw[:1].contiguous(), **d_kw)
+                stage1 = det.stage_ms()
+                det.stage_events = None
+                one_raw = raw[:1].contiguous()
+                lat1 = timed_forward_with(lambda c: det.detect_device(c, **d_kw), one_raw, 10)
+                g_det = det.graph(one_raw, **d_kw)
+                lat1_graph = timed_forward_with(g_det, one_raw, 20)
+                del g_det
+            detect_leg = {"workload": "GraspDetector.detect on the device: %d raw %d-point %s clouds per step -> 5 selected grasp "
+                                      "poses per scene (pre-processing as the reference executes it, forward with topk=2048, "
+                                      "decode, batched collision check against the raw cloud, importance sampling), pipelined"
+                                      % (B, n_raw, args.variant),
+                          "value": round(B * d_steps / d_el, 2), "unit": "scenes/sec",
+                          "ms_per_step": round(1e3 * d_el / d_steps, 3), "step_ms_median": d_step["median"],
+                          "steps": d_steps, "warmup": d_warm, "score_threshold": round(d_thr, 4),
+                          "candidates_per_scene_mean": round(float(out16.candidates[3].float().mean()), 1),
+                          "stage_ms_one_batch_of_%d" % B: {k: round(v, 3) for k, v in stage16.items()},
+                          "stage_ms_b1": {k: round(v, 3) for k, v in stage1.items()},
+                          "latency_ms_b1": round(lat1, 3), "latency_ms_b1_graph": round(lat1_graph, 3),
+                          "reference_stages": "grasp_detector.py logs the same stages per scene (:203 pre-processing, :209 "
+                                              "prediction, :231 collision check, :251 importance sampling); its collision "
+                                              "check is one launch sequence + host sync PER POSE",
+                          "note": "not the headline metric; stage times of an unpipelined call (HIP events between stages)"}
+            del det, raw, out16
             # ---- a batch that is NOT all "proven": 2 of the 16 scenes are `lattice` clouds (coordinates
             # snapped to a 3.9 mm lattice: exact distance ties), so the FPS prefix check refuses them and
             # the level-2 / level-3 samplers run inside the timed region (the headline's scenes all pass)
@@ -884,7 +940,7 @@ def main():
         # `roofline_ball_query_group_points`: the HBM-bound operator pair the north star names.
         "roofline": roofline_dense, "roofline_ball_query_group_points": roofline,
         "configs4": configs4, "modules_path": modules_path, "precision_legs": precision_legs,
-        "weights_leg": weights_leg, "mixed_batch": mixed_batch, "kept_points": kept_points, "collective": collective, "distributed": shards,
+        "weights_leg": weights_leg, "detect": detect_leg, "mixed_batch": mixed_batch, "kept_points": kept_points, "collective": collective, "distributed": shards,
         "step_ms": step_ms, "latency": latency, "io": io, "kernels": kernels,
         "cpu_baseline": cpu_baseline,
     }

@@ -52,7 +52,8 @@ extern "C" {
  * 10: s4g_group_points_backward_det_f32 / s4g_three_interpolate_backward_det_f32 / s4g_scatter_det_workspace_bytes
  *    (the backward scatters in a fixed order: run-to-run bit-identical, equal to the oracle's sequential sum).
  * 11: s4g_heads_desc_t.head_mask (a launch may evaluate a subset of the four heads).
- * 12: s4g_test_knobs_enabled (the A/B knobs below are ignored without S4G_TEST_KNOBS=1; no layout change). */
+ * 12: s4g_test_knobs_enabled (the A/B knobs below are ignored without S4G_TEST_KNOBS=1; no layout change),
+ *     s4g_collision_counts_n_f32 (collision counts over padded best-first pose lists with device-side counts). */
 #define S4G_ABI_VERSION 12
 
 /* ---------------------------------------------------------------------------
@@ -642,6 +643,12 @@ int s4g_decode_poses_f32(const float *xyz_b3n, const float *frame_R_b9n,
 int s4g_collision_counts_f32(const float *xyz_b3n, const float *g2l_bk44, int64_t B,
                              int64_t N, int64_t K, const float *gripper6,
                              int32_t *counts_bk2, s4g_stream_t stream);
+/* ABI 12: the same over best-first pose lists padded to K rows: only the first pose_count_b[b] (DEVICE int64, (B,)) rows
+ * of scene b are poses -- the rest get zero counts without scanning the cloud (detector.GraspDetector: K = 2 048 rows,
+ * a few dozen to a few hundred of them poses; the counts never visit the host). */
+int s4g_collision_counts_n_f32(const float *xyz_b3n, const float *g2l_bk44, int64_t B, int64_t N,
+                               int64_t K, const float *gripper6, const int64_t *pose_count_b,
+                               int32_t *counts_bk2, s4g_stream_t stream);
 
 /* ---- next row f3: cloud pre-processing on device -------------------------
  * Single-scene passes in front of the network (reference

@@ -106,6 +106,8 @@ SIGNATURES = {
     "s4g_decode_poses_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "s4g_collision_counts_f32": (_int, [_vp, _vp, _i64, _i64, _i64, ctypes.POINTER(ctypes.c_float),
                                         _vp, _vp]),
+    "s4g_collision_counts_n_f32": (_int, [_vp, _vp, _i64, _i64, _i64, ctypes.POINTER(ctypes.c_float),
+                                          _vp, _vp, _vp]),
     "s4g_query_group_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _vp, _sz,
                                    _int, _vp]),
     "s4g_crop_indices_f32": (_int, [_vp, _i64, ctypes.POINTER(ctypes.c_float), _vp, _vp, _vp]),

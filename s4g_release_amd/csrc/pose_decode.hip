@@ -126,9 +126,13 @@ struct GripperBox {
 
 __global__ __launch_bounds__(256) void collision_counts_kernel(
     const float* __restrict__ xyz, const float* __restrict__ g2l, int N, int K, GripperBox g,
-    int* __restrict__ counts) {
+    int* __restrict__ counts, const int64_t* __restrict__ pose_count) {
   __shared__ int sback[4], sfing[4];
   const int b = blockIdx.y, k = blockIdx.x, t = threadIdx.x;
+  if (pose_count && k >= pose_count[b]) {   // a padding row of a best-first list: no pose there, nothing to scan
+    if (t < 2) counts[((size_t)b * K + k) * 2 + t] = 0;
+    return;
+  }
   const float* G = g2l + ((size_t)b * K + k) * 16;   // row-major 4x4 global -> gripper frame
   const float g00 = G[0], g01 = G[1], g02 = G[2], g03 = G[3];
   const float g10 = G[4], g11 = G[5], g12 = G[6], g13 = G[7];
@@ -173,7 +177,22 @@ extern "C" int s4g_collision_counts_f32(const float* xyz_b3n, const float* g2l_b
   if (!xyz_b3n || !g2l_bk44 || !gripper6 || !counts_bk2) return S4G_EINVAL;
   s4g::GripperBox g = {gripper6[0], gripper6[1], gripper6[2], gripper6[3], gripper6[4], gripper6[5]};
   hipLaunchKernelGGL(s4g::collision_counts_kernel, dim3((unsigned)K, (unsigned)B), dim3(256), 0,
-                     (hipStream_t)stream, xyz_b3n, g2l_bk44, (int)N, (int)K, g, counts_bk2);
+                     (hipStream_t)stream, xyz_b3n, g2l_bk44, (int)N, (int)K, g, counts_bk2, (const int64_t*)nullptr);
+  S4G_LAUNCH_CHECK();
+  return S4G_OK;
+}
+
+// The same for best-first pose lists of which only the first pose_count_b[b] rows of scene b are poses (device counts:
+// the caller never reads them on the host): the padding rows get zero counts and cost one workgroup exit each.
+extern "C" int s4g_collision_counts_n_f32(const float* xyz_b3n, const float* g2l_bk44, int64_t B,
+                                          int64_t N, int64_t K, const float* gripper6,
+                                          const int64_t* pose_count_b, int32_t* counts_bk2, s4g_stream_t stream) {
+  if (B < 0 || N <= 0 || K < 0 || B > 65535 || N >= (1ll << 31)) return S4G_EINVAL;
+  if (B == 0 || K == 0) return S4G_OK;
+  if (!xyz_b3n || !g2l_bk44 || !gripper6 || !counts_bk2 || !pose_count_b) return S4G_EINVAL;
+  s4g::GripperBox g = {gripper6[0], gripper6[1], gripper6[2], gripper6[3], gripper6[4], gripper6[5]};
+  hipLaunchKernelGGL(s4g::collision_counts_kernel, dim3((unsigned)K, (unsigned)B), dim3(256), 0,
+                     (hipStream_t)stream, xyz_b3n, g2l_bk44, (int)N, (int)K, g, counts_bk2, pose_count_b);
   S4G_LAUNCH_CHECK();
   return S4G_OK;
 }

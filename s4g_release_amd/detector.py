@@ -106,9 +106,9 @@ class GraspDetector:
             idx = _F.farthest_point_sample(cloud, self.num_input)
         else:
             idx = self._subsample_index(n, [seed + b for b in range(B)], cloud.device)
-        g = torch.gather(cloud, 2, idx.unsqueeze(1).expand(-1, 3, -1))
+        g = _F.gather_points(cloud, idx)                  # (B, 3, num_input): the operator the samplers use
         # REAL2TRAIN (:26) is a signed permutation: (x, y, z) -> (y, x, -z), exact in fp32
-        return torch.stack([g[:, 1], g[:, 0], -g[:, 2]], dim=1).contiguous()
+        return torch.stack([g[:, 1], g[:, 0], -g[:, 2]], dim=1)
 
     # ---- the whole call
     def _mark(self, name):
@@ -117,11 +117,11 @@ class GraspDetector:
             ev.record()
             self.stage_events.append((name, ev))
 
-    def detect_device(self, cloud, num_selected=5, score_threshold=0.7, verticalness_threshold=0.2,
-                      collision_check=True, seed=None, uniforms=None, generator=None, collision_cloud=None):
-        """cloud (B, 3, n) fp32 on the device, REAL frame: what the network sees (the masked `target_cloud` of :199-203);
-        collision_cloud (B, 3, n_all): what the collision check sees (the whole `cloud_array`, :220-222; default: cloud)
-        -> `Detections`.  Nothing here waits for the device."""
+    def submit(self, cloud, num_selected=5, score_threshold=0.7, verticalness_threshold=0.2,
+               collision_check=True, seed=None, uniforms=None, generator=None, collision_cloud=None):
+        """Enqueue pre-processing and the forward pass of one batch and return a handle without waiting; `.result()`
+        enqueues the decode / collision check / sampling behind it.  Submitting batch i + 1 before collecting batch i
+        lets its FPS chain run underneath batch i's contractions (`FusedPointNet2.submit`)."""
         cloud = _F._f32c(cloud, "cloud")
         if cloud.dim() != 3 or cloud.size(1) != 3:
             raise RuntimeError("cloud must be (B, 3, n)")
@@ -129,7 +129,20 @@ class GraspDetector:
         self._mark("start")
         pts = self.pre_processing(cloud, seed)
         self._mark("pre_processing")
-        pred = self.run.submit({"scene_points": pts}, topk=self.topk).result()
+        h = self.run.submit({"scene_points": pts}, topk=self.topk)
+        return _Pending(self, h, pts, collision_cloud, num_selected, score_threshold, verticalness_threshold,
+                        collision_check, uniforms, generator)
+
+    def detect_device(self, cloud, num_selected=5, score_threshold=0.7, verticalness_threshold=0.2,
+                      collision_check=True, seed=None, uniforms=None, generator=None, collision_cloud=None):
+        """cloud (B, 3, n) fp32 on the device, REAL frame: what the network sees (the masked `target_cloud` of :199-203);
+        collision_cloud (B, 3, n_all): what the collision check sees (the whole `cloud_array`, :220-222; default: cloud)
+        -> `Detections`.  Nothing here waits for the device."""
+        return self.submit(cloud, num_selected, score_threshold, verticalness_threshold, collision_check, seed, uniforms,
+                           generator, collision_cloud).result()
+
+    def _finish(self, pred, pts, collision_cloud, num_selected, score_threshold, verticalness_threshold, collision_check,
+                uniforms, generator):
         self._mark("prediction")
         H, score, index, count = _post.detect_poses(
             pred, pts, score_threshold, verticalness_threshold, direction_matrix=self.direction_matrix,
@@ -139,8 +152,7 @@ class GraspDetector:
         dev = score.device
         if collision_check:
             # :213-234 -- against the WHOLE input cloud (`cloud_array`, not the subsample), analytic SE(3) inverse
-            ok, _ = _post.view_non_collision(H, collision_cloud, self.gripper, inverse="se3")
-            ok = ok & (torch.arange(K, device=dev).view(1, K) < count.view(B, 1))
+            ok, _ = _post.view_non_collision(H, collision_cloud, self.gripper, inverse="se3", count=count)
             order = torch.sort((~ok).to(torch.uint8), dim=1, stable=True)[1]       # survivors first, order kept
             H = torch.gather(H, 1, order.view(B, K, 1, 1).expand(-1, -1, 4, 4))
             score = torch.gather(score, 1, order)
@@ -196,6 +208,16 @@ class GraspDetector:
     def graph(self, example_cloud, **kw):
         """Record one `detect_device` call of `example_cloud`'s shape as a HIP graph: see `GraphedDetect`."""
         return GraphedDetect(self, example_cloud, kw)
+
+
+class _Pending:
+    """An in-flight `GraspDetector.submit`."""
+
+    def __init__(self, det, handle, pts, *rest):
+        self.det, self.handle, self.pts, self.rest = det, handle, pts, rest
+
+    def result(self):
+        return self.det._finish(self.handle.result(), self.pts, *self.rest)
 
 
 class GraphedDetect:

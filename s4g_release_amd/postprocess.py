@@ -303,13 +303,15 @@ def se3_inverse(poses):
     return out.contiguous()
 
 
-def view_non_collision(poses, scene_points, gripper=None, inverse="general"):
+def view_non_collision(poses, scene_points, gripper=None, inverse="general", count=None):
     """Batched `CloudCollisionChecker.view_non_collision`
     (cloud_processor/view_collision_checker.py:37-65) for all poses of all scenes
     in one launch.  poses (B,K,4,4) gripper->global frames; returns
     (ok (B,K) bool, counts (B,K,2) int32).  inverse="general": the inverse is taken in float64 and
     rounded to fp32 like the demo's caller (file_logger_cls.py:223-224); inverse="se3": the fp32
-    analytic SE(3) inverse the detector uses (grasp_detector.py:219, `se3_inverse`)."""
+    analytic SE(3) inverse the detector uses (grasp_detector.py:219, `se3_inverse`).
+    count (B,) int64 on the device (optional): only the first count[b] rows of scene b are poses (the padded best-first
+    lists of `detect_poses`); the other rows are not scanned, read ok = False and zero counts."""
     gripper = gripper or GripperConfig()
     xyz = _F._f32c(scene_points, "scene_points")
     B, _, N = xyz.shape
@@ -322,9 +324,16 @@ def view_non_collision(poses, scene_points, gripper=None, inverse="general"):
                                   gripper.half_hand_thickness, gripper.half_bottom_width,
                                   gripper.half_bottom_space, gripper.back_collision_margin)
     with torch.cuda.device(xyz.device):
-        rc = _cabi.lib().s4g_collision_counts_f32(xyz.data_ptr(), g2l.data_ptr(), B, N, K, params,
-                                                  counts.data_ptr(), _F._stream())
+        if count is None:
+            rc = _cabi.lib().s4g_collision_counts_f32(xyz.data_ptr(), g2l.data_ptr(), B, N, K, params,
+                                                      counts.data_ptr(), _F._stream())
+        else:
+            count = count.to(device=xyz.device, dtype=torch.int64).contiguous()
+            rc = _cabi.lib().s4g_collision_counts_n_f32(xyz.data_ptr(), g2l.data_ptr(), B, N, K, params,
+                                                        count.data_ptr(), counts.data_ptr(), _F._stream())
     _cabi.check(rc, "collision_counts")
     ok = (counts[..., 0] <= gripper.back_collision_threshold) & \
          (counts[..., 1] <= gripper.finger_collision_threshold)
+    if count is not None:
+        ok = ok & (torch.arange(K, device=xyz.device).view(1, K) < count.view(B, 1))
     return ok, counts

@@ -149,3 +149,21 @@ def test_intended_preprocessing_mode_runs_the_voxel_and_outlier_passes(dev):
     out = det.detect_device(cloud, score_threshold=0.6, verticalness_threshold=-2.0)
     torch.cuda.synchronize()
     assert int(out.candidates[3]) > 0
+
+
+def test_collision_counts_over_padded_lists_skip_the_padding_rows(dev):
+    """ABI 12 `s4g_collision_counts_n_f32`: with device-side counts the first count[b] rows get exactly the plain entry
+    point's counts and verdicts, the padding rows zero counts and ok = False."""
+    from s4g_release_amd import postprocess as PP, synth
+    rng = np.random.default_rng(4)
+    B, N, Kp = 3, 20000, 64
+    pts = torch.from_numpy(synth.make_batch([1, 2, 3], N)).to(dev)
+    pred = {k: torch.from_numpy(rng.standard_normal((B, c, N)).astype(np.float32)).to(dev)
+            for k, c in (("score", 3), ("frame_R", 9), ("frame_t", 4))}
+    H, _, _ = PP.decode_top_poses(pred, pts, Kp)
+    count = torch.tensor([64, 10, 0], device=dev)
+    ok_all, c_all = PP.view_non_collision(H, pts, inverse="se3")
+    ok_n, c_n = PP.view_non_collision(H, pts, inverse="se3", count=count)
+    for b, n in enumerate(count.tolist()):
+        assert torch.equal(c_n[b, :n], c_all[b, :n]) and torch.equal(ok_n[b, :n], ok_all[b, :n])
+        assert (c_n[b, n:] == 0).all() and not ok_n[b, n:].any()
