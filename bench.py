@@ -76,7 +76,7 @@ F16_MFMA_ATTAINABLE_TF = 1248.0
 # ... and the single-plane bf16 chains' loop (8 MFMAs per step and wave on four row blocks, configs[4]): 1 357 TFLOP/s
 BF16_MFMA_ATTAINABLE_TF = 1357.0
 GFLOP_PER_SCENE = 203.48       # SURVEY.md Appendix B (BN folded, 2*MAC), N = 25 600
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_traffic.json")
 
 
 def parse(argv=None):

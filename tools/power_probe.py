@@ -163,6 +163,9 @@ def main():
     ap.add_argument("--points", type=int, default=25600)
     ap.add_argument("--precision", default="f16x2")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--weights", default="calibrated", choices=["calibrated", "randomized"],
+                    help="calibrated (default): the golden run's network, activations that carry signal (bench.py's default); "
+                         "randomized: rounds 1-5's per-channel-constant network")
     args = ap.parse_args()
 
     import torch
@@ -172,10 +175,14 @@ def main():
 
     dev = torch.device("cuda:0")
     sensors = Sensors(getattr(torch.cuda.get_device_properties(0), "pci_bus_id", None))
-    torch.manual_seed(20260101)
-    net = build_pointnet2_cls(S4GConfig())
-    randomize_bn_(net, 20260102)
-    net = net.to(dev).eval()
+    if args.weights == "calibrated":
+        from tests import golden_util as GU
+        net = GU.shipped_net(dev)
+    else:
+        torch.manual_seed(20260101)
+        net = build_pointnet2_cls(S4GConfig())
+        randomize_bn_(net, 20260102)
+        net = net.to(dev).eval()
     runner = FusedPointNet2(net, precision=args.precision)
     pts = torch.from_numpy(synth.make_batch(list(range(args.batch)), args.points)).to(dev)
     batch = {"scene_points": pts}
