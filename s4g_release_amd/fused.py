@@ -136,6 +136,24 @@ class _Layer:
         self.Wfrag_bf16 = fragment_order(self.W3[:1])[:, :, :, 0].contiguous() if self.cout % 32 == 0 else None
 
 
+_STREAM_POOL = {}
+
+
+def _stream_pool(dev, n_geo, n_dense):
+    """The geometry / contraction streams of a device, shared by every FusedPointNet2 in the process.  HIP multiplexes
+    a process's streams onto a handful of hardware queues; a process that had built several runners (bench.py's legs:
+    one per precision / network) ended up with a runner whose geometry stream and contraction stream shared a hardware
+    queue -- the FPS chain then serialised with the contractions (configs[4]: 16.7 instead of 9.8 ms per step, round 6).
+    One set of streams per (device, counts): a second runner queues behind the first on the same streams, which is what
+    two users of one GPU want anyway."""
+    key = (str(dev), int(n_geo), int(n_dense))
+    pool = _STREAM_POOL.get(key)
+    if pool is None:
+        pool = _STREAM_POOL[key] = ([torch.cuda.Stream(device=dev, priority=-1) for _ in range(n_geo)],
+                                    [torch.cuda.Stream(device=dev) for _ in range(n_dense)])
+    return pool
+
+
 class FusedPointNet2:
     """Callable with the reference forward's signature: {"scene_points": (B,3,N)} -> dict."""
 
@@ -1007,9 +1025,7 @@ class FusedPointNet2:
             # S4G_DENSE_STREAMS=2 lets consecutive batches' contractions fill each
             # other's kernel tails (+1.5 % measured), the default of 1 keeps
             # per-kernel event timings clean
-            self._streams = ([torch.cuda.Stream(device=dev, priority=-1)
-                              for _ in range(self.geo_streams)],
-                             [torch.cuda.Stream(device=dev) for _ in range(self.dense_streams)])
+            self._streams = _stream_pool(dev, self.geo_streams, self.dense_streams)
             self._submitted = 0
         gs = self._streams[0][self._submitted % len(self._streams[0])]
         ds = self._streams[1][self._submitted % len(self._streams[1])]
