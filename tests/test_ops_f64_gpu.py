@@ -144,4 +144,4 @@ def test_reference_shaped_model_in_double(dev):
     for k in a:
         assert b[k].dtype == torch.float64
         # calibrated weights (outputs up to +-4 that depend on the input): fp32 through the modules vs the same in double
-        assert (a[k].double() - b[k]).abs().max().item() < 1e-4 * max(1.0, b[k].abs().max().item()), k
+        assert (a[k].double() - b[k]).abs().max().item() < GU.WIRING_TOL64 * max(1.0, b[k].abs().max().item()), k
