@@ -233,7 +233,9 @@ def test_nonfinite_scene_is_contained_and_refused_on_request(dev):
         torch.cuda.synchronize()
         alone = net({"scene_points": pts[2:3].contiguous()})
     for k in HEADS:
-        assert torch.isfinite(mod[k][2]).all() and (mod[k][2] - alone[k][0]).abs().max().item() <= 1e-4, k
+        # (torch's library convolutions may pick another kernel for another batch size: fp32 round-off apart, relative to scale)
+        assert torch.isfinite(mod[k][2]).all()
+        assert (mod[k][2] - alone[k][0]).abs().max().item() <= 1e-4 * max(1.0, alone[k].abs().max().item()), k
     with pytest.raises(ValueError, match=r"scene\(s\) \[1\]"):
         FusedPointNet2(net, check_finite=True)({"scene_points": pts})
     FusedPointNet2(net, check_finite=True)({"scene_points": pts[:1].contiguous()})
