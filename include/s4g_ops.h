@@ -53,7 +53,8 @@ extern "C" {
  *    (the backward scatters in a fixed order: run-to-run bit-identical, equal to the oracle's sequential sum).
  * 11: s4g_heads_desc_t.head_mask (a launch may evaluate a subset of the four heads).
  * 12: s4g_test_knobs_enabled (the A/B knobs below are ignored without S4G_TEST_KNOBS=1; no layout change),
- *     s4g_collision_counts_n_f32 (collision counts over padded best-first pose lists with device-side counts). */
+ *     s4g_collision_counts_n_f32 (collision counts over padded best-first pose lists with device-side counts),
+ *     s4g_sort_pairs_u32 / s4g_exclusive_scan_i32 (the library's own stable radix sort and scan). */
 #define S4G_ABI_VERSION 12
 
 /* ---------------------------------------------------------------------------
@@ -671,6 +672,18 @@ int s4g_collision_counts_n_f32(const float *xyz_b3n, const float *g2l_bk44, int6
  *   RemoveRadiusOutliers.  keep_n[j] = 1 iff more than nb_points points (j itself
  *   included) lie at squared distance < radius^2 (canonical fp32 arithmetic).
  *   Workspace: s4g_radius_outlier_workspace_bytes(N) (0 for N > 65536: scan). */
+/* ABI 12: the library's own device primitives behind the deterministic scatters and the voxel down-sample (round 6:
+ * csrc/radix_sort.hip replaces rocPRIM's): a STABLE least-significant-digit radix sort of n (uint32 key, uint32 value)
+ * pairs on the low `bits` key bits (8 bits per pass; equal keys keep their input order) -- result in keys_out / vals_out,
+ * keys_in / vals_in are clobbered -- and an int32 exclusive scan (out must not alias in).  No counterpart in the
+ * reference (which leaves order to atomicAdd / open3d's hash map). */
+size_t s4g_sort_pairs_workspace_bytes(int64_t n);
+int s4g_sort_pairs_u32(uint32_t *keys_in, uint32_t *vals_in, int64_t n, int bits, uint32_t *keys_out,
+                       uint32_t *vals_out, void *ws, size_t ws_bytes, s4g_stream_t stream);
+size_t s4g_exclusive_scan_workspace_bytes(int64_t n);
+int s4g_exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, void *ws, size_t ws_bytes,
+                           s4g_stream_t stream);
+
 int s4g_crop_indices_f32(const float *xyz_3n, int64_t N, const float *workspace6,
                          int32_t *index_n, int32_t *count, s4g_stream_t stream);
 size_t s4g_voxel_down_sample_workspace_bytes(int64_t N);

@@ -14,6 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("S4G_HIP_LIB") or os.path.join(_HERE, "libs4g_hip.so")
 
 S4G_ABI_VERSION = 12
+S4G_EINVAL = -1
+S4G_EWORKSPACE = -2
 S4G_EUNSUPPORTED = -3
 S4G_FLAG_FMAD = 1
 S4G_OP_FPS, S4G_OP_BALL_QUERY, S4G_OP_THREE_NN = 1, 2, 3
@@ -108,6 +110,10 @@ SIGNATURES = {
                                         _vp, _vp]),
     "s4g_collision_counts_n_f32": (_int, [_vp, _vp, _i64, _i64, _i64, ctypes.POINTER(ctypes.c_float),
                                           _vp, _vp, _vp]),
+    "s4g_sort_pairs_workspace_bytes": (_sz, [_i64]),
+    "s4g_sort_pairs_u32": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
+    "s4g_exclusive_scan_workspace_bytes": (_sz, [_i64]),
+    "s4g_exclusive_scan_i32": (_int, [_vp, _vp, _i64, _vp, _sz, _vp]),
     "s4g_query_group_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _vp, _sz,
                                    _int, _vp]),
     "s4g_crop_indices_f32": (_int, [_vp, _i64, ctypes.POINTER(ctypes.c_float), _vp, _vp, _vp]),

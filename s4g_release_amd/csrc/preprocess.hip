@@ -23,8 +23,7 @@
 // ball query's cell grid (grid.h) with cell edge = radius.
 #include <string.h>
 
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
+#include "radix_sort.h"
 
 #include "grid.h"
 #include "s4g_common.h"
@@ -196,11 +195,7 @@ struct VoxelWs {
 
 static VoxelWs voxel_ws(void* base, int64_t N) {
   VoxelWs w;
-  size_t sort_bytes = 0, scan_bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  (int*)nullptr, (int*)nullptr, (size_t)N);
-  (void)rocprim::exclusive_scan(nullptr, scan_bytes, (int*)nullptr, (int*)nullptr, 0, (size_t)N,
-                                rocprim::plus<int>());
+  const size_t sort_bytes = radix_sort_ws_bytes((size_t)N), scan_bytes = scan_ws_bytes((size_t)N);
   w.tmp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
   char* p = (char*)base;
   size_t off = 0;
@@ -257,15 +252,16 @@ extern "C" int s4g_voxel_down_sample_f32(const float* xyz_3n, int64_t N, float v
   hipLaunchKernelGGL(voxel_key_kernel, dim3(blocks), dim3(threads), 0, st, xyz_3n, (int)N, origin3[0],
                      origin3[1], origin3[2], voxel, dims3[0], dims3[1], dims3[2], w.key_in, w.idx_in);
   S4G_LAUNCH_CHECK();
-  size_t tb = w.tmp_bytes;
-  hipError_t e = rocprim::radix_sort_pairs(w.tmp, tb, w.key_in, w.key_out, w.idx_in, w.idx_out,
-                                           (size_t)N, 0, 32, st);
-  if (e != hipSuccess) return (int)e;
+  const uint64_t cells = (uint64_t)dims3[0] * (uint64_t)dims3[1] * (uint64_t)dims3[2];
+  unsigned bits = 1;
+  while (bits < 32 && (1ull << bits) < cells) ++bits;      // the cell keys run 0 .. cells - 1
+  int e = radix_sort_pairs(w.tmp, w.tmp_bytes, w.key_in, w.key_out, (uint32_t*)w.idx_in, (uint32_t*)w.idx_out,
+                           (size_t)N, bits, st);
+  if (e != (int)hipSuccess) return e;
   hipLaunchKernelGGL(voxel_head_kernel, dim3(blocks), dim3(threads), 0, st, w.key_out, (int)N, w.head);
   S4G_LAUNCH_CHECK();
-  tb = w.tmp_bytes;
-  e = rocprim::exclusive_scan(w.tmp, tb, w.head, w.rank, 0, (size_t)N, rocprim::plus<int>(), st);
-  if (e != hipSuccess) return (int)e;
+  e = exclusive_scan_i32(w.tmp, w.tmp_bytes, w.head, w.rank, (size_t)N, st);
+  if (e != (int)hipSuccess) return e;
   hipLaunchKernelGGL(voxel_mean_kernel, dim3(blocks), dim3(threads), 0, st, xyz_3n, (int)N, w.key_out,
                      w.idx_out, w.head, w.rank, out_3n, (int)N, count);
   S4G_LAUNCH_CHECK();

@@ -11,13 +11,12 @@
 // get an exact 0.  The atomic kernels stay (csrc/group.hip, csrc/interpolate.hip): fewer passes,
 // undefined order.
 //
-// Work: one radix sort of B T 8-byte pairs (rocPRIM device radix sort: the toolchain's primitive, as
-// in csrc/preprocess.hip), two binary searches per target, then for every (scene, channel) row one
+// Work: one radix sort of B T 8-byte pairs (csrc/radix_sort.hip: the repo's own stable LSD sort since round 6 --
+// rocPRIM's device radix sort before), two binary searches per target, then for every (scene, channel) row one
 // coalesced sweep over the targets whose reads of the row's T gradients land in L2 (a row is
 // T x 4 bytes: 1.3 MB at the first SA level).
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
-
+#include "radix_sort.h"
 #include "s4g_common.h"
 
 namespace s4g {
@@ -164,9 +163,7 @@ static int key_bits(int64_t BN) {   // keys run 0 .. B N (the sentinel)
 static ScatterWs scatter_ws(void* base, int64_t B, int64_t N, int64_t T, int64_t C = 0, int64_t S = 0) {
   ScatterWs w;
   const size_t BT = (size_t)(B * T), BN = (size_t)(B * N);
-  size_t sort_bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  (uint32_t*)nullptr, BT, 0, (unsigned)key_bits((int64_t)BN));
+  const size_t sort_bytes = radix_sort_ws_bytes(BT);
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
   char* p = (char*)base;
   size_t off = 0;
@@ -203,9 +200,8 @@ static int scatter_det(const float* gout, const int64_t* idx, const float* wgt, 
   hipLaunchKernelGGL(scatter_keys_kernel, dim3((unsigned)((BT + SC_THREADS - 1) / SC_THREADS)), dim3(SC_THREADS), 0, st,
                      idx, BT, T, N, (uint32_t)BN, w.keys_in, w.vals_in);
   S4G_LAUNCH_CHECK();
-  size_t tb = w.tmp_bytes;
-  if (rocprim::radix_sort_pairs(w.tmp, tb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)BT, 0,
-                                (unsigned)key_bits(BN), st) != hipSuccess)
+  if (radix_sort_pairs(w.tmp, w.tmp_bytes, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)BT,
+                       (unsigned)key_bits(BN), st) != (int)hipSuccess)
     return S4G_EINVAL;
   hipLaunchKernelGGL(scatter_starts_kernel, dim3((unsigned)((BN + 1 + SC_THREADS - 1) / SC_THREADS)), dim3(SC_THREADS), 0,
                      st, w.keys_out, BT, BN, w.start);
