@@ -644,12 +644,15 @@ int s4g_decode_poses_f32(const float *xyz_b3n, const float *frame_R_b9n,
 int s4g_collision_counts_f32(const float *xyz_b3n, const float *g2l_bk44, int64_t B,
                              int64_t N, int64_t K, const float *gripper6,
                              int32_t *counts_bk2, s4g_stream_t stream);
-/* ABI 12: the same over best-first pose lists padded to K rows: only the first pose_count_b[b] (DEVICE int64, (B,)) rows
- * of scene b are poses -- the rest get zero counts without scanning the cloud (detector.GraspDetector: K = 2 048 rows,
- * a few dozen to a few hundred of them poses; the counts never visit the host). */
+/* ABI 12: the same over best-first pose lists padded to K rows: only the first pose_count_b[b] (DEVICE int64, (B,); NULL =
+ * all K) rows of scene b are poses -- the rest get zero counts without scanning the cloud (detector.GraspDetector: K =
+ * 2 048 rows, a few dozen to a few hundred of them poses; the counts never visit the host) -- a workgroup walks several
+ * poses, so the launch stays small.  invert_se3 = 1: the matrices are the POSES themselves (gripper -> global) and the
+ * kernel forms their analytic SE(3) inverse [R^T | -R^T t] in fp32, the form grasp_detector.py:219 feeds the check
+ * (torch_batch_transformation_inv, utils/math_utils.py:26-40), instead of the caller. */
 int s4g_collision_counts_n_f32(const float *xyz_b3n, const float *g2l_bk44, int64_t B, int64_t N,
                                int64_t K, const float *gripper6, const int64_t *pose_count_b,
-                               int32_t *counts_bk2, s4g_stream_t stream);
+                               int invert_se3, int32_t *counts_bk2, s4g_stream_t stream);
 
 /* ---- next row f3: cloud pre-processing on device -------------------------
  * Single-scene passes in front of the network (reference

@@ -109,7 +109,7 @@ SIGNATURES = {
     "s4g_collision_counts_f32": (_int, [_vp, _vp, _i64, _i64, _i64, ctypes.POINTER(ctypes.c_float),
                                         _vp, _vp]),
     "s4g_collision_counts_n_f32": (_int, [_vp, _vp, _i64, _i64, _i64, ctypes.POINTER(ctypes.c_float),
-                                          _vp, _vp, _vp]),
+                                          _vp, _int, _vp, _vp]),
     "s4g_sort_pairs_workspace_bytes": (_sz, [_i64]),
     "s4g_sort_pairs_u32": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
     "s4g_exclusive_scan_workspace_bytes": (_sz, [_i64]),
