@@ -40,6 +40,10 @@ python3 $R/tools/power_probe.py --seconds 1.5 --points 51200 --batch 32 --precis
 rocprofv3 --kernel-trace --stats -d $O/stats_randomized -o run -- python3 $R/bench.py --weights randomized --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_randomized_profiled.json 2> $O/err_randomized.txt
 db=$(find $O/stats_randomized -name "*.db" | head -1)
 [ -n "$db" ] && python3 $R/tools/rocpd_summary.py $db 45 > $O/randomized_kernel_stats.md
+# the production entry: 25 pipelined GraspDetector steps (tools/detect_loop.py)
+rocprofv3 --kernel-trace --stats -d $O/stats_detect -o run -- python3 $R/tools/detect_loop.py 25 > $O/detect_loop.txt 2> $O/err_detect.txt
+db=$(find $O/stats_detect -name "*.db" | head -1)
+[ -n "$db" ] && python3 $R/tools/rocpd_summary.py $db 40 > $O/detect_kernel_stats.md
 # un-profiled lines of the same build, for the record
 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_default.json 2>/dev/null
 python3 $R/bench.py $CFG4 --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_cfg4.json 2>/dev/null
