@@ -60,7 +60,9 @@ class GraspDetector:
         topk: points per scene whose pose heads are evaluated (the K best expected scores).  The result equals the
         full-forward detection whenever fewer than K points of a scene pass the score threshold (always, for a
         threshold of 0.7 on a trained network: the reference then keeps a few hundred).
-        camera2base: (4, 4) camera -> robot base (the reference's `realworld.camera2base`, :155); identity if None."""
+        camera2base: (4, 4) camera -> robot base (the reference's `realworld.camera2base`, :155); identity if None.
+        seed: of the subsample (scene b of a batch uses seed + b; every call may pass its own).  The reference draws
+        unseeded (`np.random.choice`, :86-89); here the same cloud with the same seed gives the same detections."""
         self.run = net if isinstance(net, FusedPointNet2) else FusedPointNet2(net, precision=precision)
         if preprocess not in ("shipped", "intended"):
             raise ValueError("preprocess must be 'shipped' or 'intended'")

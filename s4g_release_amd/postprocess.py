@@ -244,7 +244,10 @@ def detect_poses(predictions, scene_points, score_threshold=0.7, verticalness_th
                                               H.data_ptr(), _F._stream())
     _cabi.check(rc, "decode_poses")
     fr = _small_on_device(frame, torch.float32, dev)
-    H = torch.matmul(fr.view(1, 1, 4, 4), H)
+    # frame @ H for every pose: a broadcast multiply + sum over the 4-long contraction (one elementwise kernel + one
+    # reduction) -- `torch.matmul` dispatches 32 768 4x4 products to a batched library GEMM: 0.52 ms per call in the
+    # detect loop's kernel trace (profiles/r06_detect_kernel_stats.md)
+    H = (fr.view(1, 1, 4, 4, 1) * H.unsqueeze(2)).sum(dim=3)
     valid = torch.arange(K, device=dev).view(1, K) < count.view(B, 1)
     H = torch.where(valid.view(B, K, 1, 1), H, torch.zeros_like(H))
     top = torch.where(valid, top, torch.zeros_like(top))
