@@ -27,19 +27,34 @@ def _run(args, tmp_path):
 
 
 def test_run_scene_on_the_reference_sample_scene_matches_the_golden_outputs(tmp_path):
-    g = GU.load("pn2_real.npz")
+    """Default weights = the calibrated golden run's network: the harness's written predictions against what the
+    REFERENCE's network produced for this scene (tests/golden/pn2_calib_full.npz, scene "real"), 1e-4 of scale."""
+    g = GU.load("pn2_calib_full.npz")
     cloud = tmp_path / "scene.npy"
-    np.save(cloud, g["points"][0])                       # (3, 25600): already the seeded subsample
+    np.save(cloud, GU.calib_scenes(g)["real"][0])        # (3, 25600): the seeded subsample of the reference's sample scene
     pred = tmp_path / "pred.npz"
     rep = _run([str(cloud), "--reps", "3", "--out", str(pred), "--topk", "10"], tmp_path)
     assert rep["points"] == 25600 and rep["source_points"] == 25600 and rep["precision"] == "f16x2"
+    assert rep["weights"] == "calibrated"
     assert rep["forward_ms"]["p10"] <= rep["forward_ms"]["median"] <= rep["forward_ms"]["p90"]
     assert rep["scenes_per_sec"] > 10 and rep["outputs"]["frame_R"] == [1, 9, 25600]
+    z = np.load(pred)
+    GU.calib_compare_full(g, "real", {k: z[k] for k in GU.HEADS}, {}, need_levels=())
+    assert z["pose_H"].shape == (1, 10, 4, 4) and (np.diff(z["pose_score"][0]) <= 0).all()
+    assert float(np.ptp(z["pose_score"][0])) > 1e-4      # the decoded scores have an order (a flat score head would tie)
+
+
+def test_run_scene_seeded_weights_still_match_the_index_pinning_fixture(tmp_path):
+    g = GU.load("pn2_real.npz")
+    cloud = tmp_path / "scene.npy"
+    np.save(cloud, g["points"][0])
+    pred = tmp_path / "pred.npz"
+    rep = _run([str(cloud), "--reps", "2", "--out", str(pred), "--weights", "seeded"], tmp_path)
+    assert rep["weights"].startswith("seeded random")
     z = np.load(pred)
     pos = g["positions"]
     for k in ("score", "frame_R", "frame_t", "movable_logits"):
         assert np.max(np.abs(z[k][:, :, pos] - g["out/" + k])) < 1e-4, k
-    assert z["pose_H"].shape == (1, 10, 4, 4) and (np.diff(z["pose_score"][0]) <= 0).all()
 
 
 def test_run_scene_subsamples_larger_and_smaller_clouds_reproducibly(tmp_path):

@@ -71,7 +71,11 @@ def main():
     ap.add_argument("cloud")
     ap.add_argument("--points", type=int, default=25600)
     ap.add_argument("--seed", type=int, default=2638)
-    ap.add_argument("--weights", default=None)
+    ap.add_argument("--weights", default="calibrated",
+                    help="a reference-format checkpoint (.pth: torch.save({'model': state_dict})), 'calibrated' (default: the "
+                         "golden run's network of tests/golden/pn2_calib_full.npz -- seeded convolutions, BatchNorm statistics "
+                         "calibrated through the reference's own modules: outputs that depend on the input; no trained checkpoint "
+                         "ships with the reference) or 'seeded' (default init + randomize_bn_: per-channel-constant outputs)")
     ap.add_argument("--model-seed", type=int, default=20260101)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--precision", default=None)
@@ -89,12 +93,17 @@ def main():
 
     cloud = load_cloud(args.cloud)
     pts = subsample(cloud, args.points, args.seed)[None]                      # (1, 3, N)
-    torch.manual_seed(args.model_seed)
-    net = build_pointnet2_cls(S4GConfig())
-    if args.weights:
-        load_checkpoint(net, args.weights)
+    if args.weights == "calibrated":
+        sys.path.insert(0, ROOT)
+        from tests import golden_util as GU      # data fixture (BatchNorm tensors by value, sha-checked), not the oracle
+        net = GU.calib_full_model()
     else:
-        randomize_bn_(net, args.model_seed + 1)
+        torch.manual_seed(args.model_seed)
+        net = build_pointnet2_cls(S4GConfig())
+        if args.weights == "seeded":
+            randomize_bn_(net, args.model_seed + 1)
+        else:
+            load_checkpoint(net, args.weights)
     net = net.to(dev).eval()
     run = FusedPointNet2(net, precision=args.precision)
 
@@ -119,7 +128,7 @@ def main():
     ts.sort()
     q = lambda f: ts[min(len(ts) - 1, int(round(f * (len(ts) - 1))))]
     report = {"cloud": args.cloud, "source_points": int(cloud.shape[1]), "points": int(pts.shape[2]),
-              "subsample_seed": args.seed, "weights": args.weights or "seeded random (%d)" % args.model_seed,
+              "subsample_seed": args.seed, "weights": args.weights if args.weights != "seeded" else "seeded random (%d)" % args.model_seed,
               "precision": run.precision, "forward_ms": {"median": round(q(0.5), 3), "p10": round(q(0.1), 3),
                                                          "p90": round(q(0.9), 3), "reps": args.reps},
               "scenes_per_sec": round(1e3 / q(0.5), 2), "h2d_ms": round(h2d_ms, 4),
