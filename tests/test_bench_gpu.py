@@ -40,6 +40,11 @@ def test_bench_prints_one_contract_line():
     assert c["max_err_over_scale_gpu_vs_float64"] < 1e-4
     assert c["max_err_over_scale_gpu_vs_cpu"] < 1e-4 + c["max_err_over_scale_cpu_vs_float64"]
     assert d["config"]["weights"] == "calibrated" and d["weights_leg"]["weights"] == "randomized"
+    det = d["detect"]                      # the reference's production entry composed on the device (detector.GraspDetector)
+    assert det["unit"] == "scenes/sec" and det["value"] > 0 and det["candidates_per_scene_mean"] > 0
+    assert list(det["stage_ms_b1"]) == ["pre_processing", "prediction", "post_processing", "collision_check",
+                                        "importance_sampling"]
+    assert 0 < det["latency_ms_b1_graph"] < 50 and 0 < det["latency_ms_b1"] < 50
     p = d["roofline_ball_query_group_points"]
     assert p["bound"] == "hbm" and p["unit"] == "GB/s" and 0 < p["frac"] < 1
     assert ("traffic_source" in r) != ("traffic_note" in r)      # measured on this build, or null + why
