@@ -123,3 +123,28 @@ def test_oracle_forward_reproduces_calibrated_reference_full():
             assert GU.sha(inter["%s%d" % (n, li)]) == str(g["%s%d_sha256/real" % (n, li)]), (n, li)
     worst = GU.calib_compare_full(g, "real", out, {lv: inter["feat_" + lv] for lv in GU.LEVELS}, tol=1e-5)
     print({k: "%.1e" % v for k, v in worst.items()})
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/inference"),
+                    reason="the reference tree exists in the build container only")
+def test_committed_small_fixture_is_what_the_reference_network_produces(tmp_path):
+    """Provenance: tools/gen_golden_calib.py's reduced-config part re-run HERE (child process: it imports the reference's
+    PointNet2 over the oracle stand-in) gives the committed tests/golden/pn2_calib_small.npz array for array -- weights,
+    calibrated BatchNorm statistics, the reference network's outputs, all six level feature tensors, the index tensors."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from tools import gen_golden_calib as G; G.gen_small(%r)"
+            % (root, str(tmp_path)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    new = np.load(os.path.join(str(tmp_path), "pn2_calib_small.npz"), allow_pickle=False)
+    old = GU.load("pn2_calib_small.npz")
+    assert sorted(new.files) == sorted(old.files)
+    for k in old.files:
+        if old[k].dtype.kind in "fc":
+            # same torch CPU kernels, same thread count as the generating run is not guaranteed: fp32 round-off apart
+            assert np.allclose(new[k], old[k], rtol=0, atol=2e-6 * max(1.0, float(np.abs(old[k]).max()))), k
+        else:
+            assert np.array_equal(new[k], old[k]), k

@@ -79,17 +79,27 @@ def spread_check(name, a, strict=True):
     return std
 
 
-def main():
-    install_standin_pn2_ext()
-    sys.path.insert(0, REF)
-    from grasp_proposal.network_models.models.PointNet2_tcls import PointNet2 as RefPointNet2
-    from grasp_proposal.network_models.models.pointnet2_utils import functions as ref_F
-    from tests.ref64 import forward64
-    out_dir = os.environ.get("S4G_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden"))
-    torch.set_num_threads(8)
-    captured = {}
-    capture_indices(ref_F, captured)
+_CTX = {}
 
+
+def setup():
+    """Import the reference network (once) over the oracle stand-in; returns (RefPointNet2, captured index dict)."""
+    if not _CTX:
+        install_standin_pn2_ext()
+        sys.path.insert(0, REF)
+        from grasp_proposal.network_models.models.PointNet2_tcls import PointNet2 as RefPointNet2
+        from grasp_proposal.network_models.models.pointnet2_utils import functions as ref_F
+        torch.set_num_threads(8)
+        captured = {}
+        capture_indices(ref_F, captured)
+        _CTX.update(net=RefPointNet2, captured=captured)
+    return _CTX["net"], _CTX["captured"]
+
+
+def gen_small(out_dir):
+    """tests/golden/pn2_calib_small.npz (a few seconds; tests/test_reference_dropin.py regenerates it and compares)."""
+    RefPointNet2, captured = setup()
+    from tests.ref64 import forward64
     # ---------------- reduced config: everything stored
     seed = 4321
     torch.manual_seed(seed)
@@ -134,6 +144,11 @@ def main():
     print("pn2_calib_small.npz:", {k: "std/|max| %.2f" % (blob["out/" + k].std(axis=2).mean() / np.abs(blob["out/" + k]).max())
                                    for k in HEADS})
 
+
+def gen_full(out_dir):
+    """tests/golden/pn2_calib_full.npz (about two minutes)."""
+    RefPointNet2, captured = setup()
+    from tests.ref64 import forward64
     # ---------------- shipped config, two scenes
     seed = 20260606
     torch.manual_seed(seed)
@@ -199,6 +214,12 @@ def main():
     np.savez_compressed(os.path.join(out_dir, "pn2_calib_full.npz"), **blob)
     print("pn2_calib_full.npz: %d BatchNorm tensors by value, %d positions, levels %s" % (
         sum(1 for k in blob if k.startswith("bn/")), len(pos), sorted(feats)))
+
+
+def main():
+    out_dir = os.environ.get("S4G_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden"))
+    gen_small(out_dir)
+    gen_full(out_dir)
 
 
 if __name__ == "__main__":
